@@ -1,0 +1,435 @@
+// aasm_paf.cpp -- host codec: PAF reader, short-form cs:Z codec, 15-column writers.
+//
+// Own implementation of the behaviour of the reference's host I/O around the hot path
+// (SURVEY.md 8(f) row f1), needed so `alignasm <input.paf>` and the three output files
+// stay drop-in:
+//   reader ................ src/alignasm.cpp:76-183
+//   parse_short_cs ........ src/paf_data.cpp:29-72
+//   get_overlap_range ..... src/paf_data.cpp:90-123
+//   get_edited_paf_data ... src/paf_data.cpp:125-220
+//   writers ............... src/alignasm.cpp:398-490 (field list: SURVEY.md Appendix D)
+// The reference reads/writes through csv-parser 2.2.1; its quoting of fields that hold a
+// tab/quote/newline is not reproduced (parity-unpinned, irrelevant for PAF).
+#include "aasm_paf.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string_view>
+#include <unordered_map>
+
+namespace aasm {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const char *last_error_cstr() { return g_last_error.c_str(); }
+
+static inline bool cs_is_alpha(char c) { return std::isalpha(static_cast<unsigned char>(c)) != 0; }
+
+// paf_data.cpp:29-72.  `cs` points at "cs:Z:...".
+bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err) {
+    ops.clear();
+    if (len < 5 || std::memcmp(cs, "cs:Z:", 5) != 0) {
+        err = "PAF record does not contain a short-form cs:Z tag";
+        return false;
+    }
+    int64_t pos = 5;
+    while (pos < len) {
+        const int64_t op_start = pos;
+        const char type = cs[pos++];
+        int64_t length = 0;
+        if (type == ':') {
+            int64_t p = pos;
+            // std::from_chars(int64): optional '-', digits
+            bool neg = false;
+            if (p < len && cs[p] == '-') { neg = true; p++; }
+            int64_t dstart = p;
+            while (p < len && cs[p] >= '0' && cs[p] <= '9') { length = length * 10 + (cs[p] - '0'); p++; }
+            if (p == dstart || neg || length <= 0) { err = "Invalid :length operation in cs tag"; return false; }
+            pos = p;
+        } else if (type == '*') {
+            if (pos + 2 > len || !cs_is_alpha(cs[pos]) || !cs_is_alpha(cs[pos + 1])) {
+                err = "Invalid substitution operation in cs tag";
+                return false;
+            }
+            pos += 2;
+            length = 1;
+        } else if (type == '+' || type == '-') {
+            const int64_t seq_start = pos;
+            while (pos < len && cs_is_alpha(cs[pos])) ++pos;
+            length = pos - seq_start;
+            if (length == 0) { err = "Empty indel operation in cs tag"; return false; }
+        } else {
+            err = "Unsupported operation in short-form cs tag";
+            return false;
+        }
+        ops.push_back(CsOp{type, length, (int32_t)op_start, (int32_t)(pos - op_start)});
+    }
+    return true;
+}
+
+// paf_data.cpp:90-123.  Appends ranges; returns count or -1.
+static int64_t match_ranges(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end,
+                            int64_t ref_str, int64_t ref_end, std::vector<int64_t> *ql, std::vector<int64_t> *qr,
+                            std::vector<int64_t> *rl, std::vector<CsOp> &ops, std::string &err) {
+    if (!parse_short_cs(cs, cs_len, ops, err)) return -1;
+    const int64_t ref_step = aln_fwd ? 1 : -1;
+    int64_t ref_index = ref_str, qry_index = qry_str, n = 0;
+    const int64_t nops = (int64_t)ops.size();
+    for (int64_t t = 0; t < nops; t++) {
+        const CsOp &op = aln_fwd ? ops[t] : ops[nops - 1 - t];     // query orientation, :75-86
+        if (op.type == ':') {
+            if (ql) { ql->push_back(qry_index); qr->push_back(qry_index + op.length - 1); rl->push_back(ref_index); }
+            n++;
+            ref_index += op.length * ref_step;
+            qry_index += op.length;
+        } else if (op.type == '+') qry_index += op.length;
+        else if (op.type == '-') ref_index += op.length * ref_step;
+        else { ref_index += ref_step; qry_index += 1; }
+    }
+    if (qry_index != qry_end + 1 || ref_index != ref_end + ref_step) {
+        err = "cs tag consumption does not match PAF coordinates";
+        return -1;
+    }
+    return n;
+}
+
+struct Edit { std::string cs; int32_t mat_num, aln_len; bool is_cut; };
+
+// paf_data.cpp:125-220
+static bool edit_cs(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end,
+                    int32_t mat_num, int32_t aln_len, int64_t eq_s, int64_t eq_e, int64_t er_s, int64_t er_e,
+                    Edit &out, std::vector<CsOp> &ops, std::string &err) {
+    const bool is_cut = eq_s != qry_str || eq_e != qry_end;
+    if (!is_cut) {
+        out.cs.assign(cs, cs_len);
+        out.mat_num = mat_num; out.aln_len = aln_len; out.is_cut = false;
+        return true;
+    }
+    if (!parse_short_cs(cs, cs_len, ops, err)) return false;
+    struct Kept { char type; int64_t length; int32_t off, len; };
+    std::vector<Kept> kept;
+    int64_t qry_index = qry_str;
+    const int64_t nops = (int64_t)ops.size();
+    for (int64_t t = 0; t < nops; t++) {
+        const CsOp &op = aln_fwd ? ops[t] : ops[nops - 1 - t];
+        if (op.type == ':') {
+            const int64_t op_end = qry_index + op.length - 1;
+            const int64_t rs = std::max(qry_index, eq_s), re = std::min(op_end, eq_e);
+            if (rs <= re) kept.push_back(Kept{':', re - rs + 1, 0, 0});
+            qry_index += op.length;
+        } else if (op.type == '+') {
+            const int64_t op_end = qry_index + op.length - 1;
+            const bool overlaps = qry_index <= eq_e && eq_s <= op_end;
+            if (overlaps) {
+                if (qry_index < eq_s || eq_e < op_end) { err = "Alignment was clipped inside a cs insertion"; return false; }
+                kept.push_back(Kept{'+', op.length, op.text_off, op.text_len});
+            }
+            qry_index += op.length;
+        } else if (op.type == '*') {
+            if (eq_s <= qry_index && qry_index <= eq_e) kept.push_back(Kept{'*', 1, op.text_off, op.text_len});
+            qry_index += 1;
+        } else {
+            if (eq_s < qry_index && qry_index <= eq_e) kept.push_back(Kept{'-', op.length, op.text_off, op.text_len});
+        }
+    }
+    if (!aln_fwd) std::reverse(kept.begin(), kept.end());
+    out.cs = "cs:Z:"; out.mat_num = 0; out.aln_len = 0; out.is_cut = true;
+    int64_t query_bases = 0, reference_bases = 0;
+    char buf[32];
+    for (const auto &k : kept) {
+        if (k.type == ':') {
+            int n = std::snprintf(buf, sizeof buf, ":%lld", (long long)k.length);
+            out.cs.append(buf, n);
+            out.mat_num += (int32_t)k.length; out.aln_len += (int32_t)k.length;
+            query_bases += k.length; reference_bases += k.length;
+        } else {
+            out.cs.append(cs + k.off, k.len);
+            if (k.type == '+') { query_bases += k.length; out.aln_len += (int32_t)k.length; }
+            else if (k.type == '-') { reference_bases += k.length; out.aln_len += (int32_t)k.length; }
+            else { query_bases += 1; reference_bases += 1; out.aln_len += 1; }
+        }
+    }
+    const int64_t exp_q = eq_e - eq_s + 1, exp_r = std::llabs(er_e - er_s) + 1;
+    if (query_bases != exp_q || reference_bases != exp_r) { err = "Edited cs tag does not match edited PAF coordinates"; return false; }
+    return true;
+}
+
+// ---- reader (alignasm.cpp:76-183) ---------------------------------------------------
+static bool parse_i64(std::string_view f, int64_t &v) {
+    if (f.empty()) return false;
+    char *endp = nullptr;
+    std::string tmp(f);
+    v = std::strtoll(tmp.c_str(), &endp, 10);
+    return endp && *endp == '\0';
+}
+
+static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
+    std::unordered_map<std::string, int32_t> chr_map;
+    std::string ctg_chr;
+    std::vector<std::string_view> f;
+    std::vector<CsOp> ops;
+    int32_t row_global_index = 0;
+    paf.ctg_rec_off.assign(1, 0);
+    paf.cs_off.assign(1, 0);
+    paf.rec_rng_off.assign(1, 0);
+    int64_t p = 0;
+    while (p < len) {
+        const char *nl = (const char *)std::memchr(text + p, '\n', len - p);
+        int64_t e = nl ? (nl - text) : len;
+        int64_t le = e;
+        if (le > p && text[le - 1] == '\r') le--;
+        if (le > p) {
+            f.clear();
+            int64_t s = p;
+            for (int64_t i = p; i <= le; i++)
+                if (i == le || text[i] == '\t') { f.emplace_back(text + s, i - s); s = i + 1; }
+            if (f.size() < 12) { paf.error = "PAF row " + std::to_string(row_global_index) + " has fewer than 12 columns"; return AASM_E_PARSE; }
+            std::string qry_chr(f[0]), ref_chr(f[5]);
+            if (ctg_chr.empty()) ctg_chr = qry_chr;                    // :115-117
+            auto it = chr_map.find(ref_chr);
+            int32_t chr_id;
+            if (it == chr_map.end()) { chr_id = (int32_t)paf.chr_name.size(); chr_map.emplace(ref_chr, chr_id); paf.chr_name.push_back(ref_chr); }
+            else chr_id = it->second;
+            if (ctg_chr != qry_chr) {                                  // :125-133
+                paf.ctg_name.push_back(ctg_chr);
+                paf.ctg_rec_off.push_back(paf.n_records());
+                ctg_chr = qry_chr;
+            }
+            int64_t qtot, qs, qe, rtot, rs, re, mq, mat, aln;
+            if (!parse_i64(f[1], qtot) || !parse_i64(f[2], qs) || !parse_i64(f[3], qe) || !parse_i64(f[6], rtot) ||
+                !parse_i64(f[7], rs) || !parse_i64(f[8], re) || !parse_i64(f[9], mat) || !parse_i64(f[10], aln) ||
+                !parse_i64(f[11], mq)) {
+                paf.error = "PAF row " + std::to_string(row_global_index) + ": non-numeric field";
+                return AASM_E_PARSE;
+            }
+            qe--; re--;                                                // closed intervals, :141-151
+            bool fwd = !f[4].empty() && f[4][0] == '+';
+            if (!fwd) std::swap(rs, re);                               // :155-159
+            std::string_view cs;
+            for (size_t i = 12; i < f.size(); i++)                     // find_cs_tag, :100-108
+                if (f[i].size() >= 5 && f[i].substr(0, 5) == "cs:Z:") { cs = f[i]; break; }
+            if (cs.empty()) { paf.error = "Missing cs:Z tag in PAF record for query '" + qry_chr + "'"; return AASM_E_PARSE; }
+            std::string err;
+            int64_t nr = match_ranges(cs.data(), (int64_t)cs.size(), fwd, qs, qe, rs, re, &paf.rng_qry_l, &paf.rng_qry_r, &paf.rng_ref_l, ops, err);
+            if (nr < 0) { paf.error = err + " (row " + std::to_string(row_global_index) + ")"; return AASM_E_PARSE; }
+            paf.rec_rng_off.push_back((int64_t)paf.rng_qry_l.size());
+            paf.qry_str.push_back(qs); paf.qry_end.push_back(qe); paf.ref_str.push_back(rs); paf.ref_end.push_back(re);
+            paf.qry_total.push_back(qtot); paf.ref_total.push_back(rtot);
+            paf.ref_chr.push_back(chr_id); paf.mat_num.push_back((int32_t)mat); paf.aln_len.push_back((int32_t)aln);
+            paf.row_index.push_back(row_global_index); paf.cord_type.push_back(0);
+            paf.aln_fwd.push_back(fwd ? 1 : 0); paf.map_qul.push_back((uint8_t)mq);
+            paf.cs_pool.append(cs.data(), cs.size());
+            paf.cs_off.push_back((int64_t)paf.cs_pool.size());
+            row_global_index++;
+        }
+        p = e + 1;
+    }
+    if (paf.n_records() == 0) { paf.error = "empty PAF"; return AASM_E_PARSE; }
+    paf.ctg_name.push_back(ctg_chr);                                   // :180-181
+    paf.ctg_rec_off.push_back(paf.n_records());
+    return AASM_OK;
+}
+
+// ---- writers (alignasm.cpp:398-490) ---------------------------------------------------
+static inline void put_i64(std::string &s, int64_t v) {
+    char buf[24];
+    int n = std::snprintf(buf, sizeof buf, "%lld", (long long)v);
+    s.append(buf, n);
+}
+
+static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &name, const aasm_out_elem &o,
+                     std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+    const int64_t r = paf.ctg_rec_off[contig] + o.ctg_index;
+    if (o.ctg_index < 0 || r >= paf.ctg_rec_off[contig + 1]) { err = "output element refers to a record outside its contig"; return AASM_E_INVAL; }
+    const bool fwd = paf.aln_fwd[r] != 0;
+    Edit ed;
+    const char *cs = paf.cs_pool.data() + paf.cs_off[r];
+    const int64_t cs_len = paf.cs_off[r + 1] - paf.cs_off[r];
+    if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
+                 o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, ops, err))
+        return AASM_E_PARSE;
+    buf += name; buf += '\t';
+    put_i64(buf, paf.qry_total[r]); buf += '\t';
+    put_i64(buf, o.edited_qry_str); buf += '\t';
+    put_i64(buf, o.edited_qry_end + 1); buf += '\t';
+    buf += fwd ? '+' : '-'; buf += '\t';
+    buf += paf.chr_name[paf.ref_chr[r]]; buf += '\t';
+    put_i64(buf, paf.ref_total[r]); buf += '\t';
+    put_i64(buf, fwd ? o.edited_ref_str : o.edited_ref_end); buf += '\t';
+    put_i64(buf, (fwd ? o.edited_ref_end : o.edited_ref_str) + 1); buf += '\t';
+    put_i64(buf, ed.mat_num); buf += '\t';
+    put_i64(buf, ed.aln_len); buf += '\t';
+    put_i64(buf, paf.map_qul[r]); buf += '\t';
+    buf += o.is_alt_path ? "tp:A:S" : "tp:A:P"; buf += '\t';
+    buf += "xi:Z:"; buf += paf.cord_type[r] == 0 ? "P_" : "A_"; put_i64(buf, paf.row_index[r]); buf += '\t';
+    buf += ed.cs; buf += '\n';
+    return AASM_OK;
+}
+
+static int flush_file(const char *path, const std::string &buf) {
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return AASM_E_IO;
+    size_t w = buf.empty() ? 0 : std::fwrite(buf.data(), 1, buf.size(), fp);
+    int rc = (w == buf.size()) ? AASM_OK : AASM_E_IO;
+    if (std::fclose(fp) != 0) rc = AASM_E_IO;
+    return rc;
+}
+
+}  // namespace aasm
+
+using namespace aasm;
+
+extern "C" {
+
+const char *aasm_last_error(void) { return last_error_cstr(); }
+
+int aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **out) {
+    if (!text || !out) return AASM_E_INVAL;
+    aasm_paf *paf = new aasm_paf();
+    int rc = parse_text(text, len, *paf);
+    if (rc != AASM_OK) { set_last_error(paf->error); delete paf; *out = nullptr; return rc; }
+    *out = paf;
+    return AASM_OK;
+}
+
+int aasm_paf_read(const char *path, aasm_paf **out) {
+    if (!path || !out) return AASM_E_INVAL;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) { set_last_error(std::string("cannot open ") + path); return AASM_E_IO; }
+    std::string data;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, n);
+    std::fclose(fp);
+    return aasm_paf_parse_mem(data.data(), (int64_t)data.size(), out);
+}
+
+void aasm_paf_free(aasm_paf *paf) { delete paf; }
+int64_t aasm_paf_n_contigs(const aasm_paf *paf) { return paf ? paf->n_contigs() : 0; }
+
+int aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *v) {
+    if (!paf || !v) return AASM_E_INVAL;
+    std::memset(v, 0, sizeof(*v));
+    v->n_contigs = paf->n_contigs();
+    v->n_records = paf->n_records();
+    v->n_ranges = (int64_t)paf->rng_qry_l.size();
+    v->ctg_rec_off = paf->ctg_rec_off.data();
+    v->qry_str = paf->qry_str.data(); v->qry_end = paf->qry_end.data();
+    v->ref_str = paf->ref_str.data(); v->ref_end = paf->ref_end.data();
+    v->qry_total = paf->qry_total.data();
+    v->ref_chr = paf->ref_chr.data(); v->aln_fwd = paf->aln_fwd.data(); v->map_qul = paf->map_qul.data();
+    v->rec_rng_off = paf->rec_rng_off.data();
+    v->rng_qry_l = paf->rng_qry_l.data(); v->rng_qry_r = paf->rng_qry_r.data(); v->rng_ref_l = paf->rng_ref_l.data();
+    return AASM_OK;
+}
+
+int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const char *main_path, const char *alt_path,
+                           const char *all_path) {
+    if (!paf || !out || out->n_contigs != paf->n_contigs()) return AASM_E_INVAL;
+    if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
+    std::vector<CsOp> ops;
+    std::string err, buf;
+    const int64_t C = paf->n_contigs();
+    int rc;
+    if (main_path) {                                                    // process_output, :407-443
+        buf.clear();
+        for (int64_t c = 0; c < C; c++)
+            for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++)
+                if ((rc = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
+        if ((rc = flush_file(main_path, buf)) != AASM_OK) return rc;
+    }
+    if (alt_path) {
+        buf.clear();
+        for (int64_t c = 0; c < C; c++)
+            for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++)
+                if ((rc = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
+        if ((rc = flush_file(alt_path, buf)) != AASM_OK) return rc;
+    }
+    if (all_path) {                                                     // process_max_output, :445-485
+        buf.clear();
+        for (int64_t c = 0; c < C; c++) {
+            int32_t cnt = 0;
+            for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
+                ++cnt;
+                std::string name = paf->ctg_name[c] + "." + std::to_string(cnt);
+                for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++)
+                    if ((rc = emit_line(*paf, c, name, out->all_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
+            }
+        }
+        if ((rc = flush_file(all_path, buf)) != AASM_OK) return rc;
+    }
+    return AASM_OK;
+}
+
+int64_t aasm_cs_match_ranges(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str,
+                             int64_t ref_end, int64_t *qry_l, int64_t *qry_r, int64_t *ref_l, int64_t cap) {
+    std::vector<int64_t> a, b, c;
+    std::vector<CsOp> ops;
+    std::string err;
+    int64_t n = match_ranges(cs, cs_len, aln_fwd != 0, qry_str, qry_end, ref_str, ref_end, &a, &b, &c, ops, err);
+    if (n < 0) { set_last_error(err); return AASM_E_PARSE; }
+    for (int64_t i = 0; i < n && i < cap; i++) {
+        if (qry_l) qry_l[i] = a[i];
+        if (qry_r) qry_r[i] = b[i];
+        if (ref_l) ref_l[i] = c[i];
+    }
+    return n;
+}
+
+int64_t aasm_cs_edit(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_str, int64_t qry_end, int64_t e_qry_str,
+                     int64_t e_qry_end, int64_t e_ref_str, int64_t e_ref_end, char *out_cs, int64_t cap, int32_t *mat_num,
+                     int32_t *aln_len, int32_t *is_cut) {
+    Edit ed;
+    std::vector<CsOp> ops;
+    std::string err;
+    // mat_num / aln_len of the uncut record are passed IN through the out pointers
+    int32_t m0 = mat_num ? *mat_num : 0, a0 = aln_len ? *aln_len : 0;
+    if (!edit_cs(cs, cs_len, aln_fwd != 0, qry_str, qry_end, m0, a0, e_qry_str, e_qry_end, e_ref_str, e_ref_end, ed, ops, err)) {
+        set_last_error(err);
+        return AASM_E_PARSE;
+    }
+    if (mat_num) *mat_num = ed.mat_num;
+    if (aln_len) *aln_len = ed.aln_len;
+    if (is_cut) *is_cut = ed.is_cut ? 1 : 0;
+    int64_t n = (int64_t)ed.cs.size();
+    if (out_cs && cap > 0) { int64_t m = std::min(n, cap - 1); std::memcpy(out_cs, ed.cs.data(), m); out_cs[m] = 0; }
+    return n;
+}
+
+int aasm_paf_to_text(const aasm_paf *paf, char **text, int64_t *len) {
+    if (!paf || !text || !len) return AASM_E_INVAL;
+    if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
+    std::string buf;
+    for (int64_t c = 0; c < paf->n_contigs(); c++) {
+        for (int64_t r = paf->ctg_rec_off[c]; r < paf->ctg_rec_off[c + 1]; r++) {
+            const bool fwd = paf->aln_fwd[r] != 0;
+            int64_t rs = paf->ref_str[r], re = paf->ref_end[r];
+            if (!fwd) std::swap(rs, re);
+            buf += paf->ctg_name[c]; buf += '\t';
+            put_i64(buf, paf->qry_total[r]); buf += '\t';
+            put_i64(buf, paf->qry_str[r]); buf += '\t';
+            put_i64(buf, paf->qry_end[r] + 1); buf += '\t';
+            buf += fwd ? '+' : '-'; buf += '\t';
+            buf += paf->chr_name[paf->ref_chr[r]]; buf += '\t';
+            put_i64(buf, paf->ref_total[r]); buf += '\t';
+            put_i64(buf, rs); buf += '\t';
+            put_i64(buf, re + 1); buf += '\t';
+            put_i64(buf, paf->mat_num[r]); buf += '\t';
+            put_i64(buf, paf->aln_len[r]); buf += '\t';
+            put_i64(buf, paf->map_qul[r]); buf += "\ttp:A:P\t";
+            buf.append(paf->cs_pool.data() + paf->cs_off[r], paf->cs_off[r + 1] - paf->cs_off[r]);
+            buf += '\n';
+        }
+    }
+    *len = (int64_t)buf.size();
+    *text = (char *)std::malloc(buf.size() + 1);
+    if (!*text) return AASM_E_NOMEM;
+    std::memcpy(*text, buf.data(), buf.size());
+    (*text)[buf.size()] = 0;
+    return AASM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// aasm_paf.hpp -- host-side PAF container shared by the codec, the generator and the CLI.
+// Mirrors what the reference keeps per record in PafReadData (src/paf_data.hpp:51-67)
+// plus the per-file tables of src/alignasm.cpp:87-98 (contig names, reference names).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/alignasm_amd.h"
+
+struct aasm_paf {
+    // per contig (consecutive rows with the same query name, alignasm.cpp:125-133)
+    std::vector<std::string> ctg_name;
+    std::vector<int64_t> ctg_rec_off;          // [C+1]
+    // per record, input order
+    std::vector<int64_t> qry_str, qry_end, ref_str, ref_end, qry_total, ref_total;
+    std::vector<int32_t> ref_chr, mat_num, aln_len, row_index;
+    std::vector<uint8_t> aln_fwd, map_qul, cord_type;   // cord_type: TYPE_MAIN=0 / TYPE_ALT=1
+    std::vector<int64_t> cs_off;               // [R+1] into cs_pool (each entry "cs:Z:...")
+    std::string cs_pool;
+    bool has_cs = true;                        // generator may skip cs strings (bench)
+    // reference names (chr_map / chr_rev_map, alignasm.cpp:90-93)
+    std::vector<std::string> chr_name;
+    // match ranges (get_overlap_range, paf_data.cpp:90-123)
+    std::vector<int64_t> rec_rng_off;          // [R+1]
+    std::vector<int64_t> rng_qry_l, rng_qry_r, rng_ref_l;
+    std::string error;
+
+    int64_t n_contigs() const { return (int64_t)ctg_name.size(); }
+    int64_t n_records() const { return (int64_t)qry_str.size(); }
+};
+
+namespace aasm {
+// cs codec (own implementation of the behaviour of paf_data.cpp:19-220)
+struct CsOp { char type; int64_t length; int32_t text_off, text_len; };
+// returns false + message on malformed tags (the reference throws std::invalid_argument)
+bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err);
+void set_last_error(const std::string &msg);
+}  // namespace aasm

@@ -1,0 +1,210 @@
+/*
+ * alignasm_amd.h -- C-ABI of the MI355X-native per-contig path-inference solver.
+ *
+ * Drop-in boundary for ONE hot path of ACCtools/alignasm: the per-contig solver
+ *
+ *     void solve_ctg_read(std::vector<PafReadData>& in,
+ *                         std::vector<PafOutputData>& out,
+ *                         std::vector<PafOutputData>& alt_out,
+ *                         std::vector<std::vector<PafOutputData>>& max_out)
+ *
+ * (reference: src/paf_data.hpp:193 declaration, src/paf_data.cpp:223 definition,
+ *  call sites src/alignasm.cpp:357,373,391).  The reference has no FFI layer; this
+ * header is the FFI a maintainer would bind (INTEGRATION.md shows the glue).
+ * The GPU wants many contigs per launch, so the unit is a BATCH of contigs in flat
+ * SoA arrays with per-contig offsets instead of one std::vector per call.
+ *
+ * Conventions (all taken from the reference):
+ *  - every interval is CLOSED [str, end], 0-based        (src/alignasm.cpp:141-151)
+ *  - for '-' strand records ref_str > ref_end: ref_str is the reference position of
+ *    qry_str                                              (src/alignasm.cpp:155-159)
+ *  - records of one contig are given in INPUT order; position inside the contig is
+ *    the reference's PafReadData::ctg_index               (src/alignasm.cpp:138)
+ *  - match ranges are what get_overlap_range() produces   (src/paf_data.cpp:90-123):
+ *    one (qry_l, qry_r, ref_l) triple per ':' op of the cs tag, query-oriented;
+ *    the reference-side right end is ref_l + (qry_r-qry_l)*step and is not passed.
+ *
+ * No exceptions cross this ABI; every entry point returns 0 or a negative AASM_E_*.
+ * All arithmetic on the path is int64 / int32 integer work (no floating point).
+ */
+#ifndef ALIGNASM_AMD_H
+#define ALIGNASM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AASM_ABI_VERSION 1
+
+/* error codes */
+#define AASM_OK              0
+#define AASM_E_INVAL        -1   /* bad argument / inconsistent offsets            */
+#define AASM_E_NODEVICE     -2   /* no HIP device / HIP runtime error at init      */
+#define AASM_E_HIP          -3   /* HIP runtime error during a solve               */
+#define AASM_E_NOMEM        -4   /* device or host allocation failed               */
+#define AASM_E_OVERFLOW     -5   /* an internal pool overflowed even after retry   */
+#define AASM_E_INTERNAL     -6   /* "must not happen" state of the reference hit   */
+#define AASM_E_PARSE        -7   /* PAF / cs tag parse error (host codec)          */
+#define AASM_E_IO           -8
+
+/* ---- input: a batch of contigs -------------------------------------------------
+ * Mirrors the solver-relevant fields of PafReadData (src/paf_data.hpp:51-67).
+ * All pointers are HOST pointers for aasm_solve_batch() and DEVICE pointers for
+ * aasm_solve_device().                                                           */
+typedef struct aasm_batch_in {
+    int64_t n_contigs;
+    int64_t n_records;            /* == ctg_rec_off[n_contigs]                     */
+    int64_t n_ranges;             /* == rec_rng_off[n_records]                     */
+    const int64_t *ctg_rec_off;   /* [n_contigs+1] record offsets, non-decreasing  */
+    const int64_t *qry_str;       /* [n_records]  PafReadData::qry_str             */
+    const int64_t *qry_end;       /* [n_records]  PafReadData::qry_end (closed)    */
+    const int64_t *ref_str;       /* [n_records]  ref position of qry_str          */
+    const int64_t *ref_end;       /* [n_records]  ref position of qry_end          */
+    const int64_t *qry_total;     /* [n_records]  PafReadData::qry_total_length    */
+    const int32_t *ref_chr;       /* [n_records]  dense reference-name id          */
+    const uint8_t *aln_fwd;       /* [n_records]  1 = '+', 0 = '-'                 */
+    const uint8_t *map_qul;       /* [n_records]  mapping quality                  */
+    const int64_t *rec_rng_off;   /* [n_records+1] match-range offsets             */
+    const int64_t *rng_qry_l;     /* [n_ranges]   qry_overlap_range[k].first       */
+    const int64_t *rng_qry_r;     /* [n_ranges]   qry_overlap_range[k].second      */
+    const int64_t *rng_ref_l;     /* [n_ranges]   ref_overlap_range[k].first       */
+} aasm_batch_in;
+
+/* ---- options --------------------------------------------------------------------*/
+typedef struct aasm_opts {
+    int32_t max_paths;         /* MAX_PATH_COUNT, src/paf_data.cpp:729; 0 -> 10000   */
+    int32_t non_skip_linkable; /* global NON_SKIP_LINKABLE, src/paf_data.hpp:12      */
+    int32_t device;            /* HIP device ordinal                                  */
+    int32_t collect_timing;    /* 1: bracket every kernel with HIP events            */
+    int32_t keep_debug;        /* 1: keep device intermediates for aasm_debug_fetch   */
+    int32_t reserved[3];
+} aasm_opts;
+
+/* ---- output ---------------------------------------------------------------------
+ * One element == one PafOutputData (src/paf_data.hpp:90-105).                      */
+typedef struct aasm_out_elem {
+    int64_t edited_qry_str, edited_qry_end;
+    int64_t edited_ref_str, edited_ref_end;
+    int32_t ctg_index;         /* index of the record inside its contig (input order) */
+    int32_t is_alt_path;       /* tp:A:S if 1 (src/alignasm.cpp:438)                   */
+} aasm_out_elem;
+
+#define AASM_N_PHASES 16
+typedef struct aasm_stats {
+    int64_t n_vertices;        /* sum over contigs of V = N + P + 2                   */
+    int64_t n_pairs;           /* sum of P (overlap vertices)                          */
+    int64_t n_edges;           /* sum of E = get_edge_count(graph)                     */
+    int64_t n_heap_nodes;      /* persistent leftist-heap nodes allocated              */
+    int64_t n_paths_found;     /* sum of distances.size()                              */
+    int64_t n_paths_converted; /* calls of edge_path_to_paf_path                       */
+    int64_t n_unconnectable;   /* overlap pairs with no cut (paf_data.cpp:373-375)     */
+    int64_t n_internal_errors; /* contigs that hit a must-not-happen state             */
+    int64_t n_single;          /* contigs with one record (paf_data.cpp:235-239)       */
+    int64_t range_steps;       /* match-range entries visited by the merges            */
+    int64_t device_bytes;      /* peak device workspace                                */
+    float   phase_ms[AASM_N_PHASES];  /* per-phase kernel time (HIP events), ms       */
+    float   total_ms;                 /* whole device pipeline, ms                    */
+    float   reserved_f[3];
+} aasm_stats;
+
+/* phase ids for aasm_stats::phase_ms */
+enum {
+    AASM_PH_SORT = 0,     /* K1 sort + parts                       */
+    AASM_PH_PAIRS,        /* K2 overlap pairs + cut merge          */
+    AASM_PH_EDGES,        /* K3/K4 CSR build + scores              */
+    AASM_PH_REVCSR,       /* reversed CSR                          */
+    AASM_PH_SPTREE,       /* K6 Kahn(rev) + DAG shortest-path tree */
+    AASM_PH_FWD,          /* K6 forward Kahn order + K5 anomaly    */
+    AASM_PH_HEAP,         /* K7 sidetrack heaps                    */
+    AASM_PH_ENUM,         /* K8 k-walk enumeration                 */
+    AASM_PH_SELECT,       /* K9 recover/upgrade/convert/select     */
+    AASM_PH_GATHER,       /* output compaction                     */
+    AASM_PH_MISC
+};
+
+/* Ragged result of a batch: three lists per contig, exactly the three output
+ * vectors of solve_ctg_read.  `all` is a list of paths per contig.
+ * Arrays are malloc'ed by the library, released by aasm_free_out().              */
+typedef struct aasm_batch_out {
+    int64_t n_contigs;
+    int64_t *main_off;      /* [n_contigs+1] into main_elems                       */
+    int64_t *alt_off;       /* [n_contigs+1] into alt_elems                        */
+    int64_t *all_path_off;  /* [n_contigs+1] into all_elem_off (paths per contig)  */
+    int64_t *all_elem_off;  /* [n_all_paths+1] into all_elems                      */
+    aasm_out_elem *main_elems;
+    aasm_out_elem *alt_elems;
+    aasm_out_elem *all_elems;
+    int64_t n_all_paths;
+    int32_t *ctg_status;    /* [n_contigs] 0 ok, <0 AASM_E_* for that contig       */
+    aasm_stats stats;
+} aasm_batch_out;
+
+/* ---- entry points -----------------------------------------------------------------*/
+
+/* library / device probe.  Returns AASM_OK when a gfx950-class HIP device is usable. */
+int  aasm_abi_version(void);
+int  aasm_device_count(void);
+int  aasm_init(int device);
+const char *aasm_last_error(void);
+
+/* solve_ctg_read over a batch (replaces the dispatch loop src/alignasm.cpp:346-397).
+ * Host pointers in, host arrays out (malloc'ed into *out).                           */
+int  aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out);
+
+/* Same, with the batch already resident in device memory (in->pointers are device
+ * pointers; in->ctg_rec_off / rec_rng_off too).  `stream` is a hipStream_t (or NULL).
+ * The device result stays resident in an opaque handle until fetched/freed.          */
+typedef struct aasm_result aasm_result;
+int  aasm_solve_device(const aasm_batch_in *dev_in, const aasm_opts *opts, void *stream,
+                       aasm_result **res);
+int  aasm_result_stats(const aasm_result *res, aasm_stats *stats);
+int  aasm_result_fetch(aasm_result *res, aasm_batch_out *out);   /* D2H + ragged pack */
+void aasm_result_free(aasm_result *res);
+void aasm_free_out(aasm_batch_out *out);
+
+/* Debug/parity hook: copy a named device intermediate of a result solved with
+ * opts.keep_debug=1 (names listed in DESIGN.md; e.g. "perm", "csr_col", "sp_d").
+ * Call with dst==NULL to get the byte size.                                           */
+int64_t aasm_debug_fetch(aasm_result *res, const char *name, void *dst, int64_t dst_bytes);
+
+/* ---- host-side codec + file contract (reference: src/paf_data.cpp:19-220,
+ *      src/alignasm.cpp:76-183,398-490).  Implemented in host C++.                  */
+typedef struct aasm_paf aasm_paf;    /* parsed PAF file: names, records, cs strings   */
+
+int  aasm_paf_read(const char *path, aasm_paf **paf);              /* alignasm.cpp:76-183 */
+int  aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **paf);
+void aasm_paf_free(aasm_paf *paf);
+int  aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *view);      /* borrowed pointers  */
+int64_t aasm_paf_n_contigs(const aasm_paf *paf);
+/* write <stem>.aln.paf / .aln.alt.paf / .aln.all.paf (alignasm.cpp:407-490)          */
+int  aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out,
+                            const char *main_path, const char *alt_path, const char *all_path);
+/* get_overlap_range (paf_data.cpp:90): returns #ranges or <0; arrays may be NULL      */
+int64_t aasm_cs_match_ranges(const char *cs, int64_t cs_len, int aln_fwd,
+                             int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end,
+                             int64_t *qry_l, int64_t *qry_r, int64_t *ref_l, int64_t cap);
+/* get_edited_paf_data (paf_data.cpp:125): re-cut a cs tag; returns length written     */
+int64_t aasm_cs_edit(const char *cs, int64_t cs_len, int aln_fwd,
+                     int64_t qry_str, int64_t qry_end,
+                     int64_t e_qry_str, int64_t e_qry_end, int64_t e_ref_str, int64_t e_ref_end,
+                     char *out_cs, int64_t cap, int32_t *mat_num, int32_t *aln_len, int32_t *is_cut);
+
+/* ---- synthetic PAF generator (SURVEY.md Appendix C spec; own code) -----------------*/
+typedef struct aasm_synth_cfg {
+    int64_t n_contigs;
+    int64_t recs_per_contig;   /* fixed size, or the mean when heavy_tail=1            */
+    uint64_t seed;
+    int32_t dense;             /* 0 sparse, 1 dense/high-multiplicity                  */
+    int32_t heavy_tail;        /* log-normal contig sizes                              */
+    int32_t dup_every;         /* >0: duplicate every n-th record on another chr (ties)*/
+    int32_t reserved;
+} aasm_synth_cfg;
+int  aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **paf);     /* full PAF w/ cs  */
+int  aasm_paf_to_text(const aasm_paf *paf, char **text, int64_t *len); /* free()       */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNASM_AMD_H */
