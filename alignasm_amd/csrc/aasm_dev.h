@@ -1,0 +1,176 @@
+// aasm_dev.h -- execution context + wave64 primitives + the PafDistance arithmetic.
+//
+// Every kernel body in aasm_kernels.h is a function `kb_*(const KCtx&, const WS&)`.
+//  * Product build (hipcc, gfx950): `__global__` wrappers in aasm_gpu.hip call the body
+//    with the real thread/block ids; wave primitives are the CDNA4 64-lane ones
+//    (__ballot -> 64-bit mask, __shfl over 64 lanes).
+//  * tests/host_emul (g++, AASM_HOST_EMUL): the SAME bodies run with nthreads = 1 so the
+//    arithmetic/indexing logic can be diffed against the oracle on a box without a GPU.
+//    That build is test infrastructure only; the product library never contains it.
+#pragma once
+#include <stdint.h>
+
+#if defined(AASM_HOST_EMUL)
+#define AASM_DEV static inline
+#define AASM_MEM inline
+#define AASM_WAVE 1
+#else
+#include <hip/hip_runtime.h>
+#define AASM_DEV static __device__ __forceinline__
+#define AASM_MEM __device__ __forceinline__
+#define AASM_WAVE 64
+#endif
+
+namespace aasm {
+
+struct KCtx {
+    int tid;          // thread in block
+    int nthreads;     // block size
+    int64_t bid;      // block id
+    int64_t nblocks;
+    int lane;         // tid % AASM_WAVE
+};
+
+// ------------------------------------------------------------------------------------
+// wave primitives (wave64 on gfx950; trivial with one lane)
+// ------------------------------------------------------------------------------------
+#if defined(AASM_HOST_EMUL)
+AASM_DEV uint64_t wave_ballot(bool p) { return p ? 1ull : 0ull; }
+template <class T> AASM_DEV T wave_bcast(T x, int) { return x; }
+template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return fill; }
+AASM_DEV void block_sync() {}
+AASM_DEV void wave_fence() {}
+template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
+AASM_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+AASM_DEV int ffs64(uint64_t m) { return __builtin_ffsll((long long)m); }
+#else
+AASM_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+AASM_DEV int wave_bcast(int x, int src) { return __shfl(x, src, 64); }
+AASM_DEV int64_t wave_bcast(int64_t x, int src) {
+    int lo = __shfl((int)(x & 0xffffffffll), src, 64), hi = __shfl((int)(x >> 32), src, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+AASM_DEV int wave_shfl_up(int x, int d, int fill) {
+    int y = __shfl_up(x, d, 64);
+    return ((int)(threadIdx.x & 63) >= d) ? y : fill;
+}
+AASM_DEV int64_t wave_shfl_up(int64_t x, int d, int64_t fill) {
+    int lo = __shfl_up((int)(x & 0xffffffffll), d, 64), hi = __shfl_up((int)(x >> 32), d, 64);
+    int64_t y = ((int64_t)hi << 32) | (uint32_t)lo;
+    return ((int)(threadIdx.x & 63) >= d) ? y : fill;
+}
+AASM_DEV void block_sync() { __syncthreads(); }
+// order this wave's global-memory writes before its later reads (same CU, same L1)
+AASM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+template <class T> AASM_DEV T atomic_add(T *p, T v) { return atomicAdd(p, v); }
+AASM_DEV unsigned long long atomic_add(int64_t *p, int64_t v) {
+    return atomicAdd((unsigned long long *)p, (unsigned long long)v);
+}
+AASM_DEV int popc64(uint64_t m) { return __popcll(m); }
+AASM_DEV int ffs64(uint64_t m) { return __ffsll((long long)m); }
+#endif
+
+AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
+
+// inclusive wave scans (Hillis-Steele over 64 lanes; identity with one lane)
+AASM_DEV int wave_incl_add(int x) {
+    for (int d = 1; d < AASM_WAVE; d <<= 1) x += wave_shfl_up(x, d, 0);
+    return x;
+}
+AASM_DEV int64_t wave_incl_max(int64_t x, int64_t neutral) {
+    for (int d = 1; d < AASM_WAVE; d <<= 1) { int64_t y = wave_shfl_up(x, d, neutral); x = y > x ? y : x; }
+    return x;
+}
+AASM_DEV int64_t wave_incl_min(int64_t x, int64_t neutral) {
+    for (int d = 1; d < AASM_WAVE; d <<= 1) { int64_t y = wave_shfl_up(x, d, neutral); x = y < x ? y : x; }
+    return x;
+}
+
+AASM_DEV int64_t wave_sum(int64_t x) {
+    for (int d = 1; d < AASM_WAVE; d <<= 1) x += wave_shfl_up(x, d, (int64_t)0);
+    return wave_bcast(x, AASM_WAVE - 1);
+}
+
+// ------------------------------------------------------------------------------------
+// PafDistance (reference: src/paf_data.hpp:121-189) in 32 bytes.
+// anom / qul_nonzero / qul_total are path-length-bounded counters -> int32; the two
+// scores stay int64.  calc_sum_chk only feeds asserts in the reference and is dropped.
+// ------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) Dist {
+    int64_t qry, ref;
+    int32_t anom, qnz, qtot, pad;
+};
+enum { CALC_SUM_MODE = 0, QRY_SCORE_MODE = 1 };
+
+AASM_DEV Dist dist_zero() { Dist d; d.qry = 0; d.ref = 0; d.anom = 0; d.qnz = 0; d.qtot = 0; d.pad = 0; return d; }
+AASM_DEV Dist dist_max() { Dist d; d.qry = -1; d.ref = -1; d.anom = -1; d.qnz = -1; d.qtot = 0; d.pad = 0; return d; }
+// `x == PafDistance::max()` through operator== (paf_data.hpp:163-168): max has qtot 0 -> 1
+AASM_DEV bool dist_is_max(const Dist &a) {
+    int64_t tot = a.qtot ? a.qtot : 1;
+    return a.qry == -1 && a.ref == -1 && a.anom == -1 && (int64_t)a.qnz == -tot;
+}
+AASM_DEV bool dist_eq(const Dist &a, const Dist &b) {               // paf_data.hpp:163-168
+    int64_t tot = a.qtot ? a.qtot : 1, rtot = b.qtot ? b.qtot : 1;
+    return a.qry == b.qry && a.ref == b.ref && a.anom == b.anom && (int64_t)a.qnz * rtot == (int64_t)b.qnz * tot;
+}
+template <int MODE> AASM_DEV bool dist_lt(const Dist &a, const Dist &b) {   // paf_data.hpp:142-159
+    if (dist_is_max(a)) return false;
+    if (dist_is_max(b)) return true;
+    if (MODE == CALC_SUM_MODE) {
+        int64_t sa = a.qry + a.ref, sb = b.qry + b.ref;
+        if (sa != sb) return sa < sb;
+    } else {
+        if (a.qry != b.qry) return a.qry < b.qry;
+        if (a.ref != b.ref) return a.ref < b.ref;
+    }
+    if (a.anom != b.anom) return a.anom < b.anom;
+    int64_t tot = a.qtot ? a.qtot : 1, rtot = b.qtot ? b.qtot : 1;
+    return (int64_t)a.qnz * rtot > (int64_t)b.qnz * tot;
+}
+AASM_DEV Dist dist_add(const Dist &a, const Dist &b) {               // paf_data.hpp:178-183
+    Dist r; r.qry = a.qry + b.qry; r.ref = a.ref + b.ref; r.anom = a.anom + b.anom;
+    r.qnz = a.qnz + b.qnz; r.qtot = a.qtot + b.qtot; r.pad = 0; return r;
+}
+AASM_DEV Dist dist_sub(const Dist &a, const Dist &b) {               // paf_data.hpp:184-188
+    Dist r; r.qry = a.qry - b.qry; r.ref = a.ref - b.ref; r.anom = a.anom - b.anom;
+    r.qnz = a.qnz - b.qnz; r.qtot = a.qtot - b.qtot; r.pad = 0; return r;
+}
+
+// constants, src/paf_data.hpp:21-29
+#define AASM_REF_NEGATIVE_PENALTY 2
+#define AASM_SV_BASELINE 1000000
+#define AASM_SV_TRANS_PENALTY 2000
+#define AASM_SV_INV_PENALTY 500
+#define AASM_SV_FRONT_END_COEFFICIENT 2
+
+// edge flag byte: bits 0-1 anom (0..2), bit 2 qul_nonzero, bit 3 qul_total
+AASM_DEV uint8_t edge_flags(int anom, int qnz, int qtot) { return (uint8_t)(anom | (qnz << 2) | (qtot << 3)); }
+AASM_DEV Dist edge_dist(int64_t wq, int32_t wr, uint8_t fl) {
+    Dist d; d.qry = wq; d.ref = wr; d.anom = fl & 3; d.qnz = (fl >> 2) & 1; d.qtot = (fl >> 3) & 1; d.pad = 0; return d;
+}
+
+// persistent leftist-heap node (reference: src/leftist_heap.hpp:18-27), 48 bytes
+struct __attribute__((aligned(16))) HNode {
+    int64_t kq, kr;                 // key.qry_score, key.ref_score
+    int32_t ka, kn, kt, rank;       // key.anom, key.qul_nonzero, key.qul_total, node_rank
+    int32_t left, right, u, v;      // arena indices (-1 = nullptr), value = edge (u, v)
+};
+AASM_DEV Dist hnode_key(const HNode &n) {
+    Dist d; d.qry = n.kq; d.ref = n.kr; d.anom = n.ka; d.qnz = n.kn; d.qtot = n.kt; d.pad = 0; return d;
+}
+
+// priority-queue entry of the k-walk enumeration (k_shortest_walks.hpp:231), 48 bytes
+struct __attribute__((aligned(16))) PQEnt {
+    Dist d;
+    int32_t node;                   // heap node (arena index; stands in for the pointer)
+    int32_t cur;                    // insertion index into `nodes`
+    int32_t pad0, pad1;
+};
+
+// one output element, same layout as aasm_out_elem (include/alignasm_amd.h)
+struct OutElem {
+    int64_t qs, qe, rs, re;
+    int32_t ctg_index, is_alt;
+};
+
+}  // namespace aasm

@@ -1,0 +1,1283 @@
+// aasm_kernels.h -- kernel bodies of the per-contig path-inference pipeline (gfx950).
+//
+// Stage map (reference file:line -> kernel), see DESIGN.md for layouts and byte counts:
+//   K1  sort + parts ............. paf_data.cpp:241-261 ........ kb_sort, kb_sort_fix, kb_gather_parts
+//   K2  overlap pairs + cut ...... paf_data.cpp:294-378 ........ kb_ov_count, kb_ov_merge, kb_vcount, kb_vfill_*
+//   K3/4 linkable/get_score/make_Graph paf_data.cpp:422-696 .... kb_nsl, kb_row_count, kb_row_fill
+//   --  reversed CSR ............. k_shortest_walks.hpp:180-183 . kb_rev_fill, kb_sort_rows
+//   K6  Kahn(rev)+DAG-SP ......... k_shortest_walks.hpp:132-175 . kb_rev_sweep
+//   K5/6 Kahn(fwd)+anomaly ....... paf_data.cpp:704-713,742-746 . kb_fwd_sweep
+//   K7  sidetrack heaps .......... k_shortest_walks.hpp:191-215, leftist_heap.hpp:29-40 .. kb_child_*, kb_heap
+//   K8  enumeration .............. k_shortest_walks.hpp:217-249 . kb_enum
+//   K9  recover/upgrade/select ... k_shortest_walks.hpp:254-290, paf_data.cpp:750-921,1489-1649 .. kb_select
+//
+// Data-parallel stages run one thread per record / slot / vertex over the WHOLE batch
+// (coalesced SoA reads, ballot/prefix compaction inside rows).  The order-sensitive
+// stages run ONE WAVE PER CONTIG: contigs are independent, a 64-lane wave walks one
+// contig's topological order, and the lanes fan out over the adjacency row of the
+// vertex being processed (distinct targets per row -> conflict-free read-modify-write).
+#pragma once
+#include "aasm_dev.h"
+
+namespace aasm {
+
+struct WS {
+    // ---- sizes / options
+    int64_t C, R, R0, S, VT, ET;
+    int32_t K, nsl;
+    // ---- input batch (device), original record order; rec_off already points at the chunk
+    const int64_t *rec_off, *in_qs, *in_qe, *in_rs, *in_re, *in_qt, *in_rng_off, *rql, *rqr, *rrl;
+    const int32_t *in_chr;
+    const uint8_t *in_fwd, *in_mq;
+    // ---- K1: sorted records, indexed by (sorted position + rec_off[c] - R0)
+    int32_t *perm, *dupflag, *np, *pstart;
+    int64_t *s_qs, *s_qe, *s_rs, *s_re, *s_qt, *s_rb;
+    int32_t *s_rn, *s_chr, *s_orig, *s_ctg, *s_pid;
+    uint8_t *s_fl;                       // bit0 aln_fwd, bit1 map_qul > 0
+    // ---- K2: overlap slots (i, j) for j in (i, jmax_i]
+    int32_t *ov_cnt, *ov_rec, *ov_vid;
+    int64_t *ov_off, *ov_rank, *ov_peq, *ov_per, *ov_stq, *ov_str;
+    uint8_t *ov_ok;
+    int32_t *dis_end, *next_cnt;         // NON_SKIP_LINKABLE truncation points
+    // ---- vertices
+    int32_t *ctgV, *v_i, *v_j, *v_ctg;
+    int64_t *voff, *v_slot;
+    // ---- forward CSR + reversed CSR
+    int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e, *r_src, *tmp_a, *tmp_b;
+    int64_t *rowptr, *e_wq, *rptr;
+    uint8_t *e_fl;
+    // ---- sweeps
+    Dist *sp_d;
+    int32_t *sp_best, *rev_order, *cnt_tmp, *fwd_order, *fwd_pos, *an, *anom_dest, *cnt_tmp2;
+    // ---- SP-tree children CSR
+    int32_t *ccnt, *ccur, *cval;
+    int64_t *cptr;
+    // ---- heaps
+    int64_t *hoff;
+    int32_t *hcap_cnt;                   // per contig: capacity request (for the scan)
+    HNode *hnodes;
+    int32_t *h_root, *bq, *h_cnt;
+    // ---- enumeration
+    Dist *kd;
+    int32_t *klast, *knodes, *kprev, *kfound;
+    PQEnt *pq;
+    // ---- selection / outputs
+    int32_t *pathA, *pathB, *pathT, *pre2, *stamp;    // (u,v) pairs, 2*(N+2) ints per contig
+    Dist *dist2;
+    uint8_t *notalt;
+    OutElem *cur_out, *main_out, *alt_out, *pool;
+    int32_t *main_len, *alt_len, *all_gen, *all_seq;
+    int32_t *ar_ctg, *ar_gen, *ar_seq, *ar_len;      // .all path records
+    int64_t *ar_off;
+    int64_t pool_cap, ar_cap;
+    int64_t *main_off, *alt_off;                      // compaction offsets [C+1]
+    OutElem *main_c, *alt_c;                          // compacted outputs
+    // ---- status / counters
+    int32_t *status;
+    int64_t *counters;
+};
+
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_N };
+
+AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
+
+// ====================================================================================
+// K1  sort (paf_data.cpp:241; comparator paf_data.hpp:69-73)
+// ====================================================================================
+// Stable rank sort: block per contig, every thread ranks its records against all N keys
+// (uniform key reads -> scalar loads).  std::sort is NOT stable, so when a contig holds
+// duplicate (qry_str, qry_end) keys and N > 16 (libstdc++ switches from pure insertion
+// sort to introsort there) kb_sort_fix replays libstdc++'s algorithm exactly (hazard B1).
+AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
+    const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    if (N <= 0) return;
+    const int64_t *qs = w.in_qs + gb, *qe = w.in_qe + gb;
+    int dup = 0;
+    for (int64_t i = k.tid; i < N; i += k.nthreads) {
+        const int64_t a = qs[i], e = qe[i];
+        int32_t rank = 0;
+        for (int64_t j = 0; j < N; j++) {
+            const int64_t aj = qs[j], ej = qe[j];
+            const bool lt = (aj < a) || (aj == a && ej < e);
+            const bool eq = (aj == a && ej == e);
+            rank += (lt || (eq && j < i)) ? 1 : 0;
+            dup |= (eq && j != i) ? 1 : 0;
+        }
+        w.perm[b + rank] = (int32_t)i;
+    }
+    if (dup && N > 16) w.dupflag[c] = 1;
+}
+
+// ---- libstdc++ (GCC 11) std::sort replayed on an index array ------------------------
+struct KeyLess {
+    const int64_t *qs, *qe;
+    AASM_MEM bool operator()(int32_t x, int32_t y) const {
+        if (qs[x] != qs[y]) return qs[x] < qs[y];
+        return qe[x] < qe[y];
+    }
+};
+AASM_DEV void ss_swap(int32_t *a, int64_t i, int64_t j) { int32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+AASM_DEV void ss_push_heap(int32_t *f, int64_t hole, int64_t top, int32_t val, const KeyLess &lt) {
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && lt(f[parent], val)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
+    f[hole] = val;
+}
+AASM_DEV void ss_adjust_heap(int32_t *f, int64_t hole, int64_t len, int32_t val, const KeyLess &lt) {
+    const int64_t top = hole;
+    int64_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (lt(f[child], f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    ss_push_heap(f, hole, top, val, lt);
+}
+AASM_DEV void ss_heapsort(int32_t *f, int64_t len, const KeyLess &lt) {   // __partial_sort(f, l, l)
+    if (len >= 2) {
+        int64_t parent = (len - 2) / 2;
+        while (true) {
+            int32_t v = f[parent];
+            ss_adjust_heap(f, parent, len, v, lt);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int64_t last = len;
+    while (last > 1) {
+        --last;
+        int32_t v = f[last];
+        f[last] = f[0];
+        ss_adjust_heap(f, 0, last, v, lt);
+    }
+}
+AASM_DEV void ss_unguarded_linear_insert(int32_t *a, int64_t last, const KeyLess &lt) {
+    int32_t val = a[last];
+    int64_t next = last - 1;
+    while (lt(val, a[next])) { a[last] = a[next]; last = next; --next; }
+    a[last] = val;
+}
+AASM_DEV void ss_insertion_sort(int32_t *a, int64_t first, int64_t last, const KeyLess &lt) {
+    if (first == last) return;
+    for (int64_t i = first + 1; i != last; ++i) {
+        if (lt(a[i], a[first])) {
+            int32_t val = a[i];
+            for (int64_t t = i; t > first; --t) a[t] = a[t - 1];
+            a[first] = val;
+        } else ss_unguarded_linear_insert(a, i, lt);
+    }
+}
+AASM_DEV void ss_std_sort(int32_t *a, int64_t n, const KeyLess &lt, int depth_override) {
+    if (n <= 0) return;
+    int lg = 0;
+    for (int64_t t = n; t > 1; t >>= 1) lg++;
+    int64_t st_first[72], st_last[72];
+    int st_depth[72];
+    int sp = 0;
+    st_first[0] = 0; st_last[0] = n; st_depth[0] = depth_override >= 0 ? depth_override : 2 * lg;
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        int64_t first = st_first[sp], last = st_last[sp];
+        int depth = st_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) { ss_heapsort(a + first, last - first, lt); break; }
+            --depth;
+            // __unguarded_partition_pivot
+            const int64_t mid = first + (last - first) / 2;
+            {   // __move_median_to_first(first, first+1, mid, last-1)
+                const int64_t A = first + 1, B = mid, Cc = last - 1;
+                if (lt(a[A], a[B])) {
+                    if (lt(a[B], a[Cc])) ss_swap(a, first, B);
+                    else if (lt(a[A], a[Cc])) ss_swap(a, first, Cc);
+                    else ss_swap(a, first, A);
+                } else if (lt(a[A], a[Cc])) ss_swap(a, first, A);
+                else if (lt(a[B], a[Cc])) ss_swap(a, first, Cc);
+                else ss_swap(a, first, B);
+            }
+            int64_t lo = first + 1, hi = last;
+            while (true) {                       // __unguarded_partition(first+1, last, first)
+                while (lt(a[lo], a[first])) ++lo;
+                --hi;
+                while (lt(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                ss_swap(a, lo, hi);
+                ++lo;
+            }
+            const int64_t cut = lo;
+            if (sp < 72) { st_first[sp] = cut; st_last[sp] = last; st_depth[sp] = depth; sp++; }
+            last = cut;
+        }
+    }
+    // __final_insertion_sort
+    if (n > 16) {
+        ss_insertion_sort(a, 0, 16, lt);
+        for (int64_t i = 16; i != n; ++i) ss_unguarded_linear_insert(a, i, lt);
+    } else ss_insertion_sort(a, 0, n, lt);
+}
+
+AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {         // thread per contig
+    const int64_t c = k.bid * k.nthreads + k.tid;
+    if (c >= w.C || !w.dupflag[c]) return;
+    const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    int32_t *a = w.perm + b;
+    for (int64_t i = 0; i < N; i++) a[i] = (int32_t)i;             // copy of the input order (:232)
+    KeyLess lt{w.in_qs + gb, w.in_qe + gb};
+    ss_std_sort(a, N, lt, -1);
+}
+
+// gather sorted SoA + parts (paf_data.cpp:248-261).  One wave per contig.
+AASM_DEV void kb_gather_parts(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
+    const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    if (N <= 0) { if (k.lane == 0) w.np[c] = 0; return; }
+    const int64_t NEG = INT64_MIN;
+    int64_t carry_max = -1;                       // part_end starts at -1 (:252)
+    int32_t carry_parts = 0;
+    int32_t *pst = w.pstart + b + c;              // N+1 slots per contig
+    for (int64_t base = 0; base < N; base += AASM_WAVE) {
+        const int64_t i = base + k.lane;
+        const bool act = i < N;
+        int64_t qs_i = 0, qe_i = NEG;
+        if (act) {
+            const int64_t o = gb + w.perm[b + i];
+            qs_i = w.in_qs[o]; qe_i = w.in_qe[o];
+            w.s_qs[b + i] = qs_i; w.s_qe[b + i] = qe_i;
+            w.s_rs[b + i] = w.in_rs[o]; w.s_re[b + i] = w.in_re[o]; w.s_qt[b + i] = w.in_qt[o];
+            w.s_chr[b + i] = w.in_chr[o];
+            w.s_fl[b + i] = (uint8_t)((w.in_fwd[o] ? 1 : 0) | (w.in_mq[o] ? 2 : 0));
+            w.s_orig[b + i] = (int32_t)(o - gb);
+            w.s_ctg[b + i] = (int32_t)c;
+            w.s_rb[b + i] = w.in_rng_off[o];
+            w.s_rn[b + i] = (int32_t)(w.in_rng_off[o + 1] - w.in_rng_off[o]);
+        }
+        const int64_t incl = wave_incl_max(qe_i, NEG);
+        int64_t excl = wave_shfl_up(incl, 1, NEG);
+        if (carry_max > excl) excl = carry_max;
+        const bool flag = act && (excl < qs_i);
+        const int inc = wave_incl_add(flag ? 1 : 0);
+        const int32_t pid = carry_parts + inc - 1;
+        if (act) {
+            w.s_pid[b + i] = pid;
+            if (flag) pst[pid] = (int32_t)i;
+        }
+        const int64_t tot_max = wave_bcast(incl, AASM_WAVE - 1);
+        if (tot_max > carry_max) carry_max = tot_max;
+        carry_parts += wave_bcast(inc, AASM_WAVE - 1);
+    }
+    if (k.lane == 0) { w.np[c] = carry_parts; pst[carry_parts] = (int32_t)N; }
+}
+
+// ====================================================================================
+// K2  overlap slots (paf_data.cpp:294-378)
+// ====================================================================================
+// Slot table replaces the four N x N tables (paf_data.cpp:268-272,282): record i owns one
+// slot per j in (i, jmax_i], jmax_i = last j with qry_str_j <= qry_end_i (the scan range
+// of :297-299), so slot(i, j) = ov_off[i] + (j - i - 1) and every cell the reference ever
+// writes has a slot; all other cells hold FAIL_EDIT / -1 there.
+AASM_DEV void kb_ov_count(const KCtx &k, const WS &w) {             // thread per record
+    const int64_t g = k.bid * k.nthreads + k.tid;
+    if (g >= w.R) return;
+    const int64_t c = w.s_ctg[g];
+    const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c];
+    const int64_t i = g - b, qe = w.s_qe[g];
+    int64_t lo = i + 1, hi = N;                                      // first j with qs_j > qe
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (w.s_qs[b + mid] <= qe) lo = mid + 1; else hi = mid;
+    }
+    w.ov_cnt[g] = (N <= 1) ? 0 : (int32_t)(lo - 1 - i);
+}
+
+AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread per slot
+    const int64_t s = k.bid * k.nthreads + k.tid;
+    int64_t steps = 0;
+    bool unconn = false;
+    if (s < w.S) {
+        int64_t lo = 0, hi = w.R;                                    // last g with ov_off[g] <= s
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (w.ov_off[mid + 1] <= s) lo = mid + 1; else hi = mid;
+        }
+        const int64_t g = lo, gj = g + 1 + (s - w.ov_off[g]);
+        w.ov_rec[s] = (int32_t)g;
+        int64_t peq = -1, per = -1, stq = -1, str_ = -1;
+        uint8_t ok = 0;
+        // qry_partial_overlap (paf_data.hpp:78-86) on sorted records: qs_i <= qs_j, qs_j <= qe_i
+        if (w.s_qs[g] < w.s_qs[gj] && w.s_qe[g] < w.s_qe[gj]) {
+            const int64_t *il = w.rql + w.s_rb[g], *ir = w.rqr + w.s_rb[g], *irl = w.rrl + w.s_rb[g];
+            const int64_t *jl = w.rql + w.s_rb[gj], *jr = w.rqr + w.s_rb[gj], *jrl = w.rrl + w.s_rb[gj];
+            const int64_t ni = w.s_rn[g], nj = w.s_rn[gj];
+            const int64_t step_i = (w.s_fl[g] & 1) ? 1 : -1, step_j = (w.s_fl[gj] & 1) ? 1 : -1;
+            bool determined = false;
+            int64_t min_gap = -1, mg_i = -1, mg_j = -1, p_i = 0, p_j = 0;
+            if (ni > 0 && nj > 0) {
+                // fast-forward: while r_i + 1 < l_j0 the loop of :308-359 only records the
+                // (strictly shrinking) gap and advances p_i; jump to the first other range.
+                const int64_t lj0 = jl[0];
+                int64_t a = 0, z = ni;
+                while (a < z) { const int64_t m = (a + z) >> 1; if (ir[m] + 1 < lj0) a = m + 1; else z = m; steps++; }
+                if (a > 0) { min_gap = lj0 - (ir[a - 1] + 1); mg_i = a - 1; mg_j = 0; }
+                p_i = a;
+            }
+            while (p_i < ni && p_j < nj) {
+                steps++;
+                const int64_t l_i = il[p_i], r_i = ir[p_i], l_j = jl[p_j], r_j = jr[p_j];
+                if (l_i == l_j) {                                                 // :315-327
+                    if (l_j == r_j) { p_j++; continue; }
+                    peq = l_i; per = irl[p_i]; stq = l_j + 1; str_ = jrl[p_j] + step_j;
+                    determined = true; break;
+                }
+                if (l_i < l_j) {                                                  // :328-346
+                    if (l_j <= r_i + 1) {
+                        peq = l_j - 1; per = irl[p_i] + ((l_j - 1) - l_i) * step_i; stq = l_j; str_ = jrl[p_j];
+                        determined = true; break;
+                    } else {
+                        const int64_t gap = l_j - (r_i + 1);
+                        if (min_gap == -1 || gap < min_gap) { min_gap = gap; mg_i = p_i; mg_j = p_j; }
+                    }
+                    p_i++;
+                } else {                                                          // :347-358
+                    if (l_i <= r_j - 1) {
+                        peq = l_i; per = irl[p_i]; stq = l_i + 1; str_ = jrl[p_j] + (l_i + 1 - l_j) * step_j;
+                        determined = true; break;
+                    }
+                    p_j++;
+                }
+            }
+            if (determined || min_gap != -1) {                                    // :360-372
+                if (!determined) {
+                    const int64_t l_i = il[mg_i], r_i = ir[mg_i];
+                    peq = r_i; per = irl[mg_i] + (r_i - l_i) * step_i; stq = jl[mg_j]; str_ = jrl[mg_j];
+                }
+                ok = 1;
+            } else {
+                unconn = true;                                                    // :373-375 (NDEBUG)
+                peq = per = stq = str_ = -1;
+            }
+        }
+        w.ov_peq[s] = peq; w.ov_per[s] = per; w.ov_stq[s] = stq; w.ov_str[s] = str_; w.ov_ok[s] = ok;
+    }
+    // statistics: one atomic per wave
+    const int64_t tot = wave_sum(steps);
+    if (k.lane == 0 && tot) atomic_add(&w.counters[CNT_RANGE_STEPS], tot);
+    if (unconn) atomic_add(&w.counters[CNT_UNCONN], (int64_t)1);
+}
+
+AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread per contig
+    const int64_t c = k.bid * k.nthreads + k.tid;
+    if (c >= w.C) return;
+    const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c];
+    if (N <= 1) { w.ctgV[c] = 0; return; }                          // N == 1 shortcut (:235-239)
+    const int64_t P = w.ov_rank[w.ov_off[b + N]] - w.ov_rank[w.ov_off[b]];
+    w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
+}
+
+AASM_DEV void kb_vfill_rec(const KCtx &k, const WS &w) {            // thread per record
+    const int64_t g = k.bid * k.nthreads + k.tid;
+    if (g >= w.R) return;
+    const int64_t c = w.s_ctg[g];
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    const int64_t b = w.rec_off[c] - w.R0, i = g - b, vb = w.voff[c];
+    w.v_i[vb + i] = (int32_t)i; w.v_j[vb + i] = (int32_t)i; w.v_slot[vb + i] = -1; w.v_ctg[vb + i] = (int32_t)c;
+    if (i == 0) {
+        w.v_i[vb + V - 2] = -1; w.v_j[vb + V - 2] = -1; w.v_slot[vb + V - 2] = -1; w.v_ctg[vb + V - 2] = (int32_t)c;
+        w.v_i[vb + V - 1] = -2; w.v_j[vb + V - 1] = -2; w.v_slot[vb + V - 1] = -1; w.v_ctg[vb + V - 1] = (int32_t)c;
+    }
+}
+AASM_DEV void kb_vfill_slot(const KCtx &k, const WS &w) {           // thread per slot
+    const int64_t s = k.bid * k.nthreads + k.tid;
+    if (s >= w.S) return;
+    int32_t vid = -1;
+    if (w.ov_ok[s]) {
+        const int64_t g = w.ov_rec[s], c = w.s_ctg[g];
+        const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c], vb = w.voff[c];
+        vid = (int32_t)(N + (w.ov_rank[s] - w.ov_rank[w.ov_off[b]]));      // lexicographic (i, j) (:371-372)
+        const int64_t i = g - b, j = i + 1 + (s - w.ov_off[g]);
+        w.v_i[vb + vid] = (int32_t)i; w.v_j[vb + vid] = (int32_t)j; w.v_slot[vb + vid] = s; w.v_ctg[vb + vid] = (int32_t)c;
+    }
+    w.ov_vid[s] = vid;
+}
+
+// ====================================================================================
+// K3/K4  make_Graph (paf_data.cpp:531-696) as closed-form CSR rows
+// ====================================================================================
+// Adjacency order is significant.  Row of a vertex with current record j (= (j,j) or (i,j)):
+//   [ -> dest            if j is in the last part                       (:565-595) ]
+//   [ -> (j,k) pair vertices, k over j's overlap slots, ascending k     (:622-626,642-645) ]
+//   [ -> (k,k) for the records k of j's part that start after qry_end_j (:613-619,637-640) ]
+//   [ -> (k,k) for every record k of the next part                      (:653-695) ]
+// which is exactly the emission order of the reference's loops, because inside a part the
+// overlapping k (qry_str_k <= qry_end_j) precede the disjoint ones in sorted order.
+// NON_SKIP_LINKABLE only truncates the two (k,k) ranges (dis_end / next_cnt, kb_nsl).
+struct PartInfo { int64_t pl, pr, nr; bool last; };
+AASM_DEV PartInfo part_of(const WS &w, int64_t c, int64_t b, int64_t j) {
+    const int32_t *pst = w.pstart + b + c;
+    const int32_t pid = w.s_pid[b + j], npp = w.np[c];
+    PartInfo p;
+    p.pl = pst[pid]; p.pr = pst[pid + 1];
+    p.last = (pid == npp - 1);
+    p.nr = p.last ? p.pr : pst[pid + 2];
+    return p;
+}
+
+AASM_DEV void kb_nsl(const KCtx &k, const WS &w) {                  // thread per record (nsl only)
+    const int64_t g = k.bid * k.nthreads + k.tid;
+    if (g >= w.R) return;
+    const int64_t c = w.s_ctg[g];
+    const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c];
+    if (N <= 1) return;
+    const int64_t j = g - b;
+    const PartInfo p = part_of(w, c, b, j);
+    {   // disjoint range of j inside its part: break when min(qry_end seen) < qry_str_k (:606-612,630-636)
+        int64_t kx = j + 1 + w.ov_cnt[g], mn = INT64_MAX;
+        while (kx < p.pr) {
+            if (mn < w.s_qs[b + kx]) break;
+            if (w.s_qe[b + kx] < mn) mn = w.s_qe[b + kx];
+            kx++;
+        }
+        w.dis_end[g] = (int32_t)kx;
+    }
+    if (j == p.pl) {  // how many records of THIS part a previous-part vertex (or src) links to (:547-551,663-668)
+        int64_t kx = p.pl, mn = INT64_MAX;
+        while (kx < p.pr) {
+            if (mn < w.s_qs[b + kx]) break;
+            if (w.s_qe[b + kx] < mn) mn = w.s_qe[b + kx];
+            kx++;
+        }
+        w.next_cnt[g] = (int32_t)(kx - p.pl);
+    }
+}
+
+struct RowPlan {
+    int64_t c, b, N, V, vb;
+    int32_t kind;         // 0 = record vertex (cur j), 1 = src, 2 = dest
+    int64_t i, j, slot;   // (i, j); slot = -1 for (j, j)
+    bool has_dest;
+    int64_t ov0, ovn;     // j's overlap slots
+    int64_t dis0, dis1;   // disjoint (k,k) range in j's part
+    int64_t nx0, nx1;     // (k,k) range in the next part
+    int64_t stq;          // lft.qry_str of this vertex
+};
+AASM_DEV RowPlan plan_row(const WS &w, int64_t gv) {
+    RowPlan r;
+    r.c = w.v_ctg[gv];
+    r.b = w.rec_off[r.c] - w.R0; r.N = w.rec_off[r.c + 1] - w.rec_off[r.c];
+    r.V = w.ctgV[r.c]; r.vb = w.voff[r.c];
+    const int64_t v = gv - r.vb;
+    r.i = w.v_i[gv]; r.j = w.v_j[gv]; r.slot = w.v_slot[gv];
+    r.has_dest = false; r.ov0 = r.ovn = 0; r.dis0 = r.dis1 = r.nx0 = r.nx1 = 0; r.stq = 0;
+    if (v == r.V - 1) { r.kind = 2; return r; }
+    if (v == r.V - 2) {                                   // src -> part 0 (:540-563)
+        r.kind = 1;
+        const int32_t *pst = w.pstart + r.b + r.c;
+        r.nx0 = pst[0];
+        r.nx1 = w.nsl ? (int64_t)pst[0] + w.next_cnt[r.b + pst[0]] : (int64_t)pst[1];
+        return r;
+    }
+    r.kind = 0;
+    const int64_t gj = r.b + r.j;
+    const PartInfo p = part_of(w, r.c, r.b, r.j);
+    r.has_dest = p.last;
+    if (w.nsl && p.last && w.s_qe[gj] < w.s_qs[r.b + r.N - 1]) r.has_dest = false;   // :572-576
+    r.ov0 = w.ov_off[gj]; r.ovn = w.ov_cnt[gj];
+    r.dis0 = r.j + 1 + r.ovn;
+    r.dis1 = w.nsl ? (int64_t)w.dis_end[gj] : p.pr;
+    if (!p.last) { r.nx0 = p.pr; r.nx1 = w.nsl ? p.pr + w.next_cnt[r.b + p.pr] : p.nr; }
+    r.stq = (r.slot < 0) ? w.s_qs[gj] : w.ov_stq[r.slot];
+    return r;
+}
+// pair edge (.., j) -> (j, k) exists iff the pair vertex exists and lft.qry_str < rht.qry_str (:433-436)
+AASM_DEV bool pair_edge_ok(const WS &w, const RowPlan &r, int64_t t) {
+    const int64_t s = r.ov0 + t;
+    return w.ov_vid[s] >= 0 && r.stq < w.ov_stq[s];
+}
+
+AASM_DEV void kb_row_count(const KCtx &k, const WS &w) {            // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const RowPlan r = plan_row(w, gv);
+    int32_t d = 0;
+    if (r.kind == 1) d = (int32_t)(r.nx1 - r.nx0);
+    else if (r.kind == 0) {
+        d = r.has_dest ? 1 : 0;
+        for (int64_t t = 0; t < r.ovn; t++) d += pair_edge_ok(w, r, t) ? 1 : 0;
+        d += (int32_t)((r.dis1 > r.dis0 ? r.dis1 - r.dis0 : 0) + (r.nx1 - r.nx0));
+    }
+    w.deg[gv] = d;
+}
+
+// get_score (paf_data.cpp:449-521).  lft = this row's vertex, rht = (k,k) or the pair in slot `ps`.
+AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, int64_t &wq, int32_t &wr, uint8_t &fl) {
+    const int64_t gl = r.b + r.j, gr = r.b + kk;
+    int64_t l_qe = w.s_qe[gl], l_re = w.s_re[gl];
+    const int64_t l_rs = (r.slot < 0) ? w.s_rs[gl] : w.ov_str[r.slot];
+    int64_t r_qs, r_rs;
+    const int64_t r_re = w.s_re[gr];
+    if (ps >= 0) { l_qe = w.ov_peq[ps]; l_re = w.ov_per[ps]; r_qs = w.ov_stq[ps]; r_rs = w.ov_str[ps]; }   // :460-465
+    else { r_qs = w.s_qs[gr]; r_rs = w.s_rs[gr]; }
+    const int64_t qry_diff = r_qs - l_qe - 1;
+    int64_t ref_diff = 0;
+    int anom = 0;
+    const bool lf = w.s_fl[gl] & 1, rf = w.s_fl[gr] & 1;
+    const bool same_chr = w.s_chr[gl] == w.s_chr[gr];
+    if (same_chr && lf == rf) {                                                     // :475-490
+        const int64_t gap = lf ? r_rs - (l_re + 1) : l_re - (r_rs + 1);
+        ref_diff += gap < 0 ? -gap * AASM_REF_NEGATIVE_PENALTY : gap;
+        if (ref_diff > AASM_SV_BASELINE) { anom += 1; ref_diff = AASM_SV_BASELINE; }
+    } else if (same_chr) {                                                          // :491-508
+        anom += 1;
+        ref_diff += AASM_SV_INV_PENALTY;
+        const int64_t x = lf ? r_re - (l_re + 1) : r_rs - (l_rs + 1);
+        ref_diff += x < 0 ? -x * AASM_REF_NEGATIVE_PENALTY : x;
+        if (ref_diff > AASM_SV_BASELINE) { anom += 1; ref_diff = AASM_SV_BASELINE; }
+    } else {                                                                        // :509-514
+        anom += 1;
+        ref_diff = AASM_SV_TRANS_PENALTY;
+    }
+    wq = qry_diff; wr = (int32_t)ref_diff;
+    fl = edge_flags(anom, (w.s_fl[gr] & 2) ? 1 : 0, 1);                             // :518-519
+}
+
+AASM_DEV void emit_edge(const WS &w, int64_t e, int64_t vb, int32_t col, int64_t wq, int32_t wr, uint8_t fl) {
+    w.e_col[e] = col; w.e_wq[e] = wq; w.e_wr[e] = wr; w.e_fl[e] = fl;
+    atomic_add(&w.indeg[vb + col], (int32_t)1);
+}
+
+// fills rows: each lane owns one vertex of a 64-vertex tile (short rows); rows longer than
+// LONG_ROW are then written cooperatively by the whole wave (coalesced, ballot compaction).
+#define AASM_LONG_ROW 16
+AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane, int nl) {
+    // segments: [dest][pairs][disjoint][next]; lanes stride over each segment
+    int64_t e = e0;
+    if (r.kind == 1) {                                              // src (:552-561)
+        for (int64_t t = r.nx0 + lane; t < r.nx1; t += nl) {
+            const int64_t g = r.b + t;
+            emit_edge(w, e + (t - r.nx0), r.vb, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0,
+                      edge_flags(0, (w.s_fl[g] & 2) ? 1 : 0, 1));
+        }
+        return;
+    }
+    if (r.has_dest) {                                               // :577-585,591
+        if (lane == 0) {
+            const int64_t gj = r.b + r.j;
+            emit_edge(w, e, r.vb, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0,
+                      edge_flags(0, 0, 0));
+        }
+        e += 1;
+    }
+    // pair edges need in-row compaction
+    for (int64_t t0 = 0; t0 < r.ovn; t0 += nl) {
+        const int64_t t = t0 + lane;
+        const bool ok = t < r.ovn && pair_edge_ok(w, r, t);
+        const uint64_t m = wave_ballot(ok);
+        if (ok) {
+            const int64_t s = r.ov0 + t, pos = e + popc64(m & lanemask_lt(lane));
+            int64_t wq; int32_t wr; uint8_t fl;
+            score_edge(w, r, r.j + 1 + t, s, wq, wr, fl);
+            emit_edge(w, pos, r.vb, w.ov_vid[s], wq, wr, fl);
+        }
+        e += popc64(m);
+    }
+    for (int64_t t = r.dis0 + lane; t < r.dis1; t += nl) {
+        int64_t wq; int32_t wr; uint8_t fl;
+        score_edge(w, r, t, -1, wq, wr, fl);
+        emit_edge(w, e + (t - r.dis0), r.vb, (int32_t)t, wq, wr, fl);
+    }
+    if (r.dis1 > r.dis0) e += r.dis1 - r.dis0;
+    for (int64_t t = r.nx0 + lane; t < r.nx1; t += nl) {
+        int64_t wq; int32_t wr; uint8_t fl;
+        score_edge(w, r, t, -1, wq, wr, fl);
+        emit_edge(w, e + (t - r.nx0), r.vb, (int32_t)t, wq, wr, fl);
+    }
+}
+AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 64 vertices
+    const int64_t gv = k.bid * AASM_WAVE + k.lane;
+    const bool act = gv < w.VT;
+    int32_t d = act ? w.deg[gv] : 0;
+    RowPlan r;
+    if (act && d > 0) r = plan_row(w, gv);
+    const bool small = act && d > 0 && d <= AASM_LONG_ROW;
+    const bool big = act && d > AASM_LONG_ROW;
+#if defined(AASM_HOST_EMUL)
+    if (small || big) fill_row_part(w, r, w.rowptr[gv], 0, 1);
+#else
+    // short rows: run with a single logical lane (ballot of a lone lane is its own bit)
+    if (small) {
+        int64_t e = w.rowptr[gv];
+        if (r.kind == 1) {
+            for (int64_t t = r.nx0; t < r.nx1; t++) {
+                const int64_t g = r.b + t;
+                emit_edge(w, e++, r.vb, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, (w.s_fl[g] & 2) ? 1 : 0, 1));
+            }
+        } else {
+            if (r.has_dest) {
+                const int64_t gj = r.b + r.j;
+                emit_edge(w, e++, r.vb, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, 0, 0));
+            }
+            for (int64_t t = 0; t < r.ovn; t++)
+                if (pair_edge_ok(w, r, t)) {
+                    int64_t wq; int32_t wr; uint8_t fl;
+                    score_edge(w, r, r.j + 1 + t, r.ov0 + t, wq, wr, fl);
+                    emit_edge(w, e++, r.vb, w.ov_vid[r.ov0 + t], wq, wr, fl);
+                }
+            for (int64_t t = r.dis0; t < r.dis1; t++) {
+                int64_t wq; int32_t wr; uint8_t fl;
+                score_edge(w, r, t, -1, wq, wr, fl);
+                emit_edge(w, e++, r.vb, (int32_t)t, wq, wr, fl);
+            }
+            for (int64_t t = r.nx0; t < r.nx1; t++) {
+                int64_t wq; int32_t wr; uint8_t fl;
+                score_edge(w, r, t, -1, wq, wr, fl);
+                emit_edge(w, e++, r.vb, (int32_t)t, wq, wr, fl);
+            }
+        }
+    }
+    // long rows: all 64 lanes cooperate on one row at a time
+    uint64_t bigmask = wave_ballot(big);
+    while (bigmask) {
+        const int src = ffs64(bigmask) - 1;
+        bigmask &= bigmask - 1;
+        const int64_t gv2 = k.bid * AASM_WAVE + src;
+        const RowPlan r2 = plan_row(w, gv2);
+        fill_row_part(w, r2, w.rowptr[gv2], k.lane, AASM_WAVE);
+    }
+#endif
+}
+
+// ====================================================================================
+// reversed CSR (k_shortest_walks.hpp:180-183): in-list of v = its in-edges in ascending
+// (source id, list position) = ascending contig-local edge id.
+// ====================================================================================
+AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread per vertex (row loop)
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t c = w.v_ctg[gv], vb = w.voff[c], e_base = w.rowptr[vb];
+    const int32_t u = (int32_t)(gv - vb);
+    for (int64_t e = w.rowptr[gv]; e < w.rowptr[gv + 1]; e++) {
+        const int64_t tv = vb + w.e_col[e];
+        const int64_t pos = w.rptr[tv] + atomic_add(&w.rcur[tv], (int32_t)1);
+        w.r_e[pos] = (int32_t)(e - e_base);
+        w.r_src[pos] = u;
+    }
+}
+
+// sort every row of (key, payload) ascending by key; keys inside a row are distinct.
+// Lanes insertion-sort their own short rows; long rows are rank-sorted by the whole wave
+// through the tmp arrays.
+AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, int32_t *pay, int64_t nrows) {
+    const int64_t row = k.bid * AASM_WAVE + k.lane;
+    const bool act = row < nrows;
+    const int64_t p0 = act ? ptr[row] : 0, L = act ? ptr[row + 1] - p0 : 0;
+    const bool big = L > 32;
+    if (act && !big) {
+        for (int64_t a = 1; a < L; a++) {
+            const int32_t kx = key[p0 + a], px = pay ? pay[p0 + a] : 0;
+            int64_t t = a - 1;
+            while (t >= 0 && key[p0 + t] > kx) { key[p0 + t + 1] = key[p0 + t]; if (pay) pay[p0 + t + 1] = pay[p0 + t]; t--; }
+            key[p0 + t + 1] = kx; if (pay) pay[p0 + t + 1] = px;
+        }
+    }
+    uint64_t bigmask = wave_ballot(big);
+    while (bigmask) {
+        const int src = ffs64(bigmask) - 1;
+        bigmask &= bigmask - 1;
+        const int64_t q0 = wave_bcast(p0, src), QL = wave_bcast(L, src);
+        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) {
+            const int32_t kx = key[q0 + a];
+            int64_t rank = 0;
+            for (int64_t t = 0; t < QL; t++) rank += key[q0 + t] < kx ? 1 : 0;
+            w.tmp_a[q0 + rank] = kx;
+            if (pay) w.tmp_b[q0 + rank] = pay[q0 + a];
+        }
+        wave_fence();
+        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) { key[q0 + a] = w.tmp_a[q0 + a]; if (pay) pay[q0 + a] = w.tmp_b[q0 + a]; }
+        wave_fence();
+    }
+}
+
+// ====================================================================================
+// K6  Kahn FIFO order of the reversed graph + DAG shortest-path tree in ONE sweep
+//     (k_shortest_walks.hpp:132-175,184).  One wave per contig.
+// ====================================================================================
+// Popping v in Kahn-FIFO order and relaxing its in-edges in list order with the strict
+// `d[to] > d[v] + w` test reproduces the reference's first-wins tie behaviour (hazard B2)
+// without any extra key: targets inside one in-list are distinct, so the 64 lanes relax a
+// whole in-list at once; newly free vertices are appended in list order by ballot+prefix.
+AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    const int64_t vb = w.voff[c], e_base = w.rowptr[vb];
+    Dist *d = w.sp_d + vb;
+    int32_t *best = w.sp_best + vb, *q = w.rev_order + vb, *cnt = w.cnt_tmp + vb;
+    const int32_t dest = (int32_t)(V - 1);
+    int32_t tail = 0;
+    for (int64_t base = 0; base < V; base += AASM_WAVE) {          // init + sources in ascending id (:139-141)
+        const int64_t v = base + k.lane;
+        const bool act = v < V;
+        int32_t od = 0;
+        if (act) {
+            od = (int32_t)(w.rowptr[vb + v + 1] - w.rowptr[vb + v]);
+            cnt[v] = od;
+            d[v] = (v == dest) ? dist_zero() : dist_max();
+            best[v] = -1;
+        }
+        const bool z = act && od == 0;
+        const uint64_t m = wave_ballot(z);
+        if (z) q[tail + popc64(m & lanemask_lt(k.lane))] = (int32_t)v;
+        tail += popc64(m);
+    }
+    wave_fence();
+    int32_t head = 0;
+    while (head < tail) {
+        const int32_t v = q[head++];
+        const Dist dv = d[v];
+        const bool reach = !dist_is_max(dv);                         // :166
+        const int64_t r0 = w.rptr[vb + v], r1 = w.rptr[vb + v + 1];
+        for (int64_t base = r0; base < r1; base += AASM_WAVE) {
+            const int64_t p = base + k.lane;
+            const bool act = p < r1;
+            bool z = false;
+            int32_t u = 0;
+            if (act) {
+                u = w.r_src[p];
+                if (reach) {
+                    const int64_t e = e_base + w.r_e[p];
+                    const Dist cand = dist_add(dv, edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]));
+                    if (dist_lt<CALC_SUM_MODE>(cand, d[u])) { d[u] = cand; best[u] = v; }   // :168-171
+                }
+                const int32_t left = cnt[u] - 1;
+                cnt[u] = left;
+                z = left == 0;
+            }
+            const uint64_t m = wave_ballot(z);
+            if (z) q[tail + popc64(m & lanemask_lt(k.lane))] = u;
+            tail += popc64(m);
+        }
+        wave_fence();
+    }
+    if (tail != (int32_t)V && k.lane == 0) set_status(w, c, -6);    // cycle: cannot happen (:144-148)
+}
+
+// forward Kahn order (paf_data.cpp:742-746) + anomaly distance to dest.  The reference
+// runs Dial's bucketed BFS on the 0/1/2 anomaly weights (k_weighted_bfs.hpp:16-37) and
+// keeps only anom_dis[dest] (paf_data.cpp:715,1615); on a DAG the same scalar is the
+// min-plus DP along the topological order, folded into this sweep.
+AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    const int64_t vb = w.voff[c];
+    int32_t *q = w.fwd_order + vb, *pos = w.fwd_pos + vb, *cnt = w.cnt_tmp2 + vb, *an = w.an + vb;
+    const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
+    int32_t tail = 0;
+    for (int64_t base = 0; base < V; base += AASM_WAVE) {
+        const int64_t v = base + k.lane;
+        const bool act = v < V;
+        int32_t id = 1;
+        if (act) { id = w.indeg[vb + v]; cnt[v] = id; an[v] = (v == src) ? 0 : -1; }
+        const bool z = act && id == 0;
+        const uint64_t m = wave_ballot(z);
+        if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = (int32_t)v; pos[v] = t; }
+        tail += popc64(m);
+    }
+    wave_fence();
+    int32_t head = 0;
+    while (head < tail) {
+        const int32_t u = q[head++];
+        const int32_t au = an[u];
+        const int64_t r0 = w.rowptr[vb + u], r1 = w.rowptr[vb + u + 1];
+        for (int64_t base = r0; base < r1; base += AASM_WAVE) {
+            const int64_t e = base + k.lane;
+            const bool act = e < r1;
+            bool z = false;
+            int32_t v = 0;
+            if (act) {
+                v = w.e_col[e];
+                if (au >= 0) {
+                    const int32_t nd = au + (w.e_fl[e] & 3);
+                    if (an[v] < 0 || nd < an[v]) an[v] = nd;
+                }
+                const int32_t left = cnt[v] - 1;
+                cnt[v] = left;
+                z = left == 0;
+            }
+            const uint64_t m = wave_ballot(z);
+            if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = v; pos[v] = t; }
+            tail += popc64(m);
+        }
+        wave_fence();
+    }
+    if (k.lane == 0) {
+        w.anom_dest[c] = an[dest];
+        if (tail != (int32_t)V) set_status(w, c, -6);
+    }
+}
+
+// ====================================================================================
+// K7  sidetrack heaps (k_shortest_walks.hpp:191-215; leftist_heap.hpp:29-40)
+// ====================================================================================
+AASM_DEV void kb_child_count(const KCtx &k, const WS &w) {          // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gv]];
+    const int32_t p = w.sp_best[gv];
+    if (p >= 0) atomic_add(&w.ccnt[vb + p], (int32_t)1);
+}
+AASM_DEV void kb_child_fill(const KCtx &k, const WS &w) {           // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gv]];
+    const int32_t p = w.sp_best[gv];
+    if (p >= 0) {
+        const int64_t pos = w.cptr[vb + p] + atomic_add(&w.ccur[vb + p], (int32_t)1);
+        w.cval[pos] = (int32_t)(gv - vb);
+    }
+}
+// arena capacity per contig: an insert into a heap of s nodes allocates at most
+// floor(log2(s+1)) + 2 nodes (right-spine length + the new leaf), s < #sidetracks.
+AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread per contig
+    const int64_t c = k.bid * k.nthreads + k.tid;
+    if (c >= w.C) return;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) { w.hcap_cnt[c] = 0; return; }
+    const int64_t vb = w.voff[c];
+    const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
+    int64_t I = E - (V - 1);
+    if (I < 0) I = 0;
+    int lg = 0;
+    for (int64_t t = I + 1; t > 1; t >>= 1) lg++;
+    int64_t cap = I * (lg + 2) + 8;
+    if (cap > 0x7fffff00) cap = 0x7fffff00;
+    w.hcap_cnt[c] = (int32_t)cap;
+}
+
+AASM_DEV int32_t heap_insert(HNode *nodes, int32_t &alloc, int32_t cap, int32_t a, const Dist &key, int32_t eu, int32_t ev, bool &ovf) {
+    int32_t stack[64];
+    int depth = 0;
+    while (a >= 0 && dist_lt<CALC_SUM_MODE>(hnode_key(nodes[a]), key)) {   // leftist_heap.hpp:30
+        if (depth < 64) stack[depth++] = a; else { ovf = true; return -1; }
+        a = nodes[a].right;
+    }
+    if (alloc + depth + 1 > cap) { ovf = true; return -1; }
+    int32_t r = alloc++;
+    {
+        HNode n; n.kq = key.qry; n.kr = key.ref; n.ka = key.anom; n.kn = key.qnz; n.kt = key.qtot; n.rank = 1;
+        n.left = a; n.right = -1; n.u = eu; n.v = ev;
+        nodes[r] = n;                                                       // :31-32
+    }
+    int32_t r_rank = 1;
+    while (depth > 0) {                                                     // :34-39, unwound
+        const int32_t anc = stack[--depth];
+        HNode n = nodes[anc];
+        int32_t l = n.left, rr = r;
+        int32_t l_rank = (l >= 0) ? nodes[l].rank : 0, rr_rank = r_rank;
+        if (l < 0 || l_rank < rr_rank) { int32_t t = l; l = rr; rr = t; int32_t tr = l_rank; l_rank = rr_rank; rr_rank = tr; }
+        n.left = l; n.right = rr;
+        n.rank = (rr >= 0) ? rr_rank + 1 : 0;
+        r = alloc++;
+        nodes[r] = n;
+        r_rank = n.rank;
+    }
+    return r;
+}
+
+AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // wave per contig, lane 0 works
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0 || k.lane != 0) return;
+    const int64_t vb = w.voff[c];
+    const Dist *d = w.sp_d + vb;
+    const int32_t *best = w.sp_best + vb;
+    int32_t *h = w.h_root + vb, *q = w.bq + vb;
+    HNode *nodes = w.hnodes + w.hoff[c];
+    const int32_t cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
+    const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
+    w.h_cnt[c] = 0;
+    if (dist_is_max(d[src])) { set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
+    int32_t alloc = 0, head = 0, tail = 0;
+    bool ovf = false;
+    q[tail++] = dest;
+    h[dest] = -1;
+    while (head < tail && !ovf) {
+        const int32_t u = q[head++];
+        int32_t hu = h[u];
+        const Dist du = d[u];
+        bool seen_p = false;
+        for (int64_t e = w.rowptr[vb + u]; e < w.rowptr[vb + u + 1] && !ovf; e++) {
+            const int32_t v = w.e_col[e];
+            const Dist dv = d[v];
+            if (dist_is_max(dv)) continue;                           // :204-205
+            const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
+            if (!seen_p && v == best[u] && dist_eq(cc, dist_zero())) { seen_p = true; continue; }   // :207-210
+            hu = heap_insert(nodes, alloc, cap, hu, cc, u, v, ovf);
+        }
+        h[u] = hu;
+        for (int64_t p = w.cptr[vb + u]; p < w.cptr[vb + u + 1]; p++) { const int32_t ch = w.cval[p]; h[ch] = hu; q[tail++] = ch; }   // :213
+    }
+    if (ovf) { set_status(w, c, -5); return; }
+    w.h_cnt[c] = alloc;
+    atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)alloc);
+}
+
+// ====================================================================================
+// K8  k-walk enumeration (k_shortest_walks.hpp:217-249)
+// ====================================================================================
+// std::greater<tuple<Distance, heap_t*, int64_t>>: entries in the queue are distances of
+// real walks (non-negative components), on which operator< is a strict weak order, so the
+// tuple order is total and any correct min-queue pops the same sequence.  The pointer is
+// replaced by the arena index (DESIGN.md "hazard B3").
+AASM_DEV bool pq_less(const PQEnt &a, const PQEnt &b) {
+    if (dist_lt<CALC_SUM_MODE>(a.d, b.d)) return true;
+    if (dist_lt<CALC_SUM_MODE>(b.d, a.d)) return false;
+    if (a.node != b.node) return a.node < b.node;
+    return a.cur < b.cur;
+}
+AASM_DEV void pq_push(PQEnt *hp, int32_t &n, const PQEnt &x) {
+    int32_t i = n++;
+    while (i > 0) {
+        const int32_t p = (i - 1) >> 1;
+        if (!pq_less(x, hp[p])) break;
+        hp[i] = hp[p];
+        i = p;
+    }
+    hp[i] = x;
+}
+AASM_DEV PQEnt pq_pop(PQEnt *hp, int32_t &n) {
+    const PQEnt top = hp[0];
+    const PQEnt x = hp[--n];
+    int32_t i = 0;
+    while (true) {
+        int32_t l = 2 * i + 1;
+        if (l >= n) break;
+        if (l + 1 < n && pq_less(hp[l + 1], hp[l])) l++;
+        if (!pq_less(hp[l], x)) break;
+        hp[i] = hp[l];
+        i = l;
+    }
+    if (n > 0) hp[i] = x;
+    return top;
+}
+
+AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // wave per contig, lane 0 works
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (k.lane != 0) return;
+    w.kfound[c] = 0;
+    if (V == 0 || w.status[c] != 0) return;
+    const int64_t vb = w.voff[c];
+    const int64_t K = w.K;
+    Dist *kd = w.kd + c * K;
+    int32_t *klast = w.klast + c * K, *knodes = w.knodes + c * (3 * K + 1), *kprev = w.kprev + c * (3 * K + 1);
+    PQEnt *hp = w.pq + c * (3 * K + 1);
+    const HNode *nodes = w.hnodes + w.hoff[c];
+    const int32_t *h = w.h_root + vb;
+    const int32_t src = (int32_t)(V - 2);
+    int32_t found = 0, nn = 0, pn = 0;
+    kd[found] = w.sp_d[vb + src]; klast[found] = -1; found++;        // :217-220
+    const int32_t hs = h[src];
+    if (hs >= 0) {                                                  // :227-228
+        PQEnt x; x.d = dist_add(w.sp_d[vb + src], hnode_key(nodes[hs])); x.node = hs; x.cur = nn; x.pad0 = x.pad1 = 0;
+        pq_push(hp, pn, x); knodes[nn] = hs; kprev[nn] = -1; nn++;   // :239
+        while (pn > 0 && found < K) {                               // :240-248
+            const PQEnt top = pq_pop(hp, pn);
+            const HNode ch = nodes[top.node];
+            kd[found] = top.d; klast[found] = top.cur; found++;
+            const int32_t hv = h[ch.v];
+            if (hv >= 0) {
+                PQEnt y; y.d = dist_add(top.d, hnode_key(nodes[hv])); y.node = hv; y.cur = nn; y.pad0 = y.pad1 = 0;
+                pq_push(hp, pn, y); knodes[nn] = hv; kprev[nn] = top.cur; nn++;
+            }
+            const Dist chk = hnode_key(ch);
+            if (ch.left >= 0) {
+                PQEnt y; y.d = dist_sub(dist_add(top.d, hnode_key(nodes[ch.left])), chk); y.node = ch.left; y.cur = nn; y.pad0 = y.pad1 = 0;
+                pq_push(hp, pn, y); knodes[nn] = ch.left; kprev[nn] = kprev[top.cur]; nn++;
+            }
+            if (ch.right >= 0) {
+                PQEnt y; y.d = dist_sub(dist_add(top.d, hnode_key(nodes[ch.right])), chk); y.node = ch.right; y.cur = nn; y.pad0 = y.pad1 = 0;
+                pq_push(hp, pn, y); knodes[nn] = ch.right; kprev[nn] = kprev[top.cur]; nn++;
+            }
+        }
+    }
+    w.kfound[c] = found;
+    atomic_add(&w.counters[CNT_PATHS], (int64_t)found);
+}
+
+// ====================================================================================
+// K9  path recovery, upgrade, conversion, selection
+//     (k_shortest_walks.hpp:254-290; paf_data.cpp:750-921,1489-1649)
+// ====================================================================================
+struct SelCtx {
+    const WS *w;
+    int64_t c, b, N, V, vb, cap;     // cap = N + 2 edge pairs per path buffer
+    int32_t src, dest;
+    int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
+    Dist *dist2;
+    int32_t epoch;
+    bool err;
+};
+
+// k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
+AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
+    const WS &w = *s.w;
+    const int64_t K = w.K;
+    if (kidx < 0 || kidx >= w.kfound[s.c]) return 0;
+    const int32_t *knodes = w.knodes + s.c * (3 * K + 1), *kprev = w.kprev + s.c * (3 * K + 1);
+    const HNode *nodes = w.hnodes + w.hoff[s.c];
+    const int32_t *best = w.sp_best + s.vb;
+    int32_t ns = 0;
+    int32_t cur = w.klast[s.c * K + kidx];
+    while (cur != -1) {                                             // sidetrack chain, newest first
+        if (ns >= s.cap) { s.err = true; return -1; }
+        const HNode nd = nodes[knodes[cur]];
+        s.pathT[2 * ns] = nd.u; s.pathT[2 * ns + 1] = nd.v; ns++;
+        cur = kprev[cur];
+    }
+    int32_t idx = ns - 1, la = 0, cv = s.src;
+    while (cv != s.dest || idx >= 0) {
+        if (la >= s.cap) { s.err = true; return -1; }
+        if (idx >= 0 && cv == s.pathT[2 * idx]) {
+            s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = s.pathT[2 * idx + 1]; la++;
+            cv = s.pathT[2 * idx + 1]; idx--;
+        } else {
+            const int32_t nx = best[cv];
+            if (nx < 0) { s.err = true; return -1; }
+            s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = nx; la++;
+            cv = nx;
+        }
+    }
+    return la;
+}
+
+// internal_shortest_path_recover (paf_data.cpp:750-792): QRY_SCORE-mode DAG DP over the
+// forward topological window [order[a], order[b)); the hash maps become epoch-stamped
+// dense arrays.  Result edges are left in pathT in REVERSE order; returns their count,
+// 0 when a == b, -1 on "must not happen".
+AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
+    const WS &w = *s.w;
+    if (a == bd) return 0;
+    const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
+    const int32_t ep = ++s.epoch;
+    s.dist2[a] = dist_zero(); s.pre2[a] = -1; s.stamp[a] = ep;
+    for (int32_t i = pos[a]; i < pos[bd]; i++) {
+        const int32_t u = order[i];
+        if (s.stamp[u] != ep) continue;
+        const Dist cd = s.dist2[u];
+        for (int64_t e = w.rowptr[s.vb + u]; e < w.rowptr[s.vb + u + 1]; e++) {
+            const int32_t v = w.e_col[e];
+            if (wl_flag && v == bd) {                                // :767-773
+                if (u == s.src || u == s.dest) continue;
+                if (w.v_j[s.vb + u] != wl) continue;
+            }
+            const Dist nd = dist_add(cd, edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]));
+            if (s.stamp[v] != ep || dist_lt<QRY_SCORE_MODE>(nd, s.dist2[v])) { s.dist2[v] = nd; s.pre2[v] = u; s.stamp[v] = ep; }
+        }
+    }
+    if (s.stamp[bd] != ep) { s.err = true; return -1; }             // :783
+    int32_t n = 0, last = bd;
+    while (last != a) {
+        if (n >= s.cap) { s.err = true; return -1; }
+        const int32_t pv = s.pre2[last];
+        s.pathT[2 * n] = pv; s.pathT[2 * n + 1] = last; n++;
+        last = pv;
+    }
+    return n;
+}
+AASM_DEV void sel_push(SelCtx &s, int32_t &lb, int32_t u, int32_t v) {
+    if (lb >= s.cap) { s.err = true; return; }
+    s.pathB[2 * lb] = u; s.pathB[2 * lb + 1] = v; lb++;
+}
+// append the ISPR result (reverse order in pathT), optionally without its last edge
+AASM_DEV void sel_append_alt(SelCtx &s, int32_t &lb, int32_t n, bool drop_last) {
+    for (int32_t t = n - 1; t >= (drop_last ? 1 : 0); t--) sel_push(s, lb, s.pathT[2 * t], s.pathT[2 * t + 1]);
+}
+
+// upgrade_edge_path_with_alt_path (paf_data.cpp:795-921): pathA[la] -> pathB; returns lb
+AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
+    const WS &w = *s.w;
+    int32_t lb = 0;
+    for (int32_t it = 0; it < la && !s.err; ++it) {
+        const int32_t u = s.pathA[2 * it], v = s.pathA[2 * it + 1];
+        const bool from_src = (u == s.src);
+        if (from_src || v != s.dest) {
+            int32_t start;
+            if (from_src) start = u;                                 // :804
+            else {
+                if (lb == 0) { s.err = true; break; }
+                start = s.pathB[2 * lb - 1];                         // continuation_src (:863)
+                if (w.v_i[s.vb + v] != w.v_j[s.vb + v]) { sel_push(s, lb, u, v); continue; }   // :866-873
+            }
+            const int32_t y = w.v_j[s.vb + v];
+            if (it + 1 >= la) { s.err = true; break; }
+            const int32_t nv = s.pathA[2 * (it + 1) + 1];
+            const bool nv_single = (nv == s.dest) || (w.v_i[s.vb + nv] == w.v_j[s.vb + nv]);
+            if (nv_single) {                                         // :812-833 / :879-899
+                const int32_t n = sel_ispr(s, start, nv, true, y);
+                if (n < 0) break;
+                if (n == 0) sel_push(s, lb, u, v);
+                else sel_append_alt(s, lb, n, true);
+            } else {                                                 // :834-843 / :900-909
+                const int32_t n = sel_ispr(s, start, nv, false, -1);
+                if (n < 0) break;
+                if (n == 0) { sel_push(s, lb, u, v); sel_push(s, lb, s.pathA[2 * (it + 1)], nv); }
+                else sel_append_alt(s, lb, n, false);
+                ++it;
+            }
+        } else {                                                     // v == dest (:845-858)
+            if (lb == 0) { s.err = true; break; }
+            const int32_t start = s.pathB[2 * lb - 1];
+            const int32_t n = sel_ispr(s, start, v, false, -1);
+            if (n < 0) break;
+            if (n > 0) sel_append_alt(s, lb, n, false);
+        }
+    }
+    return lb;
+}
+
+AASM_DEV OutElem out_from_rec(const WS &w, int64_t g) {             // PafOutputData(rec), paf_data.hpp:101-104
+    OutElem o; o.qs = w.s_qs[g]; o.qe = w.s_qe[g]; o.rs = w.s_rs[g]; o.re = w.s_re[g]; o.ctg_index = w.s_orig[g]; o.is_alt = 0;
+    return o;
+}
+
+// edge_path_to_paf_path (paf_data.cpp:1489-1568): path k -> cur_out; returns #elements, coverage in cov
+AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
+    const WS &w = *s.w;
+    OutElem *out = w.cur_out + s.b;
+    uint8_t *notalt = w.notalt + s.b;
+    cov = 0;
+    const int32_t la = sel_recover(s, kidx);
+    if (la <= 0) { s.err = true; return 0; }
+    for (int32_t t = 0; t < la; t++) {                               // :1490-1496
+        const int32_t v = s.pathA[2 * t + 1];
+        if (v != s.dest) { notalt[w.v_i[s.vb + v]] = 1; notalt[w.v_j[s.vb + v]] = 1; }
+    }
+    const int32_t lb = sel_upgrade(s, la);                           // :1500-1501
+    if (s.err) return 0;
+    int32_t n = 0;
+    for (int32_t t = 0; t < lb; t++) {                               // :1503-1557
+        const int32_t u = s.pathB[2 * t], v = s.pathB[2 * t + 1];
+        if (v == s.dest) continue;
+        if (n >= s.N) { s.err = true; return 0; }
+        const int32_t y1 = w.v_i[s.vb + v], y2 = w.v_j[s.vb + v];
+        if (u == s.src || y1 == y2) {
+            out[n] = out_from_rec(w, s.b + y2);
+            out[n++].is_alt = notalt[y2] ? 0 : 1;                   // :1560-1566 (map only grows at :1490-1496)
+        } else {
+            if (n == 0) { s.err = true; return 0; }
+            out[n] = out_from_rec(w, s.b + y2);
+            out[n++].is_alt = notalt[y2] ? 0 : 1;
+            const int64_t sl = w.v_slot[s.vb + v];
+            out[n - 2].qe = w.ov_peq[sl]; out[n - 2].re = w.ov_per[sl];   // edited_loc_pre_end[x][y]
+            out[n - 1].qs = w.ov_stq[sl]; out[n - 1].rs = w.ov_str[sl];   // edited_loc_str[x][y]
+        }
+    }
+    for (int32_t t = 0; t < n; t++) {                                // get_total_coverage, :1571-1579
+        cov += (out[t].qe - out[t].qs) + (out[t].re > out[t].rs ? out[t].re - out[t].rs : out[t].rs - out[t].re);
+    }
+    atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
+    return n;
+}
+
+AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // wave per contig, lane 0 works
+    const int64_t c = k.bid;
+    if (k.lane != 0) return;
+    const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    w.main_len[c] = 0; w.alt_len[c] = 0;
+    if (N <= 0) return;
+    if (N == 1) {                                                   // paf_data.cpp:235-239
+        OutElem o; o.qs = w.in_qs[gb]; o.qe = w.in_qe[gb]; o.rs = w.in_rs[gb]; o.re = w.in_re[gb]; o.ctg_index = 0; o.is_alt = 0;
+        w.main_out[b] = o; w.main_len[c] = 1;
+        return;
+    }
+    if (w.status[c] != 0) return;
+    const int32_t found = w.kfound[c];
+    if (found <= 0) { set_status(w, c, -6); return; }               // :732
+    SelCtx s;
+    s.w = &w; s.c = c; s.b = b; s.N = N; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = N + 2;
+    s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
+    const int64_t pb = 2 * (b + 2 * c);                             // (N+2) pairs per contig
+    s.pathA = w.pathA + pb; s.pathB = w.pathB + pb; s.pathT = w.pathT + pb;
+    s.pre2 = w.pre2 + s.vb; s.stamp = w.stamp + s.vb; s.dist2 = w.dist2 + s.vb;
+    s.epoch = 0; s.err = false;
+    const Dist *kd = w.kd + c * (int64_t)w.K;
+    OutElem *cur = w.cur_out + b, *mo = w.main_out + b, *ao = w.alt_out + b;
+    const Dist mind = kd[0];                                        // :1585
+    int64_t cov = 0, max_cov = 0;
+    int32_t n = sel_convert(s, 0, cov);                             // :1589-1593
+    if (s.err) { set_status(w, c, -6); return; }
+    max_cov = cov;
+    for (int32_t t = 0; t < n; t++) mo[t] = cur[t];
+    w.main_len[c] = n;
+    for (int32_t idx = 1; idx < found; idx++) {                     // ties, :1596-1611
+        const Dist dd = kd[idx];
+        if (!(mind.qry + mind.ref == dd.qry + dd.ref && mind.anom == dd.anom)) break;
+        n = sel_convert(s, idx, cov);
+        if (s.err) { set_status(w, c, -6); return; }
+        if (cov > max_cov) {
+            max_cov = cov;
+            for (int32_t t = 0; t < n; t++) mo[t] = cur[t];
+            w.main_len[c] = n;
+            w.all_gen[c] += 1;                                      // paf_ctg_max_out.clear()
+        } else if (cov == max_cov) {
+            const int64_t off = (int64_t)atomic_add(&w.counters[CNT_POOL], (int64_t)n);
+            const int64_t r = (int64_t)atomic_add(&w.counters[CNT_AR], (int64_t)1);
+            if (off + n <= w.pool_cap && r < w.ar_cap) {
+                for (int32_t t = 0; t < n; t++) w.pool[off + t] = cur[t];
+                w.ar_ctg[r] = (int32_t)c; w.ar_gen[r] = w.all_gen[c]; w.ar_seq[r] = w.all_seq[c]; w.ar_off[r] = off; w.ar_len[r] = n;
+            } else {
+                // keep counting the demand; the host re-runs the selection with an exact-size pool
+                atomic_add(&w.counters[CNT_OVF], (int64_t)1);
+            }
+            w.all_seq[c] += 1;
+        }
+    }
+    max_cov = -1;                                                   // alt path, :1613-1649
+    if (found >= 2 && mind.anom != w.anom_dest[c]) {
+        int64_t ans_up = 0, ans_down = 0;
+        int32_t ans_idx = -1;
+        for (int32_t i = 1; i < found; i++) {
+            const Dist dd = kd[i];
+            if (dd.anom >= mind.anom) continue;
+            const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref);
+            const int64_t down = (int64_t)mind.anom - dd.anom;
+            if (ans_idx == -1 || up * ans_down < down * ans_up) {
+                ans_up = up; ans_down = down; ans_idx = i;
+                n = sel_convert(s, i, cov);
+                if (s.err) { set_status(w, c, -6); return; }
+                max_cov = cov;
+                for (int32_t t = 0; t < n; t++) ao[t] = cur[t];
+                w.alt_len[c] = n;
+            } else {
+                const Dist da = kd[ans_idx];
+                if (dd.qry + dd.ref == da.qry + da.ref && dd.anom == da.anom) {
+                    n = sel_convert(s, i, cov);
+                    if (s.err) { set_status(w, c, -6); return; }
+                    if (cov > max_cov) {
+                        max_cov = cov;
+                        for (int32_t t = 0; t < n; t++) ao[t] = cur[t];
+                        w.alt_len[c] = n;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// compaction of main/alt into ragged arrays: one wave per contig
+AASM_DEV void kb_gather_out(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
+    const int64_t b = w.rec_off[c] - w.R0;
+    const int64_t nm = w.main_len[c], na = w.alt_len[c], om = w.main_off[c], oa = w.alt_off[c];
+    for (int64_t t = k.lane; t < nm; t += AASM_WAVE) w.main_c[om + t] = w.main_out[b + t];
+    for (int64_t t = k.lane; t < na; t += AASM_WAVE) w.alt_c[oa + t] = w.alt_out[b + t];
+}
+
+}  // namespace aasm

@@ -1,0 +1,320 @@
+// aasm_pipeline.h -- launch sequence of the per-contig path-inference pipeline.
+//
+// Templated on a Backend that provides memory, launches, scans and scalar read-back:
+//   * GpuBackend (aasm_gpu.hip): HIP stream, pooled device arena, HIP-event phase timers.
+//   * tests/host_emul/emul.cpp: malloc + loops, for CPU-side logic tests only.
+// Sizes are data dependent (slots S, vertices VT, edges ET, heap arena HT), so the
+// sequence is count -> exclusive scan -> read total -> allocate -> fill, with five small
+// device->host scalar reads per batch.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/alignasm_amd.h"
+#include "aasm_kernels.h"
+
+namespace aasm {
+
+enum Kern {
+    KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_SWEEP, KN_FWD_SWEEP,
+    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT
+};
+
+// dispatch a kernel body (used verbatim by both backends)
+AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
+    switch (kn) {
+        case KN_SORT: kb_sort(k, w); break;
+        case KN_SORT_FIX: kb_sort_fix(k, w); break;
+        case KN_GATHER_PARTS: kb_gather_parts(k, w); break;
+        case KN_OV_COUNT: kb_ov_count(k, w); break;
+        case KN_OV_MERGE: kb_ov_merge(k, w); break;
+        case KN_VCOUNT: kb_vcount(k, w); break;
+        case KN_VFILL_REC: kb_vfill_rec(k, w); break;
+        case KN_VFILL_SLOT: kb_vfill_slot(k, w); break;
+        case KN_NSL: kb_nsl(k, w); break;
+        case KN_ROW_COUNT: kb_row_count(k, w); break;
+        case KN_ROW_FILL: kb_row_fill(k, w); break;
+        case KN_REV_FILL: kb_rev_fill(k, w); break;
+        case KN_SORT_ROWS_REV: kb_sort_rows(k, w, w.rptr, w.r_e, w.r_src, w.VT); break;
+        case KN_REV_SWEEP: kb_rev_sweep(k, w); break;
+        case KN_FWD_SWEEP: kb_fwd_sweep(k, w); break;
+        case KN_CHILD_COUNT: kb_child_count(k, w); break;
+        case KN_CHILD_FILL: kb_child_fill(k, w); break;
+        case KN_SORT_ROWS_CHILD: kb_sort_rows(k, w, w.cptr, w.cval, nullptr, w.VT); break;
+        case KN_HEAP_CAP: kb_heap_cap(k, w); break;
+        case KN_HEAP: kb_heap(k, w); break;
+        case KN_ENUM: kb_enum(k, w); break;
+        case KN_SELECT: kb_select(k, w); break;
+        case KN_GATHER_OUT: kb_gather_out(k, w); break;
+        default: break;
+    }
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct PipelineSizes { int64_t C = 0, R = 0, S = 0, VT = 0, ET = 0, HT = 0; };
+
+// Runs the pipeline for contigs [0, C) described by `in` (device pointers; ctg_rec_off
+// already offset to the chunk).  Leaves all intermediates in the backend's arena and
+// returns the filled WS (so fetch / debug can read them).
+template <class B>
+int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, PipelineSizes &sz) {
+    std::memset(&w, 0, sizeof(w));
+    const int64_t C = in.n_contigs;
+    const int64_t R0 = be.read_i64(in.ctg_rec_off), R1 = be.read_i64(in.ctg_rec_off + C);
+    const int64_t R = R1 - R0;
+    w.C = C; w.R = R; w.R0 = R0;
+    w.K = opts.max_paths > 0 ? opts.max_paths : 10000;
+    w.nsl = opts.non_skip_linkable ? 1 : 0;
+    w.rec_off = in.ctg_rec_off; w.in_qs = in.qry_str; w.in_qe = in.qry_end; w.in_rs = in.ref_str; w.in_re = in.ref_end;
+    w.in_qt = in.qry_total; w.in_chr = in.ref_chr; w.in_fwd = in.aln_fwd; w.in_mq = in.map_qul;
+    w.in_rng_off = in.rec_rng_off; w.rql = in.rng_qry_l; w.rqr = in.rng_qry_r; w.rrl = in.rng_ref_l;
+    sz.C = C; sz.R = R;
+    if (C <= 0 || R <= 0) return AASM_E_INVAL;
+
+#define A(field, type, n, name) w.field = (type *)be.alloc(name, sizeof(type) * (size_t)((n) > 0 ? (n) : 1))
+#define AZ(field, type, n, name) do { A(field, type, n, name); be.zero(w.field, sizeof(type) * (size_t)((n) > 0 ? (n) : 1)); } while (0)
+#define CHECK_ALLOC() do { if (be.failed()) return AASM_E_NOMEM; } while (0)
+
+    AZ(status, int32_t, C, "status");
+    AZ(counters, int64_t, CNT_N, "counters");
+
+    // ---- K1 sort + parts
+    be.phase_begin(AASM_PH_SORT);
+    A(perm, int32_t, R, "perm"); AZ(dupflag, int32_t, C, "dupflag"); A(np, int32_t, C, "np"); A(pstart, int32_t, R + C, "pstart");
+    A(s_qs, int64_t, R, "s_qs"); A(s_qe, int64_t, R, "s_qe"); A(s_rs, int64_t, R, "s_rs"); A(s_re, int64_t, R, "s_re");
+    A(s_qt, int64_t, R, "s_qt"); A(s_rb, int64_t, R, "s_rb"); A(s_rn, int32_t, R, "s_rn"); A(s_chr, int32_t, R, "s_chr");
+    A(s_orig, int32_t, R, "s_orig"); A(s_ctg, int32_t, R, "s_ctg"); A(s_pid, int32_t, R, "s_pid"); A(s_fl, uint8_t, R, "s_fl");
+    CHECK_ALLOC();
+    be.launch(KN_SORT, C, 256, w);
+    be.launch(KN_SORT_FIX, cdiv(C, 64), 64, w);
+    be.launch(KN_GATHER_PARTS, C, AASM_WAVE, w);
+    be.phase_end(AASM_PH_SORT);
+
+    // ---- K2 overlap slots
+    be.phase_begin(AASM_PH_PAIRS);
+    A(ov_cnt, int32_t, R, "ov_cnt"); A(ov_off, int64_t, R + 1, "ov_off");
+    CHECK_ALLOC();
+    be.launch(KN_OV_COUNT, cdiv(R, 256), 256, w);
+    be.scan_i32(w.ov_cnt, R, w.ov_off);
+    const int64_t S = be.read_i64(w.ov_off + R);
+    w.S = S; sz.S = S;
+    A(ov_rec, int32_t, S, "ov_rec"); A(ov_vid, int32_t, S, "ov_vid"); A(ov_rank, int64_t, S + 1, "ov_rank");
+    A(ov_peq, int64_t, S, "ov_peq"); A(ov_per, int64_t, S, "ov_per"); A(ov_stq, int64_t, S, "ov_stq"); A(ov_str, int64_t, S, "ov_str");
+    A(ov_ok, uint8_t, S, "ov_ok");
+    CHECK_ALLOC();
+    if (S > 0) be.launch(KN_OV_MERGE, cdiv(S, 256), 256, w);
+    be.scan_u8(w.ov_ok, S, w.ov_rank);
+    A(ctgV, int32_t, C, "ctgV"); A(voff, int64_t, C + 1, "voff");
+    CHECK_ALLOC();
+    be.launch(KN_VCOUNT, cdiv(C, 256), 256, w);
+    be.scan_i32(w.ctgV, C, w.voff);
+    const int64_t VT = be.read_i64(w.voff + C);
+    w.VT = VT; sz.VT = VT;
+    A(v_i, int32_t, VT, "v_i"); A(v_j, int32_t, VT, "v_j"); A(v_ctg, int32_t, VT, "v_ctg"); A(v_slot, int64_t, VT, "v_slot");
+    CHECK_ALLOC();
+    be.launch(KN_VFILL_REC, cdiv(R, 256), 256, w);
+    if (S > 0) be.launch(KN_VFILL_SLOT, cdiv(S, 256), 256, w);
+    be.phase_end(AASM_PH_PAIRS);
+
+    // main/alt outputs exist even when no contig has a graph (all single-record contigs)
+    A(cur_out, OutElem, R, "cur_out"); A(main_out, OutElem, R, "main_out"); A(alt_out, OutElem, R, "alt_out");
+    AZ(main_len, int32_t, C, "main_len"); AZ(alt_len, int32_t, C, "alt_len"); AZ(all_gen, int32_t, C, "all_gen"); AZ(all_seq, int32_t, C, "all_seq");
+    A(main_off, int64_t, C + 1, "main_off"); A(alt_off, int64_t, C + 1, "alt_off");
+    AZ(kfound, int32_t, C, "kfound"); AZ(anom_dest, int32_t, C, "anom_dest"); AZ(h_cnt, int32_t, C, "h_cnt");
+    w.pool_cap = R + 1024; w.ar_cap = C + R / 4 + 1024;
+    A(pool, OutElem, w.pool_cap, "pool");
+    A(ar_ctg, int32_t, w.ar_cap, "ar_ctg"); A(ar_gen, int32_t, w.ar_cap, "ar_gen"); A(ar_seq, int32_t, w.ar_cap, "ar_seq");
+    A(ar_len, int32_t, w.ar_cap, "ar_len"); A(ar_off, int64_t, w.ar_cap, "ar_off");
+    CHECK_ALLOC();
+
+    if (VT > 0) {
+        // ---- K3/K4 CSR
+        be.phase_begin(AASM_PH_EDGES);
+        if (w.nsl) {
+            A(dis_end, int32_t, R, "dis_end"); AZ(next_cnt, int32_t, R, "next_cnt");
+            CHECK_ALLOC();
+            be.launch(KN_NSL, cdiv(R, 256), 256, w);
+        }
+        A(deg, int32_t, VT, "deg"); A(rowptr, int64_t, VT + 1, "csr_rowptr");
+        CHECK_ALLOC();
+        be.launch(KN_ROW_COUNT, cdiv(VT, 256), 256, w);
+        be.scan_i32(w.deg, VT, w.rowptr);
+        const int64_t ET = be.read_i64(w.rowptr + VT);
+        w.ET = ET; sz.ET = ET;
+        A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
+        AZ(indeg, int32_t, VT, "indeg");
+        CHECK_ALLOC();
+        be.launch(KN_ROW_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        be.phase_end(AASM_PH_EDGES);
+
+        // ---- reversed CSR
+        be.phase_begin(AASM_PH_REVCSR);
+        A(rptr, int64_t, VT + 1, "rptr"); AZ(rcur, int32_t, VT, "rcur");
+        A(r_e, int32_t, ET, "r_e"); A(r_src, int32_t, ET, "r_src"); A(tmp_a, int32_t, ET > VT ? ET : VT, "tmp_a"); A(tmp_b, int32_t, ET > VT ? ET : VT, "tmp_b");
+        CHECK_ALLOC();
+        be.scan_i32(w.indeg, VT, w.rptr);
+        be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
+        be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        be.phase_end(AASM_PH_REVCSR);
+
+        // ---- K6 / K5 sweeps
+        A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(rev_order, int32_t, VT, "rev_order"); A(cnt_tmp, int32_t, VT, "cnt_tmp");
+        A(fwd_order, int32_t, VT, "fwd_order"); A(fwd_pos, int32_t, VT, "fwd_pos"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
+        CHECK_ALLOC();
+        be.phase_begin(AASM_PH_SPTREE);
+        be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_SPTREE);
+        be.phase_begin(AASM_PH_FWD);
+        be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_FWD);
+
+        // ---- K7 heaps
+        be.phase_begin(AASM_PH_HEAP);
+        AZ(ccnt, int32_t, VT, "ccnt"); AZ(ccur, int32_t, VT, "ccur"); A(cptr, int64_t, VT + 1, "cptr"); A(cval, int32_t, VT, "cval");
+        A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
+        CHECK_ALLOC();
+        be.launch(KN_CHILD_COUNT, cdiv(VT, 256), 256, w);
+        be.scan_i32(w.ccnt, VT, w.cptr);
+        be.launch(KN_CHILD_FILL, cdiv(VT, 256), 256, w);
+        be.launch(KN_SORT_ROWS_CHILD, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
+        be.scan_i32(w.hcap_cnt, C, w.hoff);
+        const int64_t HT = be.read_i64(w.hoff + C);
+        sz.HT = HT;
+        A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
+        CHECK_ALLOC();
+        be.fill_ff(w.h_root, sizeof(int32_t) * (size_t)VT);
+        be.launch(KN_HEAP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_HEAP);
+
+        // ---- K8 enumeration
+        be.phase_begin(AASM_PH_ENUM);
+        const int64_t K = w.K;
+        A(kd, Dist, C * K, "kd"); A(klast, int32_t, C * K, "klast");
+        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PQEnt, C * (3 * K + 1), "pq");
+        CHECK_ALLOC();
+        be.launch(KN_ENUM, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_ENUM);
+    }
+
+    // ---- K9 selection (also emits the N == 1 contigs)
+    be.phase_begin(AASM_PH_SELECT);
+    A(pathA, int32_t, 2 * (R + 2 * C), "pathA"); A(pathB, int32_t, 2 * (R + 2 * C), "pathB"); A(pathT, int32_t, 2 * (R + 2 * C), "pathT");
+    A(pre2, int32_t, VT, "pre2"); AZ(stamp, int32_t, VT, "stamp"); A(dist2, Dist, VT, "dist2"); AZ(notalt, uint8_t, R, "notalt");
+    CHECK_ALLOC();
+    be.launch(KN_SELECT, C, AASM_WAVE, w);
+    {   // .all pool overflow (tie-heavy inputs): demand is now known exactly -> one re-run
+        const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
+        if (need_pool > w.pool_cap || need_ar > w.ar_cap) {
+            w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
+            A(pool, OutElem, w.pool_cap, "pool");
+            A(ar_ctg, int32_t, w.ar_cap, "ar_ctg"); A(ar_gen, int32_t, w.ar_cap, "ar_gen"); A(ar_seq, int32_t, w.ar_cap, "ar_seq");
+            A(ar_len, int32_t, w.ar_cap, "ar_len"); A(ar_off, int64_t, w.ar_cap, "ar_off");
+            CHECK_ALLOC();
+            be.zero(w.stamp, sizeof(int32_t) * (size_t)(VT > 0 ? VT : 1));
+            be.zero(w.notalt, (size_t)R);
+            be.zero(w.all_gen, sizeof(int32_t) * (size_t)C); be.zero(w.all_seq, sizeof(int32_t) * (size_t)C);
+            be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t));
+            be.zero(w.counters + CNT_CONVERTED, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
+            be.launch(KN_SELECT, C, AASM_WAVE, w);
+        }
+    }
+    be.phase_end(AASM_PH_SELECT);
+
+    // ---- output compaction
+    be.phase_begin(AASM_PH_GATHER);
+    be.scan_i32(w.main_len, C, w.main_off);
+    be.scan_i32(w.alt_len, C, w.alt_off);
+    const int64_t NM = be.read_i64(w.main_off + C), NA = be.read_i64(w.alt_off + C);
+    A(main_c, OutElem, NM, "main_c"); A(alt_c, OutElem, NA, "alt_c");
+    CHECK_ALLOC();
+    be.launch(KN_GATHER_OUT, C, AASM_WAVE, w);
+    be.phase_end(AASM_PH_GATHER);
+#undef A
+#undef AZ
+#undef CHECK_ALLOC
+    return AASM_OK;
+}
+
+// Pack device results into the ragged host structure (shared by both backends).
+template <class B>
+int fetch_results(B &be, const WS &w, const PipelineSizes &sz, aasm_batch_out *out) {
+    std::memset(out, 0, sizeof(*out));
+    const int64_t C = w.C;
+    out->n_contigs = C;
+    out->main_off = (int64_t *)calloc(C + 1, 8);
+    out->alt_off = (int64_t *)calloc(C + 1, 8);
+    out->all_path_off = (int64_t *)calloc(C + 1, 8);
+    out->ctg_status = (int32_t *)calloc(C + 1, 4);
+    be.d2h(out->main_off, w.main_off, (C + 1) * 8);
+    be.d2h(out->alt_off, w.alt_off, (C + 1) * 8);
+    be.d2h(out->ctg_status, w.status, C * 4);
+    const int64_t NM = out->main_off[C], NA = out->alt_off[C];
+    out->main_elems = (aasm_out_elem *)calloc(NM + 1, sizeof(aasm_out_elem));
+    out->alt_elems = (aasm_out_elem *)calloc(NA + 1, sizeof(aasm_out_elem));
+    static_assert(sizeof(aasm_out_elem) == sizeof(OutElem), "layout");
+    if (NM) be.d2h(out->main_elems, w.main_c, NM * sizeof(OutElem));
+    if (NA) be.d2h(out->alt_elems, w.alt_c, NA * sizeof(OutElem));
+    int64_t cnt[CNT_N];
+    be.d2h(cnt, w.counters, sizeof(cnt));
+    // .all paths: keep records of the final generation, ordered by (contig, seq)
+    int64_t nar = cnt[CNT_AR] < w.ar_cap ? cnt[CNT_AR] : w.ar_cap;
+    int64_t npool = cnt[CNT_POOL] < w.pool_cap ? cnt[CNT_POOL] : w.pool_cap;
+    std::vector<int32_t> ar_ctg(nar), ar_gen(nar), ar_seq(nar), ar_len(nar), gen(C);
+    std::vector<int64_t> ar_off(nar);
+    std::vector<OutElem> pool(npool);
+    if (nar) {
+        be.d2h(ar_ctg.data(), w.ar_ctg, nar * 4); be.d2h(ar_gen.data(), w.ar_gen, nar * 4); be.d2h(ar_seq.data(), w.ar_seq, nar * 4);
+        be.d2h(ar_len.data(), w.ar_len, nar * 4); be.d2h(ar_off.data(), w.ar_off, nar * 8);
+        be.d2h(pool.data(), w.pool, npool * sizeof(OutElem));
+    }
+    be.d2h(gen.data(), w.all_gen, C * 4);
+    std::vector<std::vector<std::pair<int32_t, int64_t>>> per(C);   // (seq, record)
+    for (int64_t r = 0; r < nar; r++) {
+        const int32_t c = ar_ctg[r];
+        if (c < 0 || c >= C || ar_gen[r] != gen[c]) continue;
+        if (ar_off[r] + ar_len[r] > npool) continue;
+        per[c].push_back({ar_seq[r], r});
+    }
+    int64_t np = 0, ne = 0;
+    for (int64_t c = 0; c < C; c++) {
+        std::sort(per[c].begin(), per[c].end());
+        np += (int64_t)per[c].size();
+        for (auto &x : per[c]) ne += ar_len[x.second];
+        out->all_path_off[c + 1] = np;
+    }
+    out->n_all_paths = np;
+    out->all_elem_off = (int64_t *)calloc(np + 1, 8);
+    out->all_elems = (aasm_out_elem *)calloc(ne + 1, sizeof(aasm_out_elem));
+    int64_t ip = 0, ie = 0;
+    for (int64_t c = 0; c < C; c++)
+        for (auto &x : per[c]) {
+            std::memcpy(out->all_elems + ie, pool.data() + ar_off[x.second], sizeof(OutElem) * (size_t)ar_len[x.second]);
+            ie += ar_len[x.second];
+            out->all_elem_off[++ip] = ie;
+        }
+    // statistics
+    aasm_stats &st = out->stats;
+    st.n_vertices = sz.VT; st.n_edges = sz.ET;
+    st.n_heap_nodes = cnt[CNT_HEAPNODES]; st.n_paths_found = cnt[CNT_PATHS]; st.n_paths_converted = cnt[CNT_CONVERTED];
+    st.n_unconnectable = cnt[CNT_UNCONN]; st.range_steps = cnt[CNT_RANGE_STEPS];
+    std::vector<int32_t> ctgV(C);
+    be.d2h(ctgV.data(), w.ctgV, C * 4);
+    std::vector<int64_t> roff(C + 1);
+    be.d2h(roff.data(), w.rec_off, (C + 1) * 8);
+    for (int64_t c = 0; c < C; c++) {
+        const int64_t N = roff[c + 1] - roff[c];
+        if (N == 1) st.n_single++;
+        if (ctgV[c] > 0) st.n_pairs += ctgV[c] - 2 - N;
+        if (out->ctg_status[c] != 0) st.n_internal_errors++;
+    }
+    return AASM_OK;
+}
+
+}  // namespace aasm

@@ -1,0 +1,93 @@
+// tests/host_emul/emul.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the product's kernel bodies (alignasm_amd/csrc/aasm_kernels.h) and launch
+// sequence (aasm_pipeline.h) for the HOST with one lane per wave, so the indexing and
+// arithmetic logic of every kernel can be diffed against the oracle in the CPU-only
+// test tier (`pytest -m "not gpu"`).  The product library never links this file and has
+// no CPU fallback: without a HIP device aasm_solve_batch() fails with AASM_E_NODEVICE.
+#define AASM_HOST_EMUL 1
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../alignasm_amd/csrc/aasm_pipeline.h"
+
+using namespace aasm;
+
+namespace {
+struct EmuBackend {
+    std::vector<void *> blocks;
+    std::map<std::string, std::pair<void *, size_t>> named;
+    bool fail = false;
+    ~EmuBackend() { for (void *p : blocks) free(p); }
+    void *alloc(const char *name, size_t bytes) {
+        void *p = malloc(bytes + 64);
+        if (!p) { fail = true; return nullptr; }
+        memset(p, 0xA5, bytes + 64);               // poison: catches reads of never-written cells
+        blocks.push_back(p);
+        named[name] = {p, bytes};
+        return p;
+    }
+    bool failed() const { return fail; }
+    void zero(void *p, size_t n) { memset(p, 0, n); }
+    void fill_ff(void *p, size_t n) { memset(p, 0xFF, n); }
+    void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
+        (void)nthreads;
+        for (int64_t b = 0; b < nblocks; b++) {
+            // one logical thread per block slot: bodies index with bid*nthreads+tid
+            for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {
+                KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0};
+                run_kernel_body(kn, k, w);
+            }
+        }
+    }
+    // wave-per-X kernels run with ONE lane (AASM_WAVE == 1); thread-per-X kernels keep their block size
+    static int nthreads_emul(int kn, int nthreads) {
+        switch (kn) {
+            case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_SORT_ROWS_CHILD:
+            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_HEAP: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT:
+                return 1;
+            default: return nthreads;
+        }
+    }
+    void scan_i32(const int32_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
+    void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
+    int64_t read_i64(const int64_t *p) { return *p; }
+    void d2h(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
+    void phase_begin(int) {}
+    void phase_end(int) {}
+};
+EmuBackend *g_be = nullptr;
+WS g_ws;
+}  // namespace
+
+extern "C" {
+int emul_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
+    delete g_be;
+    g_be = new EmuBackend();
+    aasm_opts o{};
+    if (opts) o = *opts;
+    PipelineSizes sz;
+    int rc = run_pipeline(*g_be, *in, o, g_ws, sz);
+    if (rc != AASM_OK) return rc;
+    return fetch_results(*g_be, g_ws, sz, out);
+}
+void emul_free_out(aasm_batch_out *out) {
+    if (!out) return;
+    free(out->main_off); free(out->alt_off); free(out->all_path_off); free(out->all_elem_off);
+    free(out->main_elems); free(out->alt_elems); free(out->all_elems); free(out->ctg_status);
+    memset(out, 0, sizeof(*out));
+}
+int64_t emul_debug_fetch(const char *name, void *dst, int64_t cap) {
+    if (!g_be) return -1;
+    auto it = g_be->named.find(name);
+    if (it == g_be->named.end()) return -1;
+    if (dst) memcpy(dst, it->second.first, std::min<size_t>((size_t)cap, it->second.second));
+    return (int64_t)it->second.second;
+}
+// libstdc++ std::sort replay used by kb_sort_fix, exposed for a direct test
+void emul_std_sort_replay(int32_t *idx, int64_t n, const int64_t *qs, const int64_t *qe, int depth_override) {
+    KeyLess lt{qs, qe};
+    ss_std_sort(idx, n, lt, depth_override);
+}
+}
