@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 AASM_N_PHASES = 16
-PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "misc"]
+PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "heap_prep", "misc"]
 
 AASM_OK = 0
 AASM_E_INVAL, AASM_E_NODEVICE, AASM_E_HIP, AASM_E_NOMEM = -1, -2, -3, -4
@@ -49,6 +49,7 @@ OUT_ELEM_DTYPE = np.dtype(
 _STAT_I64 = [
     "n_vertices", "n_pairs", "n_edges", "n_heap_nodes", "n_paths_found", "n_paths_converted",
     "n_unconnectable", "n_internal_errors", "n_single", "range_steps", "device_bytes",
+    "ispr_edges", "ispr_vertices", "path_edges", "out_elems", "pq_pushes",
 ]
 
 
@@ -135,6 +136,25 @@ class HostBatch:
             "ref_chr": r, "aln_fwd": r, "map_qul": r, "rec_rng_off": r + 1, "rng_qry_l": g, "rng_qry_r": g, "rng_ref_l": g,
         }
         return HostBatch({name: _np_from(getattr(view, name), sizes[name], dt) for name, dt in _IN_ARRAYS})
+
+    @staticmethod
+    def from_view_range(view: BatchIn, c0, c1):
+        """Copy only contigs [c0, c1) of a borrowed BatchIn (offsets rebased to 0)."""
+        off = _np_from(view.ctg_rec_off, int(view.n_contigs) + 1, np.int64)
+        r0, r1 = int(off[c0]), int(off[c1])
+        isz = {n: np.dtype(dt).itemsize for n, dt in _IN_ARRAYS}
+        ro = _np_from(view.rec_rng_off + r0 * 8, r1 - r0 + 1, np.int64)
+        g0, g1 = int(ro[0]), int(ro[-1])
+        out = {"ctg_rec_off": off[c0:c1 + 1] - r0, "rec_rng_off": ro - g0}
+        for name, dt in _IN_ARRAYS:
+            if name in out:
+                continue
+            base = getattr(view, name)
+            if name.startswith("rng_"):
+                out[name] = _np_from(base + g0 * isz[name], g1 - g0, dt)
+            else:
+                out[name] = _np_from(base + r0 * isz[name], r1 - r0, dt)
+        return HostBatch(out)
 
     def subset(self, contigs):
         """New HostBatch holding only the given contigs (used for sharding and tests)."""

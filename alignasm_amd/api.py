@@ -1,0 +1,219 @@
+"""ctypes binding of libalignasm_amd.so (the C-ABI of include/alignasm_amd.h).
+
+Host-side mirror of the reference's operator boundary for the per-contig path inference
+(`solve_ctg_read`, /root/reference/src/paf_data.hpp:193): `solve_batch()` takes the records
+of many contigs and returns, per contig, the three lists the reference writes to
+`.aln.paf`, `.aln.alt.paf` and `.aln.all.paf`.
+
+There is no CPU fallback: if the shared library is missing the import raises, and every
+solve entry point raises `AlignasmError(AASM_E_NODEVICE)` when no MI355X/HIP device is
+usable.  The CPU oracle under oracle/ is test infrastructure and is never loaded here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (AASM_OK, BatchIn, BatchOut, HostBatch, Opts, Stats, SynthCfg, unpack_out)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalignasm_amd.so")
+
+
+class AlignasmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"alignasm_amd error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C alignasm_amd/csrc).  alignasm_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.aasm_last_error.restype = C.c_char_p
+    lib.aasm_debug_fetch.restype = C.c_int64
+    lib.aasm_paf_n_contigs.restype = C.c_int64
+    lib.aasm_cs_match_ranges.restype = C.c_int64
+    lib.aasm_cs_edit.restype = C.c_int64
+    return lib
+
+
+LIB = _load()
+
+# every symbol include/alignasm_amd.h declares (checked by tests/test_abi.py)
+EXPORTED = [
+    "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
+    "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
+    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_parse_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_paf_write_outputs", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text",
+]
+
+
+def _check(rc):
+    if rc != AASM_OK:
+        raise AlignasmError(rc, (LIB.aasm_last_error() or b"").decode(errors="replace"))
+
+
+def device_count():
+    return int(LIB.aasm_device_count())
+
+
+def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False):
+    return Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
+
+
+class Paf:
+    """Parsed (or synthesised) PAF file held by the library."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def read(path):
+        h = C.c_void_p()
+        _check(LIB.aasm_paf_read(os.fsencode(path), C.byref(h)))
+        return Paf(h)
+
+    @staticmethod
+    def parse(text: bytes):
+        h = C.c_void_p()
+        _check(LIB.aasm_paf_parse_mem(text, C.c_int64(len(text)), C.byref(h)))
+        return Paf(h)
+
+    @staticmethod
+    def synth(n_contigs, recs_per_contig, seed, dense=False, heavy_tail=False, dup_every=0, shuffle=False, no_cs=False):
+        cfg = SynthCfg(n_contigs, recs_per_contig, seed, 1 if dense else 0, 1 if heavy_tail else 0, dup_every,
+                       (1 if shuffle else 0) | (2 if no_cs else 0))
+        h = C.c_void_p()
+        _check(LIB.aasm_synth_paf(C.byref(cfg), C.byref(h)))
+        return Paf(h)
+
+    @property
+    def n_contigs(self):
+        return int(LIB.aasm_paf_n_contigs(self._h))
+
+    def view(self) -> BatchIn:
+        v = BatchIn()
+        _check(LIB.aasm_paf_batch(self._h, C.byref(v)))
+        return v
+
+    def batch(self) -> HostBatch:
+        return HostBatch.from_view(self.view())
+
+    def to_text(self) -> bytes:
+        p = C.c_void_p()
+        n = C.c_int64()
+        _check(LIB.aasm_paf_to_text(self._h, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            C.CDLL(None).free(p)
+
+    def write_outputs(self, out: BatchOut, main_path, alt_path, all_path):
+        _check(LIB.aasm_paf_write_outputs(self._h, C.byref(out), os.fsencode(main_path), os.fsencode(alt_path), os.fsencode(all_path)))
+
+    def close(self):
+        if self._h:
+            LIB.aasm_paf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_batch_raw(view: BatchIn, opts: Opts) -> BatchOut:
+    out = BatchOut()
+    _check(LIB.aasm_solve_batch(C.byref(view), C.byref(opts), C.byref(out)))
+    return out
+
+
+def free_out(out: BatchOut):
+    LIB.aasm_free_out(C.byref(out))
+
+
+def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1):
+    """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
+    view = batch.view if isinstance(batch, HostBatch) else batch.view()
+    if n_devices > 1:
+        out = BatchOut()
+        _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(make_opts(max_paths, non_skip_linkable, device, timing)), int(n_devices), C.byref(out)))
+    else:
+        out = solve_batch_raw(view, make_opts(max_paths, non_skip_linkable, device, timing))
+    try:
+        return unpack_out(out)
+    finally:
+        free_out(out)
+
+
+class DeviceBatch:
+    """A batch uploaded once to HBM; solve() can then be timed without PCIe traffic."""
+
+    def __init__(self, batch, device=0):
+        view = batch.view if isinstance(batch, HostBatch) else batch.view()
+        self._keep = batch
+        self.device = device
+        self._up = C.c_void_p()
+        self.dev_view = BatchIn()
+        _check(LIB.aasm_upload_batch(C.byref(view), int(device), C.byref(self._up), C.byref(self.dev_view)))
+        self.n_contigs = int(view.n_contigs)
+        self.n_records = int(view.n_records)
+
+    def solve(self, max_paths=10000, non_skip_linkable=False, timing=False, keep_debug=False, stream=None):
+        res = C.c_void_p()
+        opts = make_opts(max_paths, non_skip_linkable, self.device, timing, keep_debug)
+        _check(LIB.aasm_solve_device(C.byref(self.dev_view), C.byref(opts), C.c_void_p(stream or 0), C.byref(res)))
+        return DeviceResult(res)
+
+    def close(self):
+        if self._up:
+            LIB.aasm_upload_free(self._up)
+            self._up = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceResult:
+    def __init__(self, handle):
+        self._h = handle
+
+    def stats(self):
+        st = Stats()
+        _check(LIB.aasm_result_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def fetch(self):
+        out = BatchOut()
+        _check(LIB.aasm_result_fetch(self._h, C.byref(out)))
+        try:
+            return unpack_out(out)
+        finally:
+            free_out(out)
+
+    def debug(self, name, dtype):
+        n = LIB.aasm_debug_fetch(self._h, name.encode(), None, C.c_int64(0))
+        if n < 0:
+            raise KeyError(name)
+        buf = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        LIB.aasm_debug_fetch(self._h, name.encode(), buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.nbytes))
+        return buf
+
+    def close(self):
+        if self._h:
+            LIB.aasm_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

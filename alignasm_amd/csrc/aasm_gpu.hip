@@ -1,0 +1,587 @@
+// aasm_gpu.hip -- gfx950 backend of the pipeline + the C-ABI entry points that touch the GPU.
+//
+// * one named __global__ per pipeline kernel (bodies: aasm_kernels.h), so rocprofv3
+//   --kernel-trace shows `aasm_k6_rev_sweep` etc.;
+// * exclusive scans (count -> offsets) as three small kernels;
+// * a per-device arena: device memory is carved by bump allocation out of a few large
+//   hipMalloc blocks that persist across solves (no hipMalloc in the steady state);
+// * everything is enqueued on ONE HIP stream per device context; HIP events bracket each
+//   phase on that stream when opts.collect_timing is set.
+// There is NO CPU fallback here: without a usable HIP device every solve entry point
+// returns AASM_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <mutex>
+#include <thread>
+
+#include "aasm_pipeline.h"
+#include "aasm_paf.hpp"
+
+namespace aasm {
+
+// ------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------
+#define AASM_DEF_KERNEL(name, KN, TPB)                                                        \
+    __global__ void __launch_bounds__(TPB) name(WS w) {                                       \
+        KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
+               (int)(threadIdx.x & 63)};                                                      \
+        run_kernel_body(KN, k, w);                                                            \
+    }
+AASM_DEF_KERNEL(aasm_k1_sort, KN_SORT, 256)
+AASM_DEF_KERNEL(aasm_k1_sort_fix, KN_SORT_FIX, 64)
+AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)
+AASM_DEF_KERNEL(aasm_k2_ov_count, KN_OV_COUNT, 256)
+AASM_DEF_KERNEL(aasm_k2_ov_merge, KN_OV_MERGE, 256)
+AASM_DEF_KERNEL(aasm_k2_vcount, KN_VCOUNT, 256)
+AASM_DEF_KERNEL(aasm_k2_vfill_rec, KN_VFILL_REC, 256)
+AASM_DEF_KERNEL(aasm_k2_vfill_slot, KN_VFILL_SLOT, 256)
+AASM_DEF_KERNEL(aasm_k4_nsl, KN_NSL, 256)
+AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
+AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
+AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
+AASM_DEF_KERNEL(aasm_k6_sort_rows_rev, KN_SORT_ROWS_REV, 64)
+AASM_DEF_KERNEL(aasm_k6_rev_sweep, KN_REV_SWEEP, 64)
+AASM_DEF_KERNEL(aasm_k5_fwd_sweep, KN_FWD_SWEEP, 64)
+AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
+AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
+AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
+AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
+AASM_DEF_KERNEL(aasm_k7_heap, KN_HEAP, 64)
+AASM_DEF_KERNEL(aasm_k8_enum, KN_ENUM, 64)
+AASM_DEF_KERNEL(aasm_k9_select, KN_SELECT, 64)
+AASM_DEF_KERNEL(aasm_k9_gather_out, KN_GATHER_OUT, 64)
+
+// ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
+#define SCAN_TPB 256
+#define SCAN_IPT 8
+#define SCAN_TILE (SCAN_TPB * SCAN_IPT)
+template <class T>
+__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_tiles(const T *in, int64_t n, int64_t *out, int64_t *tile_sum) {
+    __shared__ int64_t sh[SCAN_TPB];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    int64_t v[SCAN_IPT], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) { v[i] = (base + i < n) ? (int64_t)in[base + i] : 0; s += v[i]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_TPB; d <<= 1) {           // Hillis-Steele inclusive over thread sums
+        int64_t t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t run = sh[threadIdx.x] - s;                 // exclusive prefix of this thread
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == SCAN_TPB - 1) tile_sum[blockIdx.x] = sh[SCAN_TPB - 1];
+}
+__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_sums(int64_t *tile_sum, int64_t nt, int64_t *total) {
+    __shared__ int64_t sh[SCAN_TPB];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nt; base += SCAN_TPB) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t x = i < nt ? tile_sum[i] : 0;
+        sh[threadIdx.x] = x;
+        __syncthreads();
+        for (int d = 1; d < SCAN_TPB; d <<= 1) {
+            int64_t t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nt) tile_sum[i] = carry + sh[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sh[SCAN_TPB - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_add(int64_t *out, int64_t n, const int64_t *tile_sum) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    const int64_t add = tile_sum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) if (base + i < n) out[base + i] += add;
+}
+
+// ------------------------------------------------------------------------------------
+// device context + backend
+// ------------------------------------------------------------------------------------
+struct ArenaBlock { char *p; size_t cap, used; };
+
+struct DevCtx {
+    int device = -1;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    std::vector<ArenaBlock> blocks;
+    int64_t *pinned = nullptr;          // host-pinned scalar read-back buffer
+    int64_t *d_scratch = nullptr;       // scan tile sums
+    size_t d_scratch_cap = 0;
+    uint64_t generation = 0;
+    std::mutex mu;
+    hipEvent_t ev_b[AASM_N_PHASES], ev_e[AASM_N_PHASES], ev_t0, ev_t1;
+    bool events = false;
+    size_t peak_bytes = 0;
+};
+static DevCtx g_ctx[16];
+static std::mutex g_init_mu;
+
+static std::string hip_err(const char *what, hipError_t e) {
+    return std::string(what) + ": " + hipGetErrorString(e);
+}
+
+static int ctx_init(int device) {
+    if (device < 0 || device >= 16) { set_last_error("device ordinal out of range"); return AASM_E_INVAL; }
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    DevCtx &cx = g_ctx[device];
+    if (cx.ready) return AASM_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_last_error("no HIP device available (this library has no CPU fallback)"); return AASM_E_NODEVICE; }
+    if (device >= n) { set_last_error("device ordinal beyond hipGetDeviceCount"); return AASM_E_NODEVICE; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { set_last_error(hip_err("hipSetDevice", e)); return AASM_E_NODEVICE; }
+    if ((e = hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking)) != hipSuccess) { set_last_error(hip_err("hipStreamCreate", e)); return AASM_E_NODEVICE; }
+    if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t))) != hipSuccess) { set_last_error(hip_err("hipHostMalloc", e)); return AASM_E_NODEVICE; }
+    for (int i = 0; i < AASM_N_PHASES; i++) { hipEventCreate(&cx.ev_b[i]); hipEventCreate(&cx.ev_e[i]); }
+    hipEventCreate(&cx.ev_t0); hipEventCreate(&cx.ev_t1);
+    cx.events = true;
+    cx.device = device;
+    cx.ready = true;
+    return AASM_OK;
+}
+
+struct GpuBackend {
+    DevCtx &cx;
+    hipStream_t stream;
+    bool timing;
+    bool fail = false;
+    bool phase_used[AASM_N_PHASES] = {false};
+    size_t cur_block = 0, bytes = 0;
+    std::map<std::string, std::pair<void *, size_t>> named;
+    GpuBackend(DevCtx &c, hipStream_t s, bool t) : cx(c), stream(s), timing(t) {
+        for (auto &b : cx.blocks) b.used = 0;
+        cx.generation++;
+    }
+    void hip_fail(const char *what, hipError_t e) { if (!fail) set_last_error(hip_err(what, e)); fail = true; }
+    void *alloc(const char *name, size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        while (cur_block < cx.blocks.size() && cx.blocks[cur_block].used + n > cx.blocks[cur_block].cap) cur_block++;
+        if (cur_block >= cx.blocks.size()) {
+            size_t cap = n > ((size_t)512 << 20) ? n : ((size_t)512 << 20);
+            char *p = nullptr;
+            hipError_t e = hipMalloc((void **)&p, cap);
+            if (e != hipSuccess) { hip_fail("hipMalloc", e); return nullptr; }
+            cx.blocks.push_back(ArenaBlock{p, cap, 0});
+            cur_block = cx.blocks.size() - 1;
+        }
+        ArenaBlock &b = cx.blocks[cur_block];
+        void *p = b.p + b.used;
+        b.used += n;
+        bytes += n;
+        if (bytes > cx.peak_bytes) cx.peak_bytes = bytes;
+        named[name] = {p, n};
+        return p;
+    }
+    bool failed() const { return fail; }
+    void zero(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void fill_ff(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
+        if (fail || nblocks <= 0) return;
+        dim3 g((unsigned)nblocks), b((unsigned)nthreads);
+        switch (kn) {
+#define L(KN, name) case KN: hipLaunchKernelGGL(name, g, b, 0, stream, w); break;
+            L(KN_SORT, aasm_k1_sort) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
+            L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
+            L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
+            L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill)
+            L(KN_SORT_ROWS_REV, aasm_k6_sort_rows_rev) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep)
+            L(KN_CHILD_COUNT, aasm_k7_child_count) L(KN_CHILD_FILL, aasm_k7_child_fill) L(KN_SORT_ROWS_CHILD, aasm_k7_sort_rows_child)
+            L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_HEAP, aasm_k7_heap) L(KN_ENUM, aasm_k8_enum) L(KN_SELECT, aasm_k9_select)
+            L(KN_GATHER_OUT, aasm_k9_gather_out)
+#undef L
+            default: break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) hip_fail("kernel launch", e);
+    }
+    template <class T> void scan_t(const T *in, int64_t n, int64_t *out) {
+        if (fail) return;
+        if (n <= 0) { zero(out, 8); return; }
+        const int64_t nt = cdiv(n, SCAN_TILE);
+        if ((size_t)nt + 8 > cx.d_scratch_cap) {
+            if (cx.d_scratch) hipFree(cx.d_scratch);
+            cx.d_scratch_cap = (size_t)nt * 2 + 1024;
+            hipError_t e = hipMalloc((void **)&cx.d_scratch, cx.d_scratch_cap * 8);
+            if (e != hipSuccess) { cx.d_scratch = nullptr; cx.d_scratch_cap = 0; hip_fail("hipMalloc(scan)", e); return; }
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_tiles<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, cx.d_scratch);
+        hipLaunchKernelGGL(aasm_scan_sums, dim3(1), dim3(SCAN_TPB), 0, stream, cx.d_scratch, nt, out + n);
+        hipLaunchKernelGGL(aasm_scan_add, dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, out, n, cx.d_scratch);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) hip_fail("scan launch", e);
+    }
+    void scan_i32(const int32_t *in, int64_t n, int64_t *out) { scan_t<int32_t>(in, n, out); }
+    void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { scan_t<uint8_t>(in, n, out); }
+    int64_t read_i64(const int64_t *p) {
+        if (fail) return 0;
+        hipError_t e = hipMemcpyAsync(cx.pinned, p, 8, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { hip_fail("scalar read-back", e); return 0; }
+        return cx.pinned[0];
+    }
+    void d2h(void *dst, const void *src, size_t n) {
+        if (fail || n == 0) return;
+        hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) hip_fail("hipMemcpy D2H", e);
+    }
+    void h2d(void *dst, const void *src, size_t n) {
+        if (fail || n == 0) return;
+        hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) hip_fail("hipMemcpy H2D", e);
+    }
+    void phase_begin(int ph) { if (timing && !fail) { hipEventRecord(cx.ev_b[ph], stream); phase_used[ph] = true; } }
+    void phase_end(int ph) { if (timing && !fail) hipEventRecord(cx.ev_e[ph], stream); }
+};
+
+}  // namespace aasm
+
+using namespace aasm;
+
+struct aasm_result {
+    int device;
+    uint64_t generation;
+    WS w;
+    PipelineSizes sz;
+    aasm_stats stats;
+    std::map<std::string, std::pair<void *, size_t>> named;
+    hipStream_t stream;
+};
+
+static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_opts &opts, hipStream_t stream, aasm_result **res_out,
+                           GpuBackend **be_out) {
+    GpuBackend *be = *be_out;
+    const bool timing = opts.collect_timing != 0;
+    aasm_result *res = new aasm_result();
+    res->device = cx.device; res->stream = stream;
+    std::memset(&res->stats, 0, sizeof(res->stats));
+    if (timing) hipEventRecord(cx.ev_t0, stream);
+    int rc = run_pipeline(*be, dev_in, opts, res->w, res->sz);
+    if (timing) hipEventRecord(cx.ev_t1, stream);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (rc == AASM_OK && be->failed()) rc = AASM_E_HIP;
+    if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }
+    if (rc != AASM_OK) { delete res; return rc; }
+    if (timing) {
+        for (int i = 0; i < AASM_N_PHASES; i++)
+            if (be->phase_used[i]) { float ms = 0; hipEventElapsedTime(&ms, cx.ev_b[i], cx.ev_e[i]); res->stats.phase_ms[i] = ms; }
+        float ms = 0; hipEventElapsedTime(&ms, cx.ev_t0, cx.ev_t1); res->stats.total_ms = ms;
+    }
+    {   // counters are tiny: read them now so stats are available without a full fetch
+        int64_t cnt[CNT_N];
+        std::memset(cnt, 0, sizeof(cnt));
+        be->d2h(cnt, res->w.counters, sizeof(cnt));
+        aasm_stats &st = res->stats;
+        st.n_vertices = res->sz.VT; st.n_edges = res->sz.ET;
+        st.n_pairs = res->sz.S > 0 ? be->read_i64(res->w.ov_rank + res->sz.S) : 0;
+        st.n_heap_nodes = cnt[CNT_HEAPNODES]; st.n_paths_found = cnt[CNT_PATHS]; st.n_paths_converted = cnt[CNT_CONVERTED];
+        st.n_unconnectable = cnt[CNT_UNCONN]; st.range_steps = cnt[CNT_RANGE_STEPS];
+        st.ispr_edges = cnt[CNT_ISPR_E]; st.ispr_vertices = cnt[CNT_ISPR_V]; st.path_edges = cnt[CNT_PATH_E];
+        st.out_elems = cnt[CNT_OUT_E]; st.pq_pushes = cnt[CNT_PQ_PUSH];
+        if (be->failed()) { delete res; return AASM_E_HIP; }
+    }
+    res->stats.device_bytes = (int64_t)be->bytes;
+    res->generation = cx.generation;
+    res->named = be->named;
+    *res_out = res;
+    return AASM_OK;
+}
+
+extern "C" {
+
+int aasm_abi_version(void) { return AASM_ABI_VERSION; }
+
+int aasm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int aasm_init(int device) { return ctx_init(device); }
+
+int aasm_solve_device(const aasm_batch_in *dev_in, const aasm_opts *opts, void *stream, aasm_result **res) {
+    if (!dev_in || !res) return AASM_E_INVAL;
+    aasm_opts o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    int rc = ctx_init(o.device);
+    if (rc != AASM_OK) return rc;
+    DevCtx &cx = g_ctx[o.device];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    hipSetDevice(o.device);
+    hipStream_t s = stream ? (hipStream_t)stream : cx.stream;
+    GpuBackend be(cx, s, o.collect_timing != 0);
+    GpuBackend *bp = &be;
+    return solve_on_device(cx, *dev_in, o, s, res, &bp);
+}
+
+int aasm_result_stats(const aasm_result *res, aasm_stats *stats) {
+    if (!res || !stats) return AASM_E_INVAL;
+    *stats = res->stats;
+    return AASM_OK;
+}
+
+// minimal backend view for fetch (D2H only)
+namespace {
+struct FetchBackend {
+    hipStream_t stream; bool fail = false;
+    void d2h(void *dst, const void *src, size_t n) {
+        if (fail || n == 0) return;
+        hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { set_last_error(hip_err("hipMemcpy D2H", e)); fail = true; }
+    }
+};
+}
+
+int aasm_result_fetch(aasm_result *res, aasm_batch_out *out) {
+    if (!res || !out) return AASM_E_INVAL;
+    DevCtx &cx = g_ctx[res->device];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if (res->generation != cx.generation) { set_last_error("result was invalidated by a later solve on the same device"); return AASM_E_INVAL; }
+    hipSetDevice(res->device);
+    FetchBackend fb{res->stream};
+    int rc = fetch_results(fb, res->w, res->sz, out);
+    if (fb.fail) { aasm_free_out(out); return AASM_E_HIP; }
+    if (rc != AASM_OK) return rc;
+    // keep the device-side timers / sizes
+    aasm_stats st = out->stats;
+    std::memcpy(st.phase_ms, res->stats.phase_ms, sizeof(st.phase_ms));
+    st.total_ms = res->stats.total_ms; st.device_bytes = res->stats.device_bytes;
+    std::memcpy(st.reserved_f, res->stats.reserved_f, sizeof(st.reserved_f));
+    out->stats = st;
+    return AASM_OK;
+}
+
+void aasm_result_free(aasm_result *res) { delete res; }
+
+void aasm_free_out(aasm_batch_out *out) {
+    if (!out) return;
+    free(out->main_off); free(out->alt_off); free(out->all_path_off); free(out->all_elem_off);
+    free(out->main_elems); free(out->alt_elems); free(out->all_elems); free(out->ctg_status);
+    std::memset(out, 0, sizeof(*out));
+}
+
+int64_t aasm_debug_fetch(aasm_result *res, const char *name, void *dst, int64_t dst_bytes) {
+    if (!res || !name) return AASM_E_INVAL;
+    DevCtx &cx = g_ctx[res->device];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if (res->generation != cx.generation) return AASM_E_INVAL;
+    auto it = res->named.find(name);
+    if (it == res->named.end()) return AASM_E_INVAL;
+    if (dst) {
+        hipSetDevice(res->device);
+        size_t n = std::min<size_t>((size_t)dst_bytes, it->second.second);
+        hipError_t e = hipMemcpy(dst, it->second.first, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_last_error(hip_err("debug fetch", e)); return AASM_E_HIP; }
+    }
+    return (int64_t)it->second.second;
+}
+
+// Upload a host batch once (bench / repeated solves): returns a device view.
+// The upload lives in plain hipMalloc memory owned by the handle (not in the arena).
+struct aasm_upload { int device; std::vector<void *> ptrs; aasm_batch_in view; };
+
+static int upload_range(const aasm_batch_in *in, int64_t c0, int64_t c1, int device, aasm_upload **up_out, aasm_batch_in *dev_view) {
+    if (!in || !up_out || !dev_view || c0 < 0 || c1 > in->n_contigs || c0 >= c1) return AASM_E_INVAL;
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    hipSetDevice(device);
+    aasm_upload *up = new aasm_upload();
+    up->device = device;
+    bool ok = true;
+    auto put = [&](const void *src, size_t bytes) -> void * {
+        void *p = nullptr;
+        if (!ok) return nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
+        up->ptrs.push_back(p);
+        if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return p;
+    };
+    // rebase the offsets of the contig range [c0, c1) to start at 0
+    const int64_t C = c1 - c0, r0 = in->ctg_rec_off[c0], r1 = in->ctg_rec_off[c1], R = r1 - r0;
+    const int64_t g0 = in->rec_rng_off[r0], g1 = in->rec_rng_off[r1], G = g1 - g0;
+    std::vector<int64_t> coff(C + 1), roff(R + 1);
+    for (int64_t c = 0; c <= C; c++) coff[c] = in->ctg_rec_off[c0 + c] - r0;
+    for (int64_t r = 0; r <= R; r++) roff[r] = in->rec_rng_off[r0 + r] - g0;
+    aasm_batch_in &v = up->view;
+    v.n_contigs = C; v.n_records = R; v.n_ranges = G;
+    v.ctg_rec_off = (const int64_t *)put(coff.data(), (C + 1) * 8);
+    v.qry_str = (const int64_t *)put(in->qry_str + r0, R * 8);
+    v.qry_end = (const int64_t *)put(in->qry_end + r0, R * 8);
+    v.ref_str = (const int64_t *)put(in->ref_str + r0, R * 8);
+    v.ref_end = (const int64_t *)put(in->ref_end + r0, R * 8);
+    v.qry_total = (const int64_t *)put(in->qry_total + r0, R * 8);
+    v.ref_chr = (const int32_t *)put(in->ref_chr + r0, R * 4);
+    v.aln_fwd = (const uint8_t *)put(in->aln_fwd + r0, R);
+    v.map_qul = (const uint8_t *)put(in->map_qul + r0, R);
+    v.rec_rng_off = (const int64_t *)put(roff.data(), (R + 1) * 8);
+    v.rng_qry_l = (const int64_t *)put(in->rng_qry_l + g0, G * 8);
+    v.rng_qry_r = (const int64_t *)put(in->rng_qry_r + g0, G * 8);
+    v.rng_ref_l = (const int64_t *)put(in->rng_ref_l + g0, G * 8);
+    if (!ok) {
+        for (void *p : up->ptrs) hipFree(p);
+        delete up;
+        set_last_error("device upload failed (out of memory?)");
+        return AASM_E_NOMEM;
+    }
+    *dev_view = up->view;
+    *up_out = up;
+    return AASM_OK;
+}
+int aasm_upload_batch(const aasm_batch_in *in, int device, aasm_upload **up_out, aasm_batch_in *dev_view) {
+    if (!in) return AASM_E_INVAL;
+    return upload_range(in, 0, in->n_contigs, device, up_out, dev_view);
+}
+void aasm_upload_free(aasm_upload *up) {
+    if (!up) return;
+    hipSetDevice(up->device);
+    for (void *p : up->ptrs) hipFree(p);
+    delete up;
+}
+
+static int validate_batch(const aasm_batch_in *in) {
+    if (!in || in->n_contigs <= 0 || !in->ctg_rec_off || in->ctg_rec_off[0] != 0 || in->ctg_rec_off[in->n_contigs] != in->n_records) {
+        set_last_error("inconsistent contig offsets");
+        return AASM_E_INVAL;
+    }
+    for (int64_t c = 0; c < in->n_contigs; c++)
+        if (in->ctg_rec_off[c + 1] <= in->ctg_rec_off[c]) { set_last_error("empty contig"); return AASM_E_INVAL; }
+    return AASM_OK;
+}
+
+static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
+    aasm_upload *up = nullptr;
+    aasm_batch_in dv;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = upload_range(in, c0, c1, o.device, &up, &dv);
+    if (rc != AASM_OK) return rc;
+    auto t1 = std::chrono::steady_clock::now();
+    aasm_result *res = nullptr;
+    rc = aasm_solve_device(&dv, &o, nullptr, &res);
+    if (rc == AASM_OK) {
+        auto t2 = std::chrono::steady_clock::now();
+        rc = aasm_result_fetch(res, out);
+        auto t3 = std::chrono::steady_clock::now();
+        if (rc == AASM_OK) {
+            out->stats.reserved_f[0] = std::chrono::duration<float, std::milli>(t1 - t0).count();   // H2D upload
+            out->stats.reserved_f[1] = std::chrono::duration<float, std::milli>(t3 - t2).count();   // D2H + pack
+            out->stats.reserved_f[2] = std::chrono::duration<float, std::milli>(t2 - t1).count();   // solve wall
+        }
+    }
+    aasm_result_free(res);
+    aasm_upload_free(up);
+    return rc;
+}
+
+int aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
+    if (!in || !out) return AASM_E_INVAL;
+    aasm_opts o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    int rc = validate_batch(in);
+    if (rc != AASM_OK) return rc;
+    return solve_range(in, 0, in->n_contigs, o, out);
+}
+
+// Contig-sharded solve over n_devices GPUs of one node (devices opts.device .. +n-1):
+// static contiguous partition balanced on a per-contig cost estimate, one host thread and
+// one stream per device, results concatenated in contig order.  No collective anywhere:
+// contigs are independent (reference: one TBB task per contig, src/alignasm.cpp:351-359).
+int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n_devices, aasm_batch_out *out) {
+    if (!in || !out || n_devices < 1) return AASM_E_INVAL;
+    aasm_opts o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    int rc = validate_batch(in);
+    if (rc != AASM_OK) return rc;
+    const int64_t C = in->n_contigs;
+    if (n_devices > C) n_devices = (int)C;
+    if (n_devices == 1) return solve_range(in, 0, C, o, out);
+    // cost model: sequential per-contig chains dominate -> cost ~ N (records) + fixed term
+    std::vector<double> pre(C + 1, 0.0);
+    for (int64_t c = 0; c < C; c++) pre[c + 1] = pre[c] + (double)(in->ctg_rec_off[c + 1] - in->ctg_rec_off[c]) + 16.0;
+    std::vector<int64_t> cut(n_devices + 1, 0);
+    cut[n_devices] = C;
+    for (int d = 1; d < n_devices; d++) {
+        const double target = pre[C] * d / n_devices;
+        int64_t c = std::lower_bound(pre.begin(), pre.end(), target) - pre.begin();
+        if (c <= cut[d - 1]) c = cut[d - 1] + 1;
+        if (c > C - (n_devices - d)) c = C - (n_devices - d);
+        cut[d] = c;
+    }
+    std::vector<aasm_batch_out> parts(n_devices);
+    std::vector<int> rcs(n_devices, AASM_OK);
+    std::vector<std::string> errs(n_devices);
+    {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_devices; d++)
+            th.emplace_back([&, d] {
+                aasm_opts od = o;
+                od.device = o.device + d;
+                std::memset(&parts[d], 0, sizeof(parts[d]));
+                rcs[d] = solve_range(in, cut[d], cut[d + 1], od, &parts[d]);
+                if (rcs[d] != AASM_OK) errs[d] = aasm_last_error();
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < n_devices; d++)
+        if (rcs[d] != AASM_OK) {
+            set_last_error("device " + std::to_string(o.device + d) + ": " + errs[d]);
+            for (auto &p : parts) aasm_free_out(&p);
+            return rcs[d];
+        }
+    // concatenate
+    std::memset(out, 0, sizeof(*out));
+    out->n_contigs = C;
+    int64_t nm = 0, na = 0, np = 0, ne = 0;
+    for (auto &p : parts) { nm += p.main_off[p.n_contigs]; na += p.alt_off[p.n_contigs]; np += p.n_all_paths; ne += p.all_elem_off[p.n_all_paths]; }
+    out->main_off = (int64_t *)calloc(C + 1, 8); out->alt_off = (int64_t *)calloc(C + 1, 8); out->all_path_off = (int64_t *)calloc(C + 1, 8);
+    out->all_elem_off = (int64_t *)calloc(np + 1, 8); out->ctg_status = (int32_t *)calloc(C + 1, 4);
+    out->main_elems = (aasm_out_elem *)calloc(nm + 1, sizeof(aasm_out_elem));
+    out->alt_elems = (aasm_out_elem *)calloc(na + 1, sizeof(aasm_out_elem));
+    out->all_elems = (aasm_out_elem *)calloc(ne + 1, sizeof(aasm_out_elem));
+    out->n_all_paths = np;
+    int64_t bm = 0, ba = 0, bp = 0, be_ = 0;
+    for (int d = 0; d < n_devices; d++) {
+        aasm_batch_out &p = parts[d];
+        const int64_t pc = p.n_contigs, c0 = cut[d];
+        for (int64_t c = 0; c < pc; c++) {
+            out->main_off[c0 + c + 1] = bm + p.main_off[c + 1];
+            out->alt_off[c0 + c + 1] = ba + p.alt_off[c + 1];
+            out->all_path_off[c0 + c + 1] = bp + p.all_path_off[c + 1];
+            out->ctg_status[c0 + c] = p.ctg_status[c];
+        }
+        for (int64_t q = 0; q < p.n_all_paths; q++) out->all_elem_off[bp + q + 1] = be_ + p.all_elem_off[q + 1];
+        std::memcpy(out->main_elems + bm, p.main_elems, sizeof(aasm_out_elem) * (size_t)p.main_off[pc]);
+        std::memcpy(out->alt_elems + ba, p.alt_elems, sizeof(aasm_out_elem) * (size_t)p.alt_off[pc]);
+        std::memcpy(out->all_elems + be_, p.all_elems, sizeof(aasm_out_elem) * (size_t)p.all_elem_off[p.n_all_paths]);
+        bm += p.main_off[pc]; ba += p.alt_off[pc]; bp += p.n_all_paths; be_ += p.all_elem_off[p.n_all_paths];
+        aasm_stats &a = out->stats; const aasm_stats &b = p.stats;
+        a.n_vertices += b.n_vertices; a.n_pairs += b.n_pairs; a.n_edges += b.n_edges; a.n_heap_nodes += b.n_heap_nodes;
+        a.n_paths_found += b.n_paths_found; a.n_paths_converted += b.n_paths_converted; a.n_unconnectable += b.n_unconnectable;
+        a.n_internal_errors += b.n_internal_errors; a.n_single += b.n_single; a.range_steps += b.range_steps;
+        a.ispr_edges += b.ispr_edges; a.ispr_vertices += b.ispr_vertices; a.path_edges += b.path_edges; a.out_elems += b.out_elems; a.pq_pushes += b.pq_pushes;
+        if (b.device_bytes > a.device_bytes) a.device_bytes = b.device_bytes;
+        for (int i = 0; i < AASM_N_PHASES; i++) if (b.phase_ms[i] > a.phase_ms[i]) a.phase_ms[i] = b.phase_ms[i];
+        if (b.total_ms > a.total_ms) a.total_ms = b.total_ms;
+        for (int i = 0; i < 3; i++) if (b.reserved_f[i] > a.reserved_f[i]) a.reserved_f[i] = b.reserved_f[i];
+        aasm_free_out(&p);
+    }
+    return AASM_OK;
+}
+
+}  // extern "C"

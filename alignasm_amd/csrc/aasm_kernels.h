@@ -77,7 +77,7 @@ struct WS {
     int64_t *counters;
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 
@@ -1009,6 +1009,7 @@ AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // wave per 
     }
     w.kfound[c] = found;
     atomic_add(&w.counters[CNT_PATHS], (int64_t)found);
+    atomic_add(&w.counters[CNT_PQ_PUSH], (int64_t)nn);
 }
 
 // ====================================================================================
@@ -1023,6 +1024,7 @@ struct SelCtx {
     Dist *dist2;
     int32_t epoch;
     bool err;
+    int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
 };
 
 // k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
@@ -1071,6 +1073,7 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
         const int32_t u = order[i];
         if (s.stamp[u] != ep) continue;
         const Dist cd = s.dist2[u];
+        s.n_ispr_v++; s.n_ispr_e += w.rowptr[s.vb + u + 1] - w.rowptr[s.vb + u];
         for (int64_t e = w.rowptr[s.vb + u]; e < w.rowptr[s.vb + u + 1]; e++) {
             const int32_t v = w.e_col[e];
             if (wl_flag && v == bd) {                                // :767-773
@@ -1161,6 +1164,7 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
     }
     const int32_t lb = sel_upgrade(s, la);                           // :1500-1501
     if (s.err) return 0;
+    s.n_path_e += la + lb;
     int32_t n = 0;
     for (int32_t t = 0; t < lb; t++) {                               // :1503-1557
         const int32_t u = s.pathB[2 * t], v = s.pathB[2 * t + 1];
@@ -1183,6 +1187,7 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
         cov += (out[t].qe - out[t].qs) + (out[t].re > out[t].rs ? out[t].re - out[t].rs : out[t].rs - out[t].re);
     }
     atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
+    s.n_out_e += n;
     return n;
 }
 
@@ -1206,7 +1211,7 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // wave per 
     const int64_t pb = 2 * (b + 2 * c);                             // (N+2) pairs per contig
     s.pathA = w.pathA + pb; s.pathB = w.pathB + pb; s.pathT = w.pathT + pb;
     s.pre2 = w.pre2 + s.vb; s.stamp = w.stamp + s.vb; s.dist2 = w.dist2 + s.vb;
-    s.epoch = 0; s.err = false;
+    s.epoch = 0; s.err = false; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
     const Dist *kd = w.kd + c * (int64_t)w.K;
     OutElem *cur = w.cur_out + b, *mo = w.main_out + b, *ao = w.alt_out + b;
     const Dist mind = kd[0];                                        // :1585
@@ -1269,6 +1274,8 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // wave per 
             }
         }
     }
+    atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
+    atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
 }
 
 // compaction of main/alt into ragged arrays: one wave per contig

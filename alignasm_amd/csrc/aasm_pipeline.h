@@ -175,7 +175,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_end(AASM_PH_FWD);
 
         // ---- K7 heaps
-        be.phase_begin(AASM_PH_HEAP);
+        be.phase_begin(AASM_PH_HEAP_PREP);
         AZ(ccnt, int32_t, VT, "ccnt"); AZ(ccur, int32_t, VT, "ccur"); A(cptr, int64_t, VT + 1, "cptr"); A(cval, int32_t, VT, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
         CHECK_ALLOC();
@@ -190,25 +190,28 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
         CHECK_ALLOC();
         be.fill_ff(w.h_root, sizeof(int32_t) * (size_t)VT);
+        be.phase_end(AASM_PH_HEAP_PREP);
+        be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_HEAP);
 
         // ---- K8 enumeration
-        be.phase_begin(AASM_PH_ENUM);
         const int64_t K = w.K;
         A(kd, Dist, C * K, "kd"); A(klast, int32_t, C * K, "klast");
         A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PQEnt, C * (3 * K + 1), "pq");
         CHECK_ALLOC();
+        be.phase_begin(AASM_PH_ENUM);
         be.launch(KN_ENUM, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_ENUM);
     }
 
     // ---- K9 selection (also emits the N == 1 contigs)
-    be.phase_begin(AASM_PH_SELECT);
     A(pathA, int32_t, 2 * (R + 2 * C), "pathA"); A(pathB, int32_t, 2 * (R + 2 * C), "pathB"); A(pathT, int32_t, 2 * (R + 2 * C), "pathT");
     A(pre2, int32_t, VT, "pre2"); AZ(stamp, int32_t, VT, "stamp"); A(dist2, Dist, VT, "dist2"); AZ(notalt, uint8_t, R, "notalt");
     CHECK_ALLOC();
+    be.phase_begin(AASM_PH_SELECT);
     be.launch(KN_SELECT, C, AASM_WAVE, w);
+    be.phase_end(AASM_PH_SELECT);
     {   // .all pool overflow (tie-heavy inputs): demand is now known exactly -> one re-run
         const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
         if (need_pool > w.pool_cap || need_ar > w.ar_cap) {
@@ -222,10 +225,11 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.zero(w.all_gen, sizeof(int32_t) * (size_t)C); be.zero(w.all_seq, sizeof(int32_t) * (size_t)C);
             be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t));
             be.zero(w.counters + CNT_CONVERTED, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
+            be.phase_begin(AASM_PH_MISC);
             be.launch(KN_SELECT, C, AASM_WAVE, w);
+            be.phase_end(AASM_PH_MISC);
         }
     }
-    be.phase_end(AASM_PH_SELECT);
 
     // ---- output compaction
     be.phase_begin(AASM_PH_GATHER);
@@ -304,6 +308,8 @@ int fetch_results(B &be, const WS &w, const PipelineSizes &sz, aasm_batch_out *o
     st.n_vertices = sz.VT; st.n_edges = sz.ET;
     st.n_heap_nodes = cnt[CNT_HEAPNODES]; st.n_paths_found = cnt[CNT_PATHS]; st.n_paths_converted = cnt[CNT_CONVERTED];
     st.n_unconnectable = cnt[CNT_UNCONN]; st.range_steps = cnt[CNT_RANGE_STEPS];
+    st.ispr_edges = cnt[CNT_ISPR_E]; st.ispr_vertices = cnt[CNT_ISPR_V]; st.path_edges = cnt[CNT_PATH_E]; st.out_elems = cnt[CNT_OUT_E];
+    st.pq_pushes = cnt[CNT_PQ_PUSH];
     std::vector<int32_t> ctgV(C);
     be.d2h(ctgV.data(), w.ctgV, C * 4);
     std::vector<int64_t> roff(C + 1);

@@ -1,0 +1,98 @@
+// alignasm_main.cpp -- `alignasm <input.paf>` command line, MI355X build.
+//
+// Keeps the reference's CLI surface and file contract (src/alignasm.cpp:30-75,487-490):
+//   alignasm PAF_LOC [-t THREAD] [-a PAF_ALT_LOC] [-b ALT_BASELINE] [--non_skip_linkable]
+//   -> <stem>.aln.paf, <stem>.aln.alt.paf, <stem>.aln.all.paf next to the input,
+// and adds --max-paths K (MAX_PATH_COUNT, default 10000), --gpus N, --device D.
+// -t is accepted for compatibility (the per-contig parallelism now lives on the GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <iostream>
+#include <string>
+
+#include "../../include/alignasm_amd.h"
+
+static void usage(std::ostream &os) {
+    os << "Usage: alignasm [--help] [--version] [--thread THREAD] [--alt PAF_ALT_LOC] [--alt_baseline ALT_BASELINE] "
+          "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] PAF_LOC\n\n"
+          "Positional arguments:\n  PAF_LOC              Location of PAF file [required]\n\n"
+          "Optional arguments:\n  -h, --help           shows help message and exits\n  -v, --version        prints version information and exits\n"
+          "  -t, --thread THREAD  Number of threads (accepted for compatibility) [default: 1]\n"
+          "  -a, --alt PAF_ALT_LOC  Location of alternative PAF file\n"
+          "  -b, --alt_baseline ALT_BASELINE  Baseline for coverage of alternative PAF file [default: 0.5]\n"
+          "  --non_skip_linkable  no edge a -> b when a -> c -> b exists\n"
+          "  --max-paths K        paths enumerated per contig (reference constant MAX_PATH_COUNT) [default: 10000]\n"
+          "  --gpus N             shard contigs over N GPUs of this node [default: 1]\n"
+          "  --device D           first HIP device ordinal [default: 0]\n";
+}
+
+int main(int argc, char **argv) {
+    std::string paf_loc, alt_loc;
+    aasm_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    opts.max_paths = 10000;
+    int gpus = 1;
+    bool bad = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char *what) -> const char * {
+            if (i + 1 >= argc) { std::cerr << what << ": missing value\n"; bad = true; return "0"; }
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") { usage(std::cout); return 0; }
+        else if (a == "-v" || a == "--version") { std::cout << "0.1.0\n"; return 0; }
+        else if (a == "-t" || a == "--thread") (void)std::atoi(need("--thread"));
+        else if (a == "-a" || a == "--alt") alt_loc = need("--alt");
+        else if (a == "-b" || a == "--alt_baseline") (void)std::atof(need("--alt_baseline"));
+        else if (a == "--non_skip_linkable") opts.non_skip_linkable = 1;
+        else if (a == "--max-paths") opts.max_paths = std::atoi(need("--max-paths"));
+        else if (a == "--gpus") gpus = std::atoi(need("--gpus"));
+        else if (a == "--device") opts.device = std::atoi(need("--device"));
+        else if (!a.empty() && a[0] == '-') { std::cerr << "Unknown argument: " << a << "\n"; bad = true; }
+        else if (paf_loc.empty()) paf_loc = a;
+        else { std::cerr << "Maximum number of positional arguments exceeded\n"; bad = true; }
+    }
+    if (bad || paf_loc.empty()) { usage(std::cerr); return 1; }                 // alignasm.cpp:59-65
+    std::filesystem::path p{paf_loc};
+    if (p.extension() != ".paf") {                                              // :67-72
+        std::cerr << "Wrong PAF file : " << std::filesystem::absolute(p);
+        usage(std::cerr);
+        return 1;
+    }
+    if (!alt_loc.empty()) {
+        std::error_code ec;
+        auto sz = std::filesystem::file_size(alt_loc, ec);
+        if (std::filesystem::path(alt_loc).extension() != ".paf") {
+            std::cerr << "Wrong PAF file : " << std::filesystem::absolute(alt_loc);
+            usage(std::cerr);
+            return 1;
+        }
+        if (ec || sz != 0) {                                                    // empty file == no --alt (:196-200)
+            std::cerr << "--alt merge (src/alignasm.cpp:186-332) is not implemented in this build\n";
+            return 1;
+        }
+    }
+    aasm_paf *paf = nullptr;
+    int rc = aasm_paf_read(std::filesystem::absolute(p).c_str(), &paf);
+    if (rc != AASM_OK) { std::cerr << aasm_last_error() << "\n"; return 1; }    // e.g. "Missing cs:Z tag ..." (:165-168)
+    std::cout << "File read complete" << std::endl;                              // :340
+    aasm_batch_in view;
+    aasm_paf_batch(paf, &view);
+    std::cout << "Analyze PAF " << view.n_contigs << " data in parallel" << std::endl;   // :349
+    aasm_batch_out out;
+    rc = aasm_solve_batch_multi(&view, &opts, gpus, &out);
+    if (rc != AASM_OK) { std::cerr << "alignasm: solver failed (" << rc << "): " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 2; }
+    if (out.stats.n_internal_errors) std::cerr << "alignasm: " << out.stats.n_internal_errors << " contig(s) hit an internal error state\n";
+    std::cout << "Write output PAF file" << std::endl;                           // :487
+    auto ap = std::filesystem::absolute(p);
+    auto f_main = ap; f_main.replace_extension(".aln.paf");
+    auto f_alt = ap; f_alt.replace_extension(".aln.alt.paf");
+    auto f_all = ap; f_all.replace_extension(".aln.all.paf");
+    rc = aasm_paf_write_outputs(paf, &out, f_main.c_str(), f_alt.c_str(), f_all.c_str());
+    if (rc != AASM_OK) std::cerr << "alignasm: writing outputs failed: " << aasm_last_error() << "\n";
+    aasm_free_out(&out);
+    aasm_paf_free(paf);
+    return rc == AASM_OK ? 0 : 3;
+}

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- contigs/sec (+ edges-relaxed/sec) of the per-contig path inference on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+through torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the whole hot path (K1..K9 + output compaction) over one batch of
+synthetic contigs that is ALREADY RESIDENT IN HBM (uploaded before the timed region).
+Workload (config.workload): BASELINE.json configs[2] "human whole-genome-scale PAF
+(~5M records, k=4 alt paths), 1 MI355X" concretised by SURVEY.md 8(d) as C3:
+5 000 contigs x 1 000 records, sparse graph mode, K = 4, seed 21.  configs[1] (50 k
+records, K=1) is far too small to occupy the chip and is a parity-test case instead.
+
+Multi-GPU: contigs are independent, so each rank owns its own contigs and no collective
+runs on the data path (only the barrier + MAX-reduce of the wall time).  Per-GPU work is
+fixed as N grows (every rank solves a C3-sized shard generated from seed 21 + 1000*rank),
+hence "scaling": "weak"; value = contigs of ALL ranks / max-over-ranks time.
+
+roofline: the dominant kernel of the timed region (largest average HIP-event time on the
+library's stream), its ALGORITHMIC bytes per launch (byte model: DESIGN.md "Byte model")
+and the HBM peak of /opt/skills/guides/MI355X_MICROARCH.md (8 TB/s).  `traffic` (PMC
+FETCH/WRITE bytes) is collected offline with rocprofv3 --pmc; see profiles/.
+cpu_baseline: the oracle (oracle/liboracle.so, a CPU restatement: kind "port") timed on
+this box's host cores over a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (contigs, recs, dense, K, seed, description)
+    "c2": (50, 1000, False, 1, 11, "C2 single-chromosome synthetic PAF: 50 contigs x 1000 records, sparse, K=1, seed 11"),
+    "c3": (5000, 1000, False, 4, 21, "C3 human WGS-scale synthetic PAF: 5000 contigs x 1000 records (5M records), sparse, K=4, seed 21"),
+    "c5": (10000, 1000, True, 16, 31, "C5 cancer-karyotype synthetic PAF: 10000 contigs x 1000 records, dense, K=16, seed 31"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_bytes(st):
+    """Algorithmic bytes per launch for the five heavy kernels (DESIGN.md 'Byte model')."""
+    V, E, H = st["n_vertices"], st["n_edges"], st["n_heap_nodes"]
+    return {
+        "sptree": ("aasm_k6_rev_sweep", 24 * E + 2 * 40 * V),
+        "fwd": ("aasm_k5_fwd_sweep", 24 * E + 2 * 8 * V),
+        "heap": ("aasm_k7_heap", 24 * E + 40 * V + 24 * H),
+        "enum": ("aasm_k8_enum", 64 * st["pq_pushes"] + 40 * st["n_paths_found"]),
+        "select": ("aasm_k9_select", 24 * st["ispr_edges"] + 40 * st["ispr_vertices"] + 8 * st["path_edges"] + 40 * st["out_elems"]),
+    }
+
+
+def total_bytes(st, n_records):
+    """B = 48 N + 24 R_touched + 4*24 E + 3*40 V + 24 H + 3*64 K_found."""
+    return (48 * n_records + 24 * st["range_steps"] + 96 * st["n_edges"] + 120 * st["n_vertices"]
+            + 24 * st["n_heap_nodes"] + 192 * st["n_paths_found"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--contigs", type=int, default=0, help="override contigs per GPU (exploration only)")
+    ap.add_argument("--recs", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="contigs of the workload timed on the CPU oracle")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import alignasm_amd as A
+
+    if A.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: alignasm_amd has no CPU fallback")
+    nc, nr, dense, K, seed, desc = WORKLOADS[args.workload]
+    custom = bool(args.contigs or args.recs or args.k)
+    nc = args.contigs or nc
+    nr = args.recs or nr
+    K = args.k or K
+    if custom:
+        desc = f"CUSTOM {nc} contigs x {nr} records, {'dense' if dense else 'sparse'}, K={K}, seed {seed} (not the BASELINE workload)"
+
+    # ---- synthetic batch of this rank, uploaded before the timed region
+    t0 = time.time()
+    paf = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
+    n_records = int(paf.view().n_records)
+    gen_s = time.time() - t0
+    t0 = time.time()
+    db = A.DeviceBatch(paf, device=local_rank)
+    upload_s = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        db.solve(max_paths=K, timing=True).close()
+    barrier()
+    phase_acc, stats = {}, None
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        res = db.solve(max_paths=K, timing=True)          # enqueues the pipeline and syncs its stream
+        stats = res.stats()
+        res.close()
+        for k, v in stats["phase_ms"].items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    elapsed = time.perf_counter() - t_begin
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        e = torch.tensor([float(stats["n_edges"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        total_edges = float(e.item())
+    else:
+        total_edges = float(stats["n_edges"])
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = elapsed * 1e3 / steps
+        contigs_total = nc * world
+        value = contigs_total * steps / elapsed
+        edges_relaxed = 2.0 * total_edges * steps / elapsed            # 2*E per contig
+        avg = {k: v / steps for k, v in phase_acc.items()}
+        kb = kernel_bytes(stats)
+        dom = max(kb, key=lambda k: avg.get(k, 0.0))
+        dom_name, dom_bytes = kb[dom]
+        dom_ms = avg.get(dom, 0.0)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        Btot = total_bytes(stats, n_records)
+        pipe_ms = stats["total_ms"]
+        out = {
+            "metric": "contigs_per_sec", "value": round(value, 2), "unit": "contigs/s",
+            "edges_relaxed_per_sec": round(edges_relaxed, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": desc, "contigs_per_gpu": nc, "records_per_contig": nr, "max_paths": K,
+                       "graph_mode": "dense" if dense else "sparse", "parallelism": f"contig-shard x{world}",
+                       "records_per_gpu": n_records},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(dom_ms, 3), "kernel_bytes": int(dom_bytes),
+                         "pipeline_bytes": int(Btot), "pipeline_ms": round(pipe_ms, 3),
+                         "pipeline_achieved": round(Btot / (pipe_ms * 1e-3) / 1e9, 2) if pipe_ms > 0 else 0.0},
+            "phase_ms": {k: round(v, 3) for k, v in avg.items() if v > 0},
+            "graph": {"V": stats["n_vertices"], "E": stats["n_edges"], "P": stats["n_pairs"], "H": stats["n_heap_nodes"],
+                      "paths_found": stats["n_paths_found"], "paths_converted": stats["n_paths_converted"],
+                      "device_MB": stats["device_bytes"] >> 20},
+            "setup": {"gen_s": round(gen_s, 2), "upload_s": round(upload_s, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(paf, nc, K, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    db.close()
+    paf.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(paf, nc, K, sample):
+    """Oracle (CPU restatement, kind 'port') on the first `sample` contigs, all host cores."""
+    import ctypes as C
+    import aasm_testlib as T
+    from alignasm_amd._abi import BatchOut, HostBatch, Opts
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    n = min(sample, nc)
+    hb = HostBatch.from_view_range(paf.view(), 0, n)
+    lib = T.oracle()
+    o = Opts(int(K), 0, 0, 0, 0)
+    out = BatchOut()
+    t0 = time.perf_counter()
+    rc = lib.oracle_solve_batch(C.byref(hb.view), C.byref(o), cores, C.byref(out))
+    dt = time.perf_counter() - t0
+    lib.oracle_free_out(C.byref(out))
+    assert rc == 0
+    return {"value": round(n / dt, 2), "unit": "contigs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {cores} threads, {dt:.2f} s wall"}
+
+
+if __name__ == "__main__":
+    main()

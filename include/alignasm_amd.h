@@ -104,6 +104,11 @@ typedef struct aasm_stats {
     int64_t n_single;          /* contigs with one record (paf_data.cpp:235-239)       */
     int64_t range_steps;       /* match-range entries visited by the merges            */
     int64_t device_bytes;      /* peak device workspace                                */
+    int64_t ispr_edges;        /* K9: edges relaxed by internal_shortest_path_recover  */
+    int64_t ispr_vertices;     /* K9: window vertices expanded                         */
+    int64_t path_edges;        /* K9: edges of recovered + upgraded paths              */
+    int64_t out_elems;         /* K9: PafOutputData elements produced by conversions   */
+    int64_t pq_pushes;         /* K8: priority-queue pushes                            */
     float   phase_ms[AASM_N_PHASES];  /* per-phase kernel time (HIP events), ms       */
     float   total_ms;                 /* whole device pipeline, ms                    */
     float   reserved_f[3];
@@ -111,16 +116,17 @@ typedef struct aasm_stats {
 
 /* phase ids for aasm_stats::phase_ms */
 enum {
-    AASM_PH_SORT = 0,     /* K1 sort + parts                       */
-    AASM_PH_PAIRS,        /* K2 overlap pairs + cut merge          */
-    AASM_PH_EDGES,        /* K3/K4 CSR build + scores              */
-    AASM_PH_REVCSR,       /* reversed CSR                          */
-    AASM_PH_SPTREE,       /* K6 Kahn(rev) + DAG shortest-path tree */
-    AASM_PH_FWD,          /* K6 forward Kahn order + K5 anomaly    */
-    AASM_PH_HEAP,         /* K7 sidetrack heaps                    */
-    AASM_PH_ENUM,         /* K8 k-walk enumeration                 */
-    AASM_PH_SELECT,       /* K9 recover/upgrade/convert/select     */
-    AASM_PH_GATHER,       /* output compaction                     */
+    AASM_PH_SORT = 0,     /* K1 sort + parts (3 kernels)                  */
+    AASM_PH_PAIRS,        /* K2 overlap slots + cut merge + vertex ids    */
+    AASM_PH_EDGES,        /* K3/K4 CSR build + scores                     */
+    AASM_PH_REVCSR,       /* reversed CSR                                 */
+    AASM_PH_SPTREE,       /* K6 aasm_k6_rev_sweep alone                   */
+    AASM_PH_FWD,          /* K5/K6 aasm_k5_fwd_sweep alone                */
+    AASM_PH_HEAP,         /* K7 aasm_k7_heap alone                        */
+    AASM_PH_ENUM,         /* K8 aasm_k8_enum alone                        */
+    AASM_PH_SELECT,       /* K9 aasm_k9_select alone                      */
+    AASM_PH_GATHER,       /* output compaction                            */
+    AASM_PH_HEAP_PREP,    /* SP-tree children CSR + arena sizing          */
     AASM_PH_MISC
 };
 
@@ -153,6 +159,11 @@ const char *aasm_last_error(void);
  * Host pointers in, host arrays out (malloc'ed into *out).                           */
 int  aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out);
 
+/* Contig-sharded solve across n_devices GPUs of one node (devices opts->device .. +n-1):
+ * static per-contig partition, one host thread + stream per device, outputs concatenated
+ * in contig order; no collective (contigs are independent, src/alignasm.cpp:351-359).    */
+int  aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n_devices, aasm_batch_out *out);
+
 /* Same, with the batch already resident in device memory (in->pointers are device
  * pointers; in->ctg_rec_off / rec_rng_off too).  `stream` is a hipStream_t (or NULL).
  * The device result stays resident in an opaque handle until fetched/freed.          */
@@ -163,6 +174,12 @@ int  aasm_result_stats(const aasm_result *res, aasm_stats *stats);
 int  aasm_result_fetch(aasm_result *res, aasm_batch_out *out);   /* D2H + ragged pack */
 void aasm_result_free(aasm_result *res);
 void aasm_free_out(aasm_batch_out *out);
+
+/* Upload a host batch once and solve it repeatedly (benchmark path: inputs resident in
+ * HBM before the timed region).  dev_view receives device pointers for aasm_solve_device. */
+typedef struct aasm_upload aasm_upload;
+int  aasm_upload_batch(const aasm_batch_in *host_in, int device, aasm_upload **up, aasm_batch_in *dev_view);
+void aasm_upload_free(aasm_upload *up);
 
 /* Debug/parity hook: copy a named device intermediate of a result solved with
  * opts.keep_debug=1 (names listed in DESIGN.md; e.g. "perm", "csr_col", "sp_d").

@@ -1,0 +1,246 @@
+"""Shared helpers for the test tiers.
+
+Loads the CHECKERS (never used by the product):
+  oracle/liboracle.so                     CPU restatement of the reference
+  oracle/_ref/libaasm_ref_algos*.so       the real reference's algorithm headers (optional;
+                                          built only where /root/reference exists, the
+                                          prebuilt files travel to the GPU box)
+  tests/host_emul/libaasm_emul.so         1-lane host build of the product's kernel bodies
+and the PRODUCT through alignasm_amd.api (libalignasm_amd.so, C-ABI).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from alignasm_amd._abi import BatchOut, HostBatch, Opts, unpack_out
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos.so")
+REF_MONO_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos_mono.so")
+EMUL_SO = os.path.join(ROOT, "tests", "host_emul", "libaasm_emul.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+_i64p = C.POINTER(C.c_int64)
+
+
+def _P(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def _ensure(path, make_dir):
+    if not os.path.exists(path):
+        subprocess.run(["make", "-s", "-C", make_dir], check=True)
+    return path
+
+
+_cache = {}
+
+
+def oracle():
+    if "o" not in _cache:
+        lib = C.CDLL(_ensure(ORACLE_SO, os.path.join(ROOT, "oracle")))
+        for fn in ("oracle_debug_size", "oracle_debug_copy", "oracle_generic_kwalks", "oracle_generic_path", "oracle_generic_fetch"):
+            getattr(lib, fn).restype = C.c_int64
+        _cache["o"] = lib
+    return _cache["o"]
+
+
+def emul():
+    if "e" not in _cache:
+        lib = C.CDLL(_ensure(EMUL_SO, os.path.join(ROOT, "tests", "host_emul")))
+        lib.emul_debug_fetch.restype = C.c_int64
+        _cache["e"] = lib
+    return _cache["e"]
+
+
+def ref(mono=True):
+    key = "rm" if mono else "r"
+    path = REF_MONO_SO if mono else REF_SO
+    if key not in _cache:
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        for fn in ("ref_generic_kwalks", "ref_generic_path", "ref_generic_fetch", "ref_generic_heap", "ref_generic_arena_inversions"):
+            getattr(lib, fn).restype = C.c_int64
+        _cache[key] = lib
+    return _cache[key]
+
+
+def api():
+    import alignasm_amd.api as a
+    return a
+
+
+def synth(n_contigs, recs, seed, dense=False, dup_every=0, shuffle=False, heavy_tail=False) -> HostBatch:
+    paf = api().Paf.synth(n_contigs, recs, seed, dense=dense, heavy_tail=heavy_tail, dup_every=dup_every, shuffle=shuffle, no_cs=True)
+    hb = paf.batch()
+    paf.close()
+    return hb
+
+
+def oracle_solve(hb: HostBatch, K=10000, nsl=False, threads=4):
+    o = Opts(int(K), 1 if nsl else 0, 0, 0, 0)
+    out = BatchOut()
+    rc = oracle().oracle_solve_batch(C.byref(hb.view), C.byref(o), int(threads), C.byref(out))
+    assert rc == 0, rc
+    try:
+        return unpack_out(out)
+    finally:
+        oracle().oracle_free_out(C.byref(out))
+
+
+def emul_solve(hb: HostBatch, K=10000, nsl=False):
+    o = Opts(int(K), 1 if nsl else 0, 0, 0, 1)
+    out = BatchOut()
+    rc = emul().emul_solve_batch(C.byref(hb.view), C.byref(o), C.byref(out))
+    assert rc == 0, rc
+    try:
+        return unpack_out(out)
+    finally:
+        emul().emul_free_out(C.byref(out))
+
+
+def emul_debug(name, dtype):
+    n = emul().emul_debug_fetch(name.encode(), None, C.c_int64(0))
+    assert n >= 0, name
+    buf = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+    emul().emul_debug_fetch(name.encode(), buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.nbytes))
+    return buf
+
+
+OUT_KEYS = ("main_off", "alt_off", "all_path_off", "all_elem_off", "main", "alt", "all", "status")
+STAT_KEYS = ("n_vertices", "n_pairs", "n_edges", "n_heap_nodes", "n_paths_found", "n_paths_converted",
+             "n_unconnectable", "n_internal_errors", "n_single")
+
+
+def diff_outputs(want, got, stats=True):
+    bad = [k for k in OUT_KEYS if not np.array_equal(want[k], got[k])]
+    if stats:
+        bad += [f"stats.{k}" for k in STAT_KEYS if want["stats"][k] != got["stats"][k]]
+    return bad
+
+
+def oracle_debug(hb: HostBatch, contig, K=10000, nsl=False):
+    """Intermediates of ONE contig from the oracle, as a dict of int64 arrays."""
+    o = Opts(int(K), 1 if nsl else 0, 0, 0, 0)
+    lib = oracle()
+    assert lib.oracle_debug_solve(C.byref(hb.view), C.byref(o), C.c_int64(contig)) == 0
+    names = ["perm", "part_idx", "vtx_i", "vtx_j", "pair_pe_q", "pair_pe_r", "pair_st_q", "pair_st_r", "csr_rowptr", "csr_col",
+             "csr_w_qry", "csr_w_ref", "csr_w_anom", "csr_w_qnz", "csr_w_qtot", "anom_dis_dest", "sp_d_qry", "sp_d_ref",
+             "sp_d_anom", "sp_d_qnz", "sp_d_qtot", "sp_best", "rev_order", "fwd_order", "kd_qry", "kd_ref", "kd_anom",
+             "kd_qnz", "kd_qtot", "heap_nodes", "heap_key_qry", "heap_left", "heap_right", "heap_u", "heap_v", "heap_rank", "heap_root"]
+    out = {}
+    for n in names:
+        sz = lib.oracle_debug_size(n.encode())
+        if sz < 0:
+            continue
+        a = np.zeros(sz, np.int64)
+        lib.oracle_debug_copy(n.encode(), _P(a), C.c_int64(sz))
+        out[n] = a
+    return out
+
+
+DIST_DT = np.dtype([("qry", np.int64), ("ref", np.int64), ("anom", np.int32), ("qnz", np.int32), ("qtot", np.int32), ("pad", np.int32)])
+HNODE_DT = np.dtype([("kq", np.int64), ("kr", np.int64), ("ka", np.int32), ("kn", np.int32), ("kt", np.int32), ("rank", np.int32),
+                     ("left", np.int32), ("right", np.int32), ("u", np.int32), ("v", np.int32)])
+
+
+def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None):
+    """Compare per-contig intermediates of a product/emulation run with the oracle.
+
+    `fetch(name, dtype)` returns the batch-level workspace array `name`.
+    Returns a list of (contig, what) mismatches.
+    """
+    rec_off = hb.arrays["ctg_rec_off"]
+    C_ = len(rec_off) - 1
+    ctgV = fetch("ctgV", np.int32)[:C_]
+    voff = fetch("voff", np.int64)[:C_ + 1]      # debug arrays carry allocation padding
+    perm = fetch("perm", np.int32)
+    s_pid = fetch("s_pid", np.int32)
+    bad = []
+    has_graph = int(voff[-1]) > 0
+    if has_graph:
+        v_i, v_j, v_slot = fetch("v_i", np.int32), fetch("v_j", np.int32), fetch("v_slot", np.int64)
+        rowptr, col = fetch("csr_rowptr", np.int64), fetch("csr_col", np.int32)
+        wq, wr, fl = fetch("csr_w_qry", np.int64), fetch("csr_w_ref", np.int32), fetch("csr_w_flags", np.uint8)
+        ov = {k: fetch(k, np.int64) for k in ("ov_peq", "ov_per", "ov_stq", "ov_str")}
+        sp_d, sp_best = fetch("sp_d", DIST_DT), fetch("sp_best", np.int32)
+        rev_order, fwd_order = fetch("rev_order", np.int32), fetch("fwd_order", np.int32)
+        anom_dest, kfound, h_cnt = fetch("anom_dest", np.int32), fetch("kfound", np.int32), fetch("h_cnt", np.int32)
+        kd = fetch("kd", DIST_DT)
+        hoff, hnodes, h_root = fetch("hoff", np.int64), fetch("hnodes", HNODE_DT), fetch("h_root", np.int32)
+    for c in (contigs if contigs is not None else range(C_)):
+        b, N = int(rec_off[c]), int(rec_off[c + 1] - rec_off[c])
+        if N <= 1:
+            continue
+        o = oracle_debug(hb, c, K, nsl)
+
+        def chk(what, a, bexp):
+            if not np.array_equal(np.asarray(a, np.int64), np.asarray(bexp, np.int64)):
+                bad.append((c, what))
+        chk("perm", perm[b:b + N], o["perm"])
+        chk("part_idx", s_pid[b:b + N], o["part_idx"])
+        V = int(ctgV[c])
+        if V != len(o["csr_rowptr"]) - 1:
+            bad.append((c, "V"))
+            continue
+        vb = int(voff[c])
+        chk("vtx_i", v_i[vb:vb + V - 2], o["vtx_i"])
+        chk("vtx_j", v_j[vb:vb + V - 2], o["vtx_j"])
+        sl = v_slot[vb + N:vb + V - 2]
+        chk("pair_pe_q", ov["ov_peq"][sl], o["pair_pe_q"]); chk("pair_pe_r", ov["ov_per"][sl], o["pair_pe_r"])
+        chk("pair_st_q", ov["ov_stq"][sl], o["pair_st_q"]); chk("pair_st_r", ov["ov_str"][sl], o["pair_st_r"])
+        e0, e1 = int(rowptr[vb]), int(rowptr[vb + V])
+        chk("rowptr", rowptr[vb:vb + V + 1] - e0, o["csr_rowptr"])
+        chk("col", col[e0:e1], o["csr_col"])
+        chk("w_qry", wq[e0:e1], o["csr_w_qry"]); chk("w_ref", wr[e0:e1], o["csr_w_ref"])
+        chk("w_anom", fl[e0:e1] & 3, o["csr_w_anom"]); chk("w_qnz", (fl[e0:e1] >> 2) & 1, o["csr_w_qnz"]); chk("w_qtot", (fl[e0:e1] >> 3) & 1, o["csr_w_qtot"])
+        chk("anom_dest", [anom_dest[c]], o["anom_dis_dest"])
+        d = sp_d[vb:vb + V]
+        for f, k in (("qry", "sp_d_qry"), ("ref", "sp_d_ref"), ("anom", "sp_d_anom"), ("qnz", "sp_d_qnz"), ("qtot", "sp_d_qtot")):
+            chk(k, d[f], o[k])
+        chk("sp_best", sp_best[vb:vb + V], o["sp_best"])
+        chk("rev_order", rev_order[vb:vb + V], o["rev_order"])
+        chk("fwd_order", fwd_order[vb:vb + V], o["fwd_order"])
+        nf = int(kfound[c])
+        chk("kfound", [nf], [len(o["kd_qry"])])
+        kk = kd[c * K:c * K + nf]
+        for f, k in (("qry", "kd_qry"), ("ref", "kd_ref"), ("anom", "kd_anom"), ("qnz", "kd_qnz"), ("qtot", "kd_qtot")):
+            chk(k, kk[f], o[k])
+        chk("heap_count", [h_cnt[c]], o["heap_nodes"])
+        hn = hnodes[int(hoff[c]):int(hoff[c]) + int(h_cnt[c])]
+        chk("heap_key_qry", hn["kq"], o["heap_key_qry"]); chk("heap_left", hn["left"], o["heap_left"]); chk("heap_right", hn["right"], o["heap_right"])
+        chk("heap_u", hn["u"], o["heap_u"]); chk("heap_v", hn["v"], o["heap_v"]); chk("heap_rank", hn["rank"], o["heap_rank"])
+        chk("heap_root", h_root[vb:vb + V], o["heap_root"])
+    return bad
+
+
+# ---- generic-graph harness (oracle vs real reference headers) -----------------------
+def generic_run(lib, prefix, n, rowptr, col, w, src, sink, K, with_paths=True):
+    d = np.zeros(max(K, 1) * 5, np.int64)
+    nd = getattr(lib, prefix + "generic_kwalks")(C.c_int64(n), _P(rowptr), _P(col), _P(w), C.c_int64(src), C.c_int64(sink),
+                                                 C.c_int64(K), _P(d), C.c_int64(K))
+    out = {"nd": int(nd), "dist": d[:nd * 5].copy()}
+    for what, name, sz in ((0, "anom", n), (1, "rev", n), (2, "fwd", n), (3, "best", n), (4, "d", 5 * n), (5, "hroot", n), (6, "hcount", 1)):
+        a = np.zeros(sz, np.int64)
+        getattr(lib, prefix + "generic_fetch")(what, _P(a), C.c_int64(sz))
+        out[name] = a
+    if with_paths:
+        buf = np.zeros(2 * (n + 8), np.int64)
+        paths = []
+        for k in range(nd):
+            m = getattr(lib, prefix + "generic_path")(C.c_int64(src), C.c_int64(sink), C.c_int64(k), _P(buf), C.c_int64(n + 8))
+            paths.append(buf[:2 * m].copy())
+        out["paths"] = paths
+    return out
+
+
+def contig_graph(hb, contig, K=10000, nsl=False):
+    o = oracle_debug(hb, contig, K, nsl)
+    rp, col = o["csr_rowptr"], o["csr_col"]
+    w = np.stack([o["csr_w_qry"], o["csr_w_ref"], o["csr_w_anom"], o["csr_w_qnz"], o["csr_w_qtot"]], 1).reshape(-1).copy()
+    n = len(rp) - 1
+    return n, rp, col, w

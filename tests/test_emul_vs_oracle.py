@@ -1,0 +1,34 @@
+"""CPU tier: the product's kernel bodies (1-lane host emulation, tests/host_emul) against
+the oracle -- final outputs bit-exact and every intermediate (sorted order, parts, pair
+cuts, CSR rows + weights, shortest-path tree, Kahn orders, heaps, k distances)."""
+import numpy as np
+import pytest
+
+CASES = [
+    # (contigs, recs, seed, K, dense, dup_every, shuffle, heavy_tail, nsl)
+    (10, 100, 1, 10000, False, 0, False, False, False),      # BASELINE config C1 shape
+    (3, 700, 11, 4, False, 0, False, False, False),
+    (3, 300, 31, 16, True, 0, False, False, False),
+    (2, 300, 31, 10000, True, 0, False, False, False),
+    (4, 300, 5, 10000, False, 3, False, False, False),       # co-optimal ties (.all paths)
+    (6, 200, 7, 10000, False, 0, False, False, True),        # NON_SKIP_LINKABLE
+    (3, 250, 8, 10000, True, 0, False, False, True),
+    (6, 150, 9, 10000, False, 3, True, False, False),        # shuffled input + duplicate keys (std::sort replay)
+    (40, 50, 10, 1, False, 0, False, True, False),           # ragged sizes incl. tiny contigs
+    (30, 40, 10, 10000, True, 0, True, True, False),
+    (5, 1, 3, 10000, False, 0, False, False, False),         # single-record contigs
+    (5, 2, 3, 10000, False, 0, False, False, False),
+    (8, 40, 13, 10000, True, 1, True, False, False),         # every record duplicated
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%dx%d_s%d_k%d_%s%s%s%s%s" % (
+    c[0], c[1], c[2], c[3], "D" if c[4] else "S", f"_dup{c[5]}" if c[5] else "", "_shuf" if c[6] else "", "_ht" if c[7] else "", "_nsl" if c[8] else ""))
+def test_outputs_and_intermediates(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = T.emul_solve(hb, K, nsl)
+    assert T.diff_outputs(want, got) == []
+    assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+    assert want["stats"]["n_internal_errors"] == 0

@@ -1,0 +1,60 @@
+"""GPU tier: the HIP path through the C-ABI against the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (10, 100, 1, 10000, False, 0, False, False, False),      # BASELINE config C1: 10 x 100, K as shipped
+    (6, 1000, 11, 1, False, 0, False, False, False),         # C2 shape (single chromosome, K=1), reduced contig count
+    (6, 1000, 21, 4, False, 0, False, False, False),         # C3 shape
+    (4, 600, 31, 16, True, 0, False, False, False),          # C5 shape (dense, K=16)
+    (2, 300, 31, 10000, True, 0, False, False, False),
+    (4, 300, 5, 10000, False, 3, False, False, False),
+    (6, 200, 7, 10000, False, 0, False, False, True),
+    (3, 250, 8, 10000, True, 0, False, False, True),
+    (6, 150, 9, 10000, False, 3, True, False, False),
+    (200, 50, 10, 4, False, 0, False, True, False),
+    (30, 40, 10, 10000, True, 0, True, True, False),
+    (5, 1, 3, 10000, False, 0, False, False, False),
+    (5, 2, 3, 10000, False, 0, False, False, False),
+    (8, 40, 13, 10000, True, 1, True, False, False),
+]
+
+
+def _id(c):
+    return "c%dx%d_s%d_k%d_%s%s%s%s%s" % (c[0], c[1], c[2], c[3], "D" if c[4] else "S", f"_dup{c[5]}" if c[5] else "",
+                                          "_shuf" if c[6] else "", "_ht" if c[7] else "", "_nsl" if c[8] else "")
+
+
+@pytest.mark.parametrize("case", CASES, ids=_id)
+def test_hip_outputs_match_oracle(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl)
+    assert T.diff_outputs(want, got) == []
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5], CASES[8], CASES[13]], ids=_id)
+def test_hip_intermediates_match_oracle(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    db = api.DeviceBatch(hb)
+    res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True)
+    assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+    res.close(); db.close()
+
+
+def test_repeat_solve_is_deterministic(T):
+    api = T.api()
+    hb = T.synth(50, 200, 77, dup_every=5, shuffle=True)
+    db = api.DeviceBatch(hb)
+    outs = []
+    for _ in range(3):
+        r = db.solve(max_paths=64)
+        outs.append(r.fetch()); r.close()
+    db.close()
+    assert T.diff_outputs(outs[0], outs[1]) == [] and T.diff_outputs(outs[0], outs[2]) == []

@@ -1,0 +1,20 @@
+"""Scratch profiling helper: per-phase HIP-event times of one resident batch."""
+import argparse, json, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import alignasm_amd as A
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--contigs", type=int, default=500); ap.add_argument("--recs", type=int, default=1000)
+ap.add_argument("--k", type=int, default=4); ap.add_argument("--dense", type=int, default=0)
+ap.add_argument("--seed", type=int, default=21); ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--heavy", type=int, default=0)
+a = ap.parse_args()
+t = time.time(); paf = A.Paf.synth(a.contigs, a.recs, a.seed, dense=bool(a.dense), heavy_tail=bool(a.heavy), no_cs=True); hb = paf.batch(); paf.close()
+print("gen %.2fs records=%d ranges=%d" % (time.time() - t, hb.view.n_records, hb.view.n_ranges), flush=True)
+t = time.time(); db = A.DeviceBatch(hb); print("upload %.2fs" % (time.time() - t), flush=True)
+for r in range(a.reps):
+    t = time.time(); res = db.solve(max_paths=a.k, timing=True); wall = time.time() - t
+    st = res.stats(); res.close()
+    ph = {k: round(v, 3) for k, v in st["phase_ms"].items() if v > 0}
+    print(json.dumps({"rep": r, "wall_ms": round(wall * 1e3, 2), "total_ms": round(st["total_ms"], 3), "phases": ph,
+                      "V": st["n_vertices"], "E": st["n_edges"], "dev_MB": st["device_bytes"] >> 20}), flush=True)
