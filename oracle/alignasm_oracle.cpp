@@ -1037,6 +1037,17 @@ int64_t oracle_debug_copy(const char *name, int64_t *dst, int64_t cap) {
     return n;
 }
 
+// The permutation std::sort (libstdc++, unstable) produces for records keyed by
+// (qry_str, qry_end) -- exactly paf_data.cpp:241 -- and, with heap_only, what
+// std::partial_sort(first, last, last) produces (introsort's depth-limit fallback).
+void oracle_std_sort_perm(const int64_t *qs, const int64_t *qe, int64_t n, int32_t *perm, int heap_only) {
+    std::vector<Rec> v((size_t)n);
+    for (int64_t i = 0; i < n; i++) { v[i] = Rec{}; v[i].qry_str = qs[i]; v[i].qry_end = qe[i]; v[i].ctg_index = (int32_t)i; }
+    if (heap_only) std::partial_sort(v.begin(), v.end(), v.end());
+    else std::sort(v.begin(), v.end());
+    for (int64_t i = 0; i < n; i++) perm[i] = v[i].ctg_index;
+}
+
 // PafDistance predicates exposed for truth-table tests against the real header.
 int oracle_dist_lt(const int64_t *a, const int64_t *b, int mode) {
     return d_lt(Dist{a[0], a[1], a[2], a[3], a[4]}, Dist{b[0], b[1], b[2], b[3], b[4]}, (Mode)mode) ? 1 : 0;

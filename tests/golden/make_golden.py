@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz and tests/golden/files/* (run from the repo root, in the
+build container where /root/reference exists).
+
+  ref_algos.npz   inputs: small DAGs (CSR + 5-int64 weights); expected: outputs of the REAL
+                  reference headers (oracle/_ref/libaasm_ref_algos_mono.so: k_shortest_walks.hpp,
+                  k_weighted_bfs.hpp, leftist_heap.hpp, PafDistance) -- distances, every
+                  recovered path, Kahn orders, shortest-path tree, anomaly distances, heap
+                  roots/counts.  Pins the oracle on boxes without /root/reference.
+  solve.npz       seeded synthetic batches (generator parameters only) and the oracle's
+                  main/alt/all outputs: regression anchor for the oracle itself and the
+                  expected values of the emulation and the HIP path.
+  files/          a tiny synthetic PAF and the three output files (oracle + host writer).
+Fixtures are DATA (inputs and expected outputs); no reference source text is stored.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import aasm_testlib as T  # noqa: E402
+from alignasm_amd._abi import BatchOut, Opts  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SOLVE_CASES = [  # contigs, recs, seed, K, dense, dup_every, shuffle, heavy_tail, nsl
+    (10, 100, 1, 10000, 0, 0, 0, 0, 0),     # BASELINE C1
+    (3, 300, 31, 16, 1, 0, 0, 0, 0),
+    (4, 200, 5, 10000, 0, 3, 1, 0, 0),
+    (5, 150, 7, 10000, 0, 0, 0, 0, 1),
+    (25, 40, 10, 4, 0, 0, 0, 1, 0),
+    (6, 60, 13, 10000, 1, 1, 1, 0, 1),
+]
+
+
+def ref_algos():
+    R = T.ref(True)
+    assert R is not None, "build oracle/_ref first (make -C oracle)"
+    graphs = []
+    for (nc, nr, seed, dense, dup) in ((2, 60, 1, False, 0), (1, 120, 31, True, 0), (2, 50, 5, False, 2)):
+        hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup)
+        for c in range(nc):
+            n, rp, col, w = T.contig_graph(hb, c)
+            graphs.append((n, rp, col, w, n - 2, n - 1))
+    rng = np.random.default_rng(7)
+    for _ in range(6):
+        n = int(rng.integers(5, 30))
+        rows = [[] for _ in range(n)]
+        for u in range(n - 1):
+            for v in range(u + 1, n):
+                if rng.random() < 0.3:
+                    rows[u].append((v, [int(rng.integers(0, 5)), int(rng.integers(0, 5)), int(rng.integers(0, 3)), int(rng.integers(0, 2)), 1]))
+            if not rows[u]:
+                rows[u].append((int(rng.integers(u + 1, n)), [1, 0, 0, 0, 1]))
+            rng.shuffle(rows[u])
+        rp = np.zeros(n + 1, np.int64); col = []; w = []
+        for u in range(n):
+            for v, ww in rows[u]:
+                col.append(v); w.extend(ww)
+            rp[u + 1] = len(col)
+        graphs.append((n, rp, np.array(col, np.int64), np.array(w, np.int64), 0, n - 1))
+    out = {"n_graphs": np.array([len(graphs)])}
+    K = 300
+    for g, (n, rp, col, w, s, t) in enumerate(graphs):
+        r = T.generic_run(R, "ref_", n, rp, col, w, s, t, K)
+        out[f"g{g}_rowptr"], out[f"g{g}_col"], out[f"g{g}_w"] = rp, col, w
+        out[f"g{g}_meta"] = np.array([n, s, t, K], np.int64)
+        for key in ("dist", "anom", "rev", "fwd", "best", "d", "hroot", "hcount"):
+            out[f"g{g}_{key}"] = r[key]
+        out[f"g{g}_path_len"] = np.array([len(p) for p in r["paths"]], np.int64)
+        out[f"g{g}_paths"] = np.concatenate(r["paths"]) if r["paths"] else np.zeros(0, np.int64)
+    np.savez_compressed(os.path.join(HERE, "ref_algos.npz"), **out)
+    print("ref_algos.npz:", len(graphs), "graphs")
+
+
+def solve():
+    out = {"cases": np.array(SOLVE_CASES, np.int64)}
+    for i, (nc, nr, seed, K, dense, dup, shuf, heavy, nsl) in enumerate(SOLVE_CASES):
+        hb = T.synth(nc, nr, seed, dense=bool(dense), dup_every=dup, shuffle=bool(shuf), heavy_tail=bool(heavy))
+        r = T.oracle_solve(hb, K, bool(nsl))
+        assert r["stats"]["n_internal_errors"] == 0
+        for k in T.OUT_KEYS:
+            out[f"c{i}_{k}"] = r[k]
+        out[f"c{i}_input_checksum"] = np.array([int(hb.arrays["qry_str"].sum()), int(hb.arrays["rng_ref_l"].sum()), int(hb.view.n_ranges)], np.int64)
+    np.savez_compressed(os.path.join(HERE, "solve.npz"), **out)
+    print("solve.npz:", len(SOLVE_CASES), "cases")
+
+
+def files():
+    api = T.api()
+    d = os.path.join(HERE, "files")
+    os.makedirs(d, exist_ok=True)
+    paf = api.Paf.synth(3, 14, 101, dup_every=2)
+    open(os.path.join(d, "tiny.paf"), "wb").write(paf.to_text())
+    view = paf.view()
+    out = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(view), C.byref(Opts(10000, 0, 0, 0, 0)), 1, C.byref(out)) == 0
+    paf.write_outputs(out, os.path.join(d, "tiny.aln.paf"), os.path.join(d, "tiny.aln.alt.paf"), os.path.join(d, "tiny.aln.all.paf"))
+    T.oracle().oracle_free_out(C.byref(out))
+    print("files/:", os.listdir(d))
+
+
+if __name__ == "__main__":
+    ref_algos(); solve(); files()
