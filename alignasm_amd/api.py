@@ -17,7 +17,7 @@ import numpy as np
 from ._abi import (AASM_OK, BatchIn, BatchOut, HostBatch, Opts, Stats, SynthCfg, unpack_out)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalignasm_amd.so")
+LIB_PATH = os.environ.get("AASM_LIB_OVERRIDE") or os.path.join(_HERE, "libalignasm_amd.so")   # override: diagnostic builds (tools/)
 
 
 class AlignasmError(RuntimeError):

@@ -29,7 +29,9 @@ struct KCtx {
     int64_t bid;      // block id
     int64_t nblocks;
     int lane;         // tid % AASM_WAVE
+    char *lds;        // per-block LDS scratch (AASM_LDS_BYTES), 16-byte aligned
 };
+#define AASM_LDS_BYTES 6144   // 6 KB per single-wave block -> 26 blocks per CU by LDS
 
 // ------------------------------------------------------------------------------------
 // wave primitives (wave64 on gfx950; trivial with one lane)
@@ -69,6 +71,33 @@ AASM_DEV unsigned long long atomic_add(int64_t *p, int64_t v) {
 AASM_DEV int popc64(uint64_t m) { return __popcll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __ffsll((long long)m); }
 #endif
+
+// Diagnostic build only (-DAASM_KPROF, tools/): cycle stamps per kernel section.  The
+// product build compiles these to nothing.
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+#define KPROF_DECL int64_t kp_t0 = 0, kp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define KPROF_START() do { __builtin_amdgcn_s_waitcnt(0); kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); } while (0)
+#define KPROF_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const int64_t kp_t1 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); kp_acc[i] += kp_t1 - kp_t0; kp_t0 = kp_t1; } while (0)
+#define KPROF_FLUSH(ptr, c, lane) do { if ((ptr) && (lane) == 0) for (int kp_i = 0; kp_i < 8; kp_i++) (ptr)[(c) * 8 + kp_i] = kp_acc[kp_i]; } while (0)
+#else
+#define KPROF_DECL
+#define KPROF_START() do {} while (0)
+#define KPROF_STAMP(i) do {} while (0)
+#define KPROF_FLUSH(ptr, c, lane) do {} while (0)
+#endif
+
+// Wave-uniform values made explicitly scalar: v_readfirstlane moves them to SGPRs, so the
+// arithmetic and the branches that follow run on the scalar unit instead of occupying all
+// 64 VALU lanes with identical work.  Only valid where every lane holds the same value.
+#if defined(AASM_HOST_EMUL)
+AASM_DEV int32_t uni(int32_t x) { return x; }
+#else
+AASM_DEV int32_t uni(int32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+AASM_DEV int64_t uni(int64_t x) {
+    return (int64_t)(((uint64_t)(uint32_t)uni((int32_t)((uint64_t)x >> 32)) << 32) | (uint32_t)uni((int32_t)(uint32_t)(uint64_t)x));
+}
+AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
 
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 
@@ -124,8 +153,8 @@ template <int MODE> AASM_DEV bool dist_lt(const Dist &a, const Dist &b) {   // p
         if (a.ref != b.ref) return a.ref < b.ref;
     }
     if (a.anom != b.anom) return a.anom < b.anom;
-    int64_t tot = a.qtot ? a.qtot : 1, rtot = b.qtot ? b.qtot : 1;
-    return (int64_t)a.qnz * rtot > (int64_t)b.qnz * tot;
+    const int32_t tot = a.qtot ? a.qtot : 1, rtot = b.qtot ? b.qtot : 1;
+    return (int64_t)a.qnz * (int64_t)rtot > (int64_t)b.qnz * (int64_t)tot;      // 32 x 32 -> 64
 }
 AASM_DEV Dist dist_add(const Dist &a, const Dist &b) {               // paf_data.hpp:178-183
     Dist r; r.qry = a.qry + b.qry; r.ref = a.ref + b.ref; r.anom = a.anom + b.anom;
@@ -152,9 +181,33 @@ AASM_DEV Dist edge_dist(int64_t wq, int32_t wr, uint8_t fl) {
 // persistent leftist-heap node (reference: src/leftist_heap.hpp:18-27), 48 bytes
 struct __attribute__((aligned(16))) HNode {
     int64_t kq, kr;                 // key.qry_score, key.ref_score
-    int32_t ka, kn, kt, rank;       // key.anom, key.qul_nonzero, key.qul_total, node_rank
+    int32_t ka, kn, kt, rank;       // key.anom, key.qul_nonzero, key.qul_total;
+                                    // rank = node_rank | rank(left) << 8 | rank(right) << 16 (child ranks cached)
     int32_t left, right, u, v;      // arena indices (-1 = nullptr), value = edge (u, v)
 };
+// a node as three 16-byte quads kept in registers: q0 = {kq, kr}, q1 = {ka, kn, kt, rank},
+// q2 = {left, right, u, v}
+struct __attribute__((aligned(16))) I4 { int32_t x, y, z, w; };
+struct NodeQ { I4 q0, q1, q2; };
+AASM_DEV NodeQ nodeq_load(const HNode *p) { const I4 *q = (const I4 *)p; NodeQ n; n.q0 = q[0]; n.q1 = q[1]; n.q2 = q[2]; return n; }
+AASM_DEV void nodeq_store(HNode *p, const NodeQ &n) { I4 *q = (I4 *)p; q[0] = n.q0; q[1] = n.q1; q[2] = n.q2; }
+AASM_DEV Dist nodeq_key(const NodeQ &n) {
+    Dist d;
+    d.qry = (int64_t)(((uint64_t)(uint32_t)n.q0.y << 32) | (uint32_t)n.q0.x);
+    d.ref = (int64_t)(((uint64_t)(uint32_t)n.q0.w << 32) | (uint32_t)n.q0.z);
+    d.anom = n.q1.x; d.qnz = n.q1.y; d.qtot = n.q1.z; d.pad = 0;
+    return d;
+}
+AASM_DEV NodeQ uni(const NodeQ &n) {
+    NodeQ r;
+    r.q0.x = uni(n.q0.x); r.q0.y = uni(n.q0.y); r.q0.z = uni(n.q0.z); r.q0.w = uni(n.q0.w);
+    r.q1.x = uni(n.q1.x); r.q1.y = uni(n.q1.y); r.q1.z = uni(n.q1.z); r.q1.w = uni(n.q1.w);
+    r.q2.x = uni(n.q2.x); r.q2.y = uni(n.q2.y); r.q2.z = uni(n.q2.z); r.q2.w = uni(n.q2.w);
+    return r;
+}
+AASM_DEV Dist uni(const Dist &d) {
+    Dist r; r.qry = uni(d.qry); r.ref = uni(d.ref); r.anom = uni(d.anom); r.qnz = uni(d.qnz); r.qtot = uni(d.qtot); r.pad = 0; return r;
+}
 AASM_DEV Dist hnode_key(const HNode &n) {
     Dist d; d.qry = n.kq; d.ref = n.kr; d.anom = n.ka; d.qnz = n.kn; d.qtot = n.kt; d.pad = 0; return d;
 }

@@ -26,7 +26,16 @@ namespace aasm {
 #define AASM_DEF_KERNEL(name, KN, TPB)                                                        \
     __global__ void __launch_bounds__(TPB) name(WS w) {                                       \
         KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
-               (int)(threadIdx.x & 63)};                                                      \
+               (int)(threadIdx.x & 63), nullptr};                                             \
+        run_kernel_body(KN, k, w);                                                            \
+    }
+// kernels whose wave keeps a working set in LDS (AASM_LDS_BYTES per 64-thread block);
+// launch bound 5 waves/SIMD (<= 96 VGPRs) so that 20 contigs are resident per CU
+#define AASM_DEF_KERNEL_LDS(name, KN, TPB)                                                    \
+    __global__ void __launch_bounds__(TPB, 5) name(WS w) {                                    \
+        __shared__ __attribute__((aligned(16))) char smem[AASM_LDS_BYTES];                    \
+        KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
+               (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }
 AASM_DEF_KERNEL(aasm_k1_sort, KN_SORT, 256)
@@ -48,9 +57,9 @@ AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
-AASM_DEF_KERNEL(aasm_k7_heap, KN_HEAP, 64)
+AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64)
 AASM_DEF_KERNEL(aasm_k8_enum, KN_ENUM, 64)
-AASM_DEF_KERNEL(aasm_k9_select, KN_SELECT, 64)
+AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64)
 AASM_DEF_KERNEL(aasm_k9_gather_out, KN_GATHER_OUT, 64)
 
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------

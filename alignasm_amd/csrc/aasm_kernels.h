@@ -75,6 +75,7 @@ struct WS {
     // ---- status / counters
     int32_t *status;
     int64_t *counters;
+    int64_t *prof_heap, *prof_sel;    // [C * 8] cycle sums per section (diagnostic build only)
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
@@ -860,40 +861,122 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.hcap_cnt[c] = (int32_t)cap;
 }
 
-AASM_DEV int32_t heap_insert(HNode *nodes, int32_t &alloc, int32_t cap, int32_t a, const Dist &key, int32_t eu, int32_t ev, bool &ovf) {
-    int32_t stack[64];
+// Cooperative K7.  The wave keeps its working set in LDS:
+//   ring[HEAP_RING]   the most recently allocated nodes (an insert walks the right spine from
+//                     the root, whose top nodes were copied by the previous inserts)
+//   stk[HEAP_STACK]   the nodes passed on the way down (so unwinding needs no reload; the
+//                     child ranks are cached inside each node)
+//   cbuf / vbuf       sidetrack costs + heads of one 64-edge chunk of the adjacency row,
+//                     computed by all lanes at once
+// Control flow is wave-uniform; every lane executes the same scalar walk (uniform loads).
+#define HEAP_RING 32
+#define HEAP_STACK 40
+#define HEAP_QN 128
+#define HEAP_FLUSH 16
+struct HeapLds {
+    HNode ring[HEAP_RING];          // newest nodes; [flushed, alloc) exist ONLY here
+    int32_t stk[HEAP_STACK];
+    Dist cbuf[AASM_WAVE];
+    int32_t vbuf[AASM_WAVE];
+    int32_t bqv[HEAP_QN], bqh[HEAP_QN];   // BFS queue window: vertex + inherited heap root
+};
+static_assert(sizeof(HeapLds) <= AASM_LDS_BYTES, "LDS budget");
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+#define HI_PROF_ARGS , int64_t &kp_t0, int64_t *kp_acc
+#define HI_PROF_PASS , kp_t0, kp_acc
+#else
+#define HI_PROF_ARGS
+#define HI_PROF_PASS
+#endif
+// One persistent insert (leftist_heap.hpp:29-40), instruction-lean: with 20 single-wave
+// contigs per CU this kernel is bound by instruction issue, not by memory.
+//  * nodes move as 16-byte quads; the ring read (ds_read) and the global read sit in
+//    separate uniform branches so neither degenerates into a flat access, and ring hits never
+//    wait on outstanding global stores (LDS counts on lgkmcnt, stores on vmcnt);
+//  * the descent compares score sums first (PafDistance::max() has sum -2) and only falls
+//    back to the full operator< on a sum tie; it pushes node INDICES on an LDS stack;
+//  * the unwinding re-reads each ancestor (ring hit) and rewrites three words with selects;
+//  * uniform data is stored by lane 0 only.
+// Write-back of the ring: vmcnt is in-order over loads AND stores, so a global store issued
+// just before a dependent global load makes that load wait for the store's acknowledgement.
+// New nodes therefore live in LDS only and are written back HEAP_FLUSH at a time by one
+// coalesced 768-byte store of 48 lanes.
+AASM_DEV void heap_flush(HNode *nodes, HeapLds *L, int32_t &flushed, int32_t upto, int lane) {
+    while (flushed < upto) {
+        const int32_t n = (upto - flushed < HEAP_FLUSH) ? (upto - flushed) : HEAP_FLUSH;
+        for (int32_t t = lane; t < 3 * n; t += AASM_WAVE) {
+            const int32_t node = flushed + t / 3, part = t % 3;
+            ((I4 *)&nodes[node])[part] = ((const I4 *)&L->ring[node & (HEAP_RING - 1)])[part];
+        }
+        flushed += n;
+    }
+}
+AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, int32_t &alloc, int32_t &flushed, int32_t cap, int32_t a, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
     int depth = 0;
-    while (a >= 0 && dist_lt<CALC_SUM_MODE>(hnode_key(nodes[a]), key)) {   // leftist_heap.hpp:30
-        if (depth < 64) stack[depth++] = a; else { ovf = true; return -1; }
-        a = nodes[a].right;
+    int32_t a_rank = 0;
+    const int64_t ksum = key.qry + key.ref;
+    while (a >= 0) {                                                        // leftist_heap.hpp:30
+        I4 q0, q1;
+        int32_t right;
+        if (a >= alloc - HEAP_RING) { const HNode *p = &L->ring[a & (HEAP_RING - 1)]; q0 = ((const I4 *)p)[0]; q1 = ((const I4 *)p)[1]; right = p->right; }
+        else { const HNode *p = &nodes[a]; q0 = ((const I4 *)p)[0]; q1 = ((const I4 *)p)[1]; right = p->right; asm volatile("" ::: "memory"); }
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+        if (a >= alloc - HEAP_RING) kp_acc[6]++; else kp_acc[7]++;
+#endif
+        NodeQ n; n.q0 = q0; n.q1 = q1;
+        const Dist nk = nodeq_key(n);
+        const int64_t nsum = nk.qry + nk.ref;
+        bool lt;
+        if (nsum != ksum && nsum != -2 && ksum != -2) lt = nsum < ksum;      // paf_data.hpp:142-149, neither side is max()
+        else lt = dist_lt<CALC_SUM_MODE>(nk, key);
+        if (!uni(lt)) { a_rank = q1.w & 0xff; break; }
+        if (depth >= HEAP_STACK) { ovf = true; return -1; }
+        if (lane == 0) L->stk[depth] = a;
+        depth++;
+        a = uni(right);
     }
+    KPROF_STAMP(4);                                                         // descent
     if (alloc + depth + 1 > cap) { ovf = true; return -1; }
-    int32_t r = alloc++;
-    {
-        HNode n; n.kq = key.qry; n.kr = key.ref; n.ka = key.anom; n.kn = key.qnz; n.kt = key.qtot; n.rank = 1;
-        n.left = a; n.right = -1; n.u = eu; n.v = ev;
-        nodes[r] = n;                                                       // :31-32
+    if (alloc - flushed >= HEAP_RING) { block_sync(); heap_flush(nodes, L, flushed, flushed + HEAP_FLUSH, lane); }
+    int32_t r = alloc;
+    if (lane == 0) {                                                        // :31-32: (1, k, v, left = a, right = null)
+        NodeQ n;
+        n.q0.x = (int32_t)(uint32_t)(uint64_t)key.qry; n.q0.y = (int32_t)((uint64_t)key.qry >> 32);
+        n.q0.z = (int32_t)(uint32_t)(uint64_t)key.ref; n.q0.w = (int32_t)((uint64_t)key.ref >> 32);
+        n.q1.x = key.anom; n.q1.y = key.qnz; n.q1.z = key.qtot; n.q1.w = 1 | (a_rank << 8);
+        n.q2.x = a; n.q2.y = -1; n.q2.z = eu; n.q2.w = ev;
+        nodeq_store(&L->ring[r & (HEAP_RING - 1)], n);
     }
+    alloc++;
     int32_t r_rank = 1;
     while (depth > 0) {                                                     // :34-39, unwound
-        const int32_t anc = stack[--depth];
-        HNode n = nodes[anc];
-        int32_t l = n.left, rr = r;
-        int32_t l_rank = (l >= 0) ? nodes[l].rank : 0, rr_rank = r_rank;
-        if (l < 0 || l_rank < rr_rank) { int32_t t = l; l = rr; rr = t; int32_t tr = l_rank; l_rank = rr_rank; rr_rank = tr; }
-        n.left = l; n.right = rr;
-        n.rank = (rr >= 0) ? rr_rank + 1 : 0;
-        r = alloc++;
-        nodes[r] = n;
-        r_rank = n.rank;
+        --depth;
+        const int32_t anc = uni(L->stk[depth]);
+        NodeQ n;
+        if (anc >= alloc - HEAP_RING) n = nodeq_load(&L->ring[anc & (HEAP_RING - 1)]);
+        else { n = nodeq_load(&nodes[anc]); asm volatile("" ::: "memory"); }
+        const int32_t l = n.q2.x, l_rank = (n.q1.w >> 8) & 0xff;
+        const bool sw = (l < 0) || (l_rank < r_rank);                       // :36-37
+        const int32_t nl = sw ? r : l, nrr = sw ? l : r;
+        const int32_t nl_rank = sw ? r_rank : l_rank, nr_rank = (nrr >= 0) ? (sw ? l_rank : r_rank) : 0;
+        const int32_t nrank = (nrr >= 0) ? nr_rank + 1 : 0;                 // :38
+        n.q2.x = nl; n.q2.y = nrr;
+        n.q1.w = nrank | (nl_rank << 8) | (nr_rank << 16);
+        if (alloc - flushed >= HEAP_RING) { block_sync(); heap_flush(nodes, L, flushed, flushed + HEAP_FLUSH, lane); }
+        r = alloc;
+        if (lane == 0) nodeq_store(&L->ring[r & (HEAP_RING - 1)], n);
+        alloc++;
+        r_rank = nrank;
     }
+    KPROF_STAMP(5);                                                         // leaf + unwinding stores
     return r;
 }
 
-AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // wave per contig, lane 0 works
+AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
-    if (V == 0 || k.lane != 0) return;
+    if (V == 0) return;
+    HeapLds *L = (HeapLds *)k.lds;
     const int64_t vb = w.voff[c];
     const Dist *d = w.sp_d + vb;
     const int32_t *best = w.sp_best + vb;
@@ -901,31 +984,75 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // wave per 
     HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
-    w.h_cnt[c] = 0;
-    if (dist_is_max(d[src])) { set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
-    int32_t alloc = 0, head = 0, tail = 0;
+    if (k.lane == 0) w.h_cnt[c] = 0;
+    if (dist_is_max(d[src])) { if (k.lane == 0) set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
+    int32_t alloc = 0, flushed = 0, head = 0, tail = 1, lds_hi = 1;
     bool ovf = false;
-    q[tail++] = dest;
-    h[dest] = -1;
+    if (k.lane == 0) { q[0] = dest; h[dest] = -1; L->bqv[0] = dest; L->bqh[0] = -1; }
+    block_sync();
+    KPROF_DECL;
+    KPROF_START();
     while (head < tail && !ovf) {
-        const int32_t u = q[head++];
-        int32_t hu = h[u];
-        const Dist du = d[u];
+        int32_t u, hu;
+        if (head < lds_hi) { u = uni(L->bqv[head & (HEAP_QN - 1)]); hu = uni(L->bqh[head & (HEAP_QN - 1)]); }
+        else { wave_fence(); u = uni(q[head]); hu = uni(h[u]); }     // queue window overflow (wide trees)
+        head++;
+        const Dist du = uni(d[u]);
+        const int32_t bu = uni(best[u]);
         bool seen_p = false;
-        for (int64_t e = w.rowptr[vb + u]; e < w.rowptr[vb + u + 1] && !ovf; e++) {
-            const int32_t v = w.e_col[e];
-            const Dist dv = d[v];
-            if (dist_is_max(dv)) continue;                           // :204-205
-            const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
-            if (!seen_p && v == best[u] && dist_eq(cc, dist_zero())) { seen_p = true; continue; }   // :207-210
-            hu = heap_insert(nodes, alloc, cap, hu, cc, u, v, ovf);
+        const int64_t r0 = uni(w.rowptr[vb + u]), r1 = uni(w.rowptr[vb + u + 1]);
+        const int64_t c0 = uni(w.cptr[vb + u]), c1 = uni(w.cptr[vb + u + 1]);
+        KPROF_STAMP(0);                                              // vertex header loads
+        for (int64_t base = r0; base < r1 && !ovf; base += AASM_WAVE) {
+            const int64_t e = base + k.lane;
+            bool valid = false, tree = false;
+            if (e < r1) {
+                const int32_t v = w.e_col[e];
+                const Dist dv = d[v];
+                if (!dist_is_max(dv)) {                              // :204-205
+                    const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
+                    valid = true;
+                    tree = (v == bu) && dist_eq(cc, dist_zero());    // :207
+                    L->cbuf[k.lane] = cc;
+                    L->vbuf[k.lane] = v;
+                }
+            }
+            block_sync();                                            // cbuf/vbuf visible to every lane
+            KPROF_STAMP(1);                                          // row chunk loads + costs
+            if (!seen_p) {                                           // skip the tree edge once (:207-210)
+                const uint64_t tm = wave_ballot(tree);
+                if (tm) { seen_p = true; if (k.lane == ffs64(tm) - 1) valid = false; }
+            }
+            uint64_t vm = wave_ballot(valid);
+            while (vm && !ovf) {                                     // inserts in list order
+                const int t = ffs64(vm) - 1;
+                vm &= vm - 1;
+                const Dist cc = uni(L->cbuf[t]);
+                hu = heap_insert(nodes, L, alloc, flushed, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
+            }
+            block_sync();                                            // before the next chunk overwrites cbuf
+            KPROF_STAMP(2);                                          // inserts
         }
-        h[u] = hu;
-        for (int64_t p = w.cptr[vb + u]; p < w.cptr[vb + u + 1]; p++) { const int32_t ch = w.cval[p]; h[ch] = hu; q[tail++] = ch; }   // :213
+        if (k.lane == 0) h[u] = hu;
+        // children adopt the heap (:213); they enter the LDS queue window while it has room
+        const int32_t nch = (int32_t)(c1 - c0);
+        int32_t ncache = 0;
+        if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
+        for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
+            const int32_t ch = w.cval[c0 + t];
+            h[ch] = hu; q[tail + t] = ch;
+            if (t < ncache) { L->bqv[(tail + t) & (HEAP_QN - 1)] = ch; L->bqh[(tail + t) & (HEAP_QN - 1)] = hu; }
+        }
+        lds_hi += ncache;
+        tail += nch;
+        block_sync();
+        KPROF_STAMP(3);                                              // children
     }
-    if (ovf) { set_status(w, c, -5); return; }
-    w.h_cnt[c] = alloc;
-    atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)alloc);
+    block_sync();
+    heap_flush(nodes, L, flushed, alloc, k.lane);
+    KPROF_FLUSH(w.prof_heap, c, k.lane);
+    if (ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
+    if (k.lane == 0) { w.h_cnt[c] = alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)alloc); }
 }
 
 // ====================================================================================
@@ -1022,8 +1149,10 @@ struct SelCtx {
     int32_t src, dest;
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
     Dist *dist2;
-    int32_t epoch;
+    int32_t epoch, last_head;
     bool err;
+    int lane;
+    char *lds;
     int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
 };
 
@@ -1040,19 +1169,24 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     while (cur != -1) {                                             // sidetrack chain, newest first
         if (ns >= s.cap) { s.err = true; return -1; }
         const HNode nd = nodes[knodes[cur]];
-        s.pathT[2 * ns] = nd.u; s.pathT[2 * ns + 1] = nd.v; ns++;
+        if (s.lane == 0) { s.pathT[2 * ns] = nd.u; s.pathT[2 * ns + 1] = nd.v; }
+        ns++;
         cur = kprev[cur];
     }
+    wave_fence();
     int32_t idx = ns - 1, la = 0, cv = s.src;
     while (cv != s.dest || idx >= 0) {
         if (la >= s.cap) { s.err = true; return -1; }
         if (idx >= 0 && cv == s.pathT[2 * idx]) {
-            s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = s.pathT[2 * idx + 1]; la++;
-            cv = s.pathT[2 * idx + 1]; idx--;
+            const int32_t hv = s.pathT[2 * idx + 1];
+            if (s.lane == 0) { s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = hv; }
+            la++;
+            cv = hv; idx--;
         } else {
             const int32_t nx = best[cv];
             if (nx < 0) { s.err = true; return -1; }
-            s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = nx; la++;
+            if (s.lane == 0) { s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = nx; }
+            la++;
             cv = nx;
         }
     }
@@ -1060,43 +1194,149 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
 }
 
 // internal_shortest_path_recover (paf_data.cpp:750-792): QRY_SCORE-mode DAG DP over the
-// forward topological window [order[a], order[b)); the hash maps become epoch-stamped
-// dense arrays.  Result edges are left in pathT in REVERSE order; returns their count,
-// 0 when a == b, -1 on "must not happen".
-AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
+// forward topological window [order[a], order[b)).  Result edges are left in pathT in
+// REVERSE order; returns their count, 0 when a == b, -1 on "must not happen".
+//
+// Targets beyond position order[b] are never expanded and never lie on the returned path,
+// so relaxing them (as the reference's hash map does) is unobservable and is skipped.
+// Two forms:
+//  * window of <= 63 vertices and <= ISPR_MAX_E edges (the common case): the window is
+//    staged in LDS by the whole wave in four parallel load rounds (order -> rowptr -> edges ->
+//    position of heads), then the DP runs on LDS state, lanes sharing one source's edges;
+//  * otherwise: same DP on epoch-stamped global arrays, lanes sharing one source's edges.
+// Inside a row targets are distinct, so the lane-parallel relaxation is conflict-free and
+// the sequential source order keeps the reference's strict-`<` first-wins behaviour.
+#define ISPR_MAX_E 192
+struct IsprLds {
+    int64_t wq[ISPR_MAX_E];
+    int32_t wr[ISPR_MAX_E];
+    int8_t tgt[ISPR_MAX_E];
+    uint8_t fl[ISPR_MAX_E];
+    Dist dist[64];
+    int64_t r0[64];
+    int32_t excl[64], u[64];
+    int8_t pre[64];
+    uint8_t reach[64];
+};
+static_assert(sizeof(IsprLds) <= AASM_LDS_BYTES, "LDS budget");
+
+AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
     const WS &w = *s.w;
-    if (a == bd) return 0;
     const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
     const int32_t ep = ++s.epoch;
-    s.dist2[a] = dist_zero(); s.pre2[a] = -1; s.stamp[a] = ep;
-    for (int32_t i = pos[a]; i < pos[bd]; i++) {
+    const int32_t pb = pos[bd];
+    if (s.lane == 0) { s.dist2[a] = dist_zero(); s.pre2[a] = -1; s.stamp[a] = ep; }
+    wave_fence();
+    for (int32_t i = pos[a]; i < pb; i++) {
         const int32_t u = order[i];
         if (s.stamp[u] != ep) continue;
         const Dist cd = s.dist2[u];
-        s.n_ispr_v++; s.n_ispr_e += w.rowptr[s.vb + u + 1] - w.rowptr[s.vb + u];
-        for (int64_t e = w.rowptr[s.vb + u]; e < w.rowptr[s.vb + u + 1]; e++) {
+        const int64_t r0 = w.rowptr[s.vb + u], r1 = w.rowptr[s.vb + u + 1];
+        s.n_ispr_v++; s.n_ispr_e += r1 - r0;
+        const bool u_ok = !(u == s.src || u == s.dest) && (w.v_j[s.vb + u] == wl);   // :767-773
+        for (int64_t e = r0 + s.lane; e < r1; e += AASM_WAVE) {
             const int32_t v = w.e_col[e];
-            if (wl_flag && v == bd) {                                // :767-773
-                if (u == s.src || u == s.dest) continue;
-                if (w.v_j[s.vb + u] != wl) continue;
-            }
+            if (pos[v] > pb) continue;
+            if (wl_flag && v == bd && !u_ok) continue;
             const Dist nd = dist_add(cd, edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]));
             if (s.stamp[v] != ep || dist_lt<QRY_SCORE_MODE>(nd, s.dist2[v])) { s.dist2[v] = nd; s.pre2[v] = u; s.stamp[v] = ep; }
         }
+        wave_fence();
     }
     if (s.stamp[bd] != ep) { s.err = true; return -1; }             // :783
     int32_t n = 0, last = bd;
     while (last != a) {
         if (n >= s.cap) { s.err = true; return -1; }
         const int32_t pv = s.pre2[last];
-        s.pathT[2 * n] = pv; s.pathT[2 * n + 1] = last; n++;
+        if (s.lane == 0) { s.pathT[2 * n] = pv; s.pathT[2 * n + 1] = last; }
+        n++;
         last = pv;
     }
+    wave_fence();
+    return n;
+}
+
+AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
+    const WS &w = *s.w;
+    if (a == bd) return 0;
+    const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
+    const int32_t pa = pos[a], pb = pos[bd];
+    const int32_t W = pb - pa;
+    if (W <= 0) { s.err = true; return -1; }
+    if (W > 63) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+    IsprLds *L = (IsprLds *)s.lds;
+    // round 1+2: window vertices and their rows, one lane per vertex
+    int32_t u_t = 0, deg = 0, T = 0;
+#if defined(AASM_HOST_EMUL)
+    {   // one lane: plain prefix loop
+        int32_t run = 0;
+        for (int32_t t = 0; t < W; t++) {
+            const int32_t uu = order[pa + t];
+            const int64_t r0 = w.rowptr[s.vb + uu];
+            L->u[t] = uu; L->r0[t] = r0; L->excl[t] = run;
+            run += (int32_t)(w.rowptr[s.vb + uu + 1] - r0);
+        }
+        T = run; (void)u_t; (void)deg;
+    }
+#else
+    {
+        int64_t r0 = 0;
+        if (s.lane < W) { u_t = order[pa + s.lane]; r0 = w.rowptr[s.vb + u_t]; deg = (int32_t)(w.rowptr[s.vb + u_t + 1] - r0); }
+        const int incl = wave_incl_add(deg);
+        T = wave_bcast(incl, AASM_WAVE - 1);
+        if (s.lane < W) { L->u[s.lane] = u_t; L->r0[s.lane] = r0; L->excl[s.lane] = incl - deg; }
+    }
+#endif
+    if (T > ISPR_MAX_E) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+    block_sync();
+    // round 3+4: every window edge, one lane per edge (source found by binary search in LDS)
+    for (int32_t idx = s.lane; idx < T; idx += AASM_WAVE) {
+        int lo = 0, hi = W - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L->excl[mid] <= idx) lo = mid; else hi = mid - 1; }
+        const int32_t su = L->u[lo];
+        const int64_t e = L->r0[lo] + (idx - L->excl[lo]);
+        const int32_t v = w.e_col[e];
+        int32_t rel = pos[v] - pa;
+        if (rel > W) rel = -1;
+        if (rel >= 0 && wl_flag && v == bd) {                        // :767-773
+            if (su == s.src || su == s.dest || w.v_j[s.vb + su] != wl) rel = -1;
+        }
+        L->tgt[idx] = (int8_t)rel; L->wq[idx] = w.e_wq[e]; L->wr[idx] = w.e_wr[e]; L->fl[idx] = w.e_fl[e];
+    }
+    for (int32_t t = s.lane; t <= W; t += AASM_WAVE) L->reach[t] = (t == 0) ? 1 : 0;
+    if (s.lane == 0) { L->dist[0] = dist_zero(); L->pre[0] = -1; }
+    block_sync();
+    // DP over the window, source by source
+    for (int32_t t = 0; t < W; t++) {
+        if (!L->reach[t]) continue;
+        const Dist cd = L->dist[t];
+        const int32_t e0 = L->excl[t], e1 = (t + 1 < W) ? L->excl[t + 1] : T;
+        s.n_ispr_v++; s.n_ispr_e += e1 - e0;
+        for (int32_t idx = e0 + s.lane; idx < e1; idx += AASM_WAVE) {
+            const int32_t tg = L->tgt[idx];
+            if (tg < 0) continue;
+            const Dist nd = dist_add(cd, edge_dist(L->wq[idx], L->wr[idx], L->fl[idx]));
+            if (!L->reach[tg] || dist_lt<QRY_SCORE_MODE>(nd, L->dist[tg])) { L->dist[tg] = nd; L->pre[tg] = (int8_t)t; L->reach[tg] = 1; }
+        }
+        block_sync();
+    }
+    if (!L->reach[W]) { s.err = true; return -1; }                   // :783
+    int32_t n = 0, last = W;
+    while (last != 0) {
+        if (n >= s.cap) { s.err = true; return -1; }
+        const int32_t pv = L->pre[last];
+        if (s.lane == 0) { s.pathT[2 * n] = L->u[pv]; s.pathT[2 * n + 1] = (last == W) ? bd : L->u[last]; }
+        n++;
+        last = pv;
+    }
+    wave_fence();
     return n;
 }
 AASM_DEV void sel_push(SelCtx &s, int32_t &lb, int32_t u, int32_t v) {
     if (lb >= s.cap) { s.err = true; return; }
-    s.pathB[2 * lb] = u; s.pathB[2 * lb + 1] = v; lb++;
+    if (s.lane == 0) { s.pathB[2 * lb] = u; s.pathB[2 * lb + 1] = v; }
+    lb++;
+    s.last_head = v;
 }
 // append the ISPR result (reverse order in pathT), optionally without its last edge
 AASM_DEV void sel_append_alt(SelCtx &s, int32_t &lb, int32_t n, bool drop_last) {
@@ -1115,7 +1355,7 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
             if (from_src) start = u;                                 // :804
             else {
                 if (lb == 0) { s.err = true; break; }
-                start = s.pathB[2 * lb - 1];                         // continuation_src (:863)
+                start = s.last_head;                                 // continuation_src (:863)
                 if (w.v_i[s.vb + v] != w.v_j[s.vb + v]) { sel_push(s, lb, u, v); continue; }   // :866-873
             }
             const int32_t y = w.v_j[s.vb + v];
@@ -1136,7 +1376,7 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
             }
         } else {                                                     // v == dest (:845-858)
             if (lb == 0) { s.err = true; break; }
-            const int32_t start = s.pathB[2 * lb - 1];
+            const int32_t start = s.last_head;
             const int32_t n = sel_ispr(s, start, v, false, -1);
             if (n < 0) break;
             if (n > 0) sel_append_alt(s, lb, n, false);
@@ -1158,90 +1398,98 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
     cov = 0;
     const int32_t la = sel_recover(s, kidx);
     if (la <= 0) { s.err = true; return 0; }
-    for (int32_t t = 0; t < la; t++) {                               // :1490-1496
+    wave_fence();
+    for (int32_t t = s.lane; t < la; t += AASM_WAVE) {               // :1490-1496
         const int32_t v = s.pathA[2 * t + 1];
         if (v != s.dest) { notalt[w.v_i[s.vb + v]] = 1; notalt[w.v_j[s.vb + v]] = 1; }
     }
+    wave_fence();
     const int32_t lb = sel_upgrade(s, la);                           // :1500-1501
+    wave_fence();
     if (s.err) return 0;
     s.n_path_e += la + lb;
-    int32_t n = 0;
-    for (int32_t t = 0; t < lb; t++) {                               // :1503-1557
-        const int32_t u = s.pathB[2 * t], v = s.pathB[2 * t + 1];
-        if (v == s.dest) continue;
-        if (n >= s.N) { s.err = true; return 0; }
+    // :1503-1557 as a map over path edges: edge t = (u, v) emits record cur(v) (nothing for
+    // v == dest, which is the last edge); a pair vertex v = (x, y) clips the start of its own
+    // element to edited_loc_str[x][y] and the END of the previous element to
+    // edited_loc_pre_end[x][y], i.e. element t takes its end clip from edge t + 1.
+    if (lb < 2 || s.pathB[2 * (lb - 1) + 1] != s.dest) { s.err = true; return 0; }
+    const int32_t n = lb - 1;
+    if (n > s.N) { s.err = true; return 0; }
+    int64_t part = 0;
+    bool bad = false;
+    for (int32_t t = s.lane; t < n; t += AASM_WAVE) {
+        const int32_t v = s.pathB[2 * t + 1], nv = s.pathB[2 * (t + 1) + 1];
+        if (v == s.dest) { bad = true; continue; }
         const int32_t y1 = w.v_i[s.vb + v], y2 = w.v_j[s.vb + v];
-        if (u == s.src || y1 == y2) {
-            out[n] = out_from_rec(w, s.b + y2);
-            out[n++].is_alt = notalt[y2] ? 0 : 1;                   // :1560-1566 (map only grows at :1490-1496)
-        } else {
-            if (n == 0) { s.err = true; return 0; }
-            out[n] = out_from_rec(w, s.b + y2);
-            out[n++].is_alt = notalt[y2] ? 0 : 1;
-            const int64_t sl = w.v_slot[s.vb + v];
-            out[n - 2].qe = w.ov_peq[sl]; out[n - 2].re = w.ov_per[sl];   // edited_loc_pre_end[x][y]
-            out[n - 1].qs = w.ov_stq[sl]; out[n - 1].rs = w.ov_str[sl];   // edited_loc_str[x][y]
-        }
+        OutElem o = out_from_rec(w, s.b + y2);
+        o.is_alt = notalt[y2] ? 0 : 1;                               // :1560-1566 (the map only grows at :1490-1496)
+        if (y1 != y2) { const int64_t sl = w.v_slot[s.vb + v]; o.qs = w.ov_stq[sl]; o.rs = w.ov_str[sl]; }
+        if (nv != s.dest && w.v_i[s.vb + nv] != w.v_j[s.vb + nv]) { const int64_t sl = w.v_slot[s.vb + nv]; o.qe = w.ov_peq[sl]; o.re = w.ov_per[sl]; }
+        out[t] = o;
+        part += (o.qe - o.qs) + (o.re > o.rs ? o.re - o.rs : o.rs - o.re);   // get_total_coverage, :1571-1579
     }
-    for (int32_t t = 0; t < n; t++) {                                // get_total_coverage, :1571-1579
-        cov += (out[t].qe - out[t].qs) + (out[t].re > out[t].rs ? out[t].re - out[t].rs : out[t].rs - out[t].re);
-    }
-    atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
+    if (wave_ballot(bad)) { s.err = true; return 0; }
+    cov = wave_sum(part);
+    if (s.lane == 0) atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
     s.n_out_e += n;
     return n;
 }
 
-AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // wave per contig, lane 0 works
+AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // one wave per contig
+    // Control flow is wave-uniform: every lane runs the same scalar program (uniform loads;
+    // identical stores), and the lanes fan out inside sel_ispr and the output copies.
     const int64_t c = k.bid;
-    if (k.lane != 0) return;
     const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
-    w.main_len[c] = 0; w.alt_len[c] = 0;
+    const bool L0 = (k.lane == 0);
+    if (L0) { w.main_len[c] = 0; w.alt_len[c] = 0; }
     if (N <= 0) return;
     if (N == 1) {                                                   // paf_data.cpp:235-239
         OutElem o; o.qs = w.in_qs[gb]; o.qe = w.in_qe[gb]; o.rs = w.in_rs[gb]; o.re = w.in_re[gb]; o.ctg_index = 0; o.is_alt = 0;
-        w.main_out[b] = o; w.main_len[c] = 1;
+        if (L0) { w.main_out[b] = o; w.main_len[c] = 1; }
         return;
     }
     if (w.status[c] != 0) return;
     const int32_t found = w.kfound[c];
-    if (found <= 0) { set_status(w, c, -6); return; }               // :732
+    if (found <= 0) { if (L0) set_status(w, c, -6); return; }               // :732
     SelCtx s;
     s.w = &w; s.c = c; s.b = b; s.N = N; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = N + 2;
     s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
     const int64_t pb = 2 * (b + 2 * c);                             // (N+2) pairs per contig
     s.pathA = w.pathA + pb; s.pathB = w.pathB + pb; s.pathT = w.pathT + pb;
     s.pre2 = w.pre2 + s.vb; s.stamp = w.stamp + s.vb; s.dist2 = w.dist2 + s.vb;
-    s.epoch = 0; s.err = false; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
+    s.epoch = 0; s.last_head = -1; s.err = false; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
     const Dist *kd = w.kd + c * (int64_t)w.K;
     OutElem *cur = w.cur_out + b, *mo = w.main_out + b, *ao = w.alt_out + b;
     const Dist mind = kd[0];                                        // :1585
     int64_t cov = 0, max_cov = 0;
     int32_t n = sel_convert(s, 0, cov);                             // :1589-1593
-    if (s.err) { set_status(w, c, -6); return; }
+    if (s.err) { if (L0) set_status(w, c, -6); return; }
     max_cov = cov;
-    for (int32_t t = 0; t < n; t++) mo[t] = cur[t];
-    w.main_len[c] = n;
+    for (int32_t t = k.lane; t < n; t += AASM_WAVE) mo[t] = cur[t];
+    if (L0) w.main_len[c] = n;
     for (int32_t idx = 1; idx < found; idx++) {                     // ties, :1596-1611
         const Dist dd = kd[idx];
         if (!(mind.qry + mind.ref == dd.qry + dd.ref && mind.anom == dd.anom)) break;
         n = sel_convert(s, idx, cov);
-        if (s.err) { set_status(w, c, -6); return; }
+        if (s.err) { if (L0) set_status(w, c, -6); return; }
         if (cov > max_cov) {
             max_cov = cov;
-            for (int32_t t = 0; t < n; t++) mo[t] = cur[t];
-            w.main_len[c] = n;
-            w.all_gen[c] += 1;                                      // paf_ctg_max_out.clear()
+            for (int32_t t = k.lane; t < n; t += AASM_WAVE) mo[t] = cur[t];
+            if (L0) { w.main_len[c] = n; w.all_gen[c] += 1; }       // paf_ctg_max_out.clear()
+            wave_fence();
         } else if (cov == max_cov) {
-            const int64_t off = (int64_t)atomic_add(&w.counters[CNT_POOL], (int64_t)n);
-            const int64_t r = (int64_t)atomic_add(&w.counters[CNT_AR], (int64_t)1);
+            int64_t off = 0, r = 0;
+            if (k.lane == 0) { off = (int64_t)atomic_add(&w.counters[CNT_POOL], (int64_t)n); r = (int64_t)atomic_add(&w.counters[CNT_AR], (int64_t)1); }
+            off = wave_bcast(off, 0); r = wave_bcast(r, 0);
             if (off + n <= w.pool_cap && r < w.ar_cap) {
-                for (int32_t t = 0; t < n; t++) w.pool[off + t] = cur[t];
-                w.ar_ctg[r] = (int32_t)c; w.ar_gen[r] = w.all_gen[c]; w.ar_seq[r] = w.all_seq[c]; w.ar_off[r] = off; w.ar_len[r] = n;
-            } else {
+                for (int32_t t = k.lane; t < n; t += AASM_WAVE) w.pool[off + t] = cur[t];
+                if (L0) { w.ar_ctg[r] = (int32_t)c; w.ar_gen[r] = w.all_gen[c]; w.ar_seq[r] = w.all_seq[c]; w.ar_off[r] = off; w.ar_len[r] = n; }
+            } else if (k.lane == 0) {
                 // keep counting the demand; the host re-runs the selection with an exact-size pool
                 atomic_add(&w.counters[CNT_OVF], (int64_t)1);
             }
-            w.all_seq[c] += 1;
+            if (L0) w.all_seq[c] += 1;
+            wave_fence();
         }
     }
     max_cov = -1;                                                   // alt path, :1613-1649
@@ -1256,26 +1504,28 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // wave per 
             if (ans_idx == -1 || up * ans_down < down * ans_up) {
                 ans_up = up; ans_down = down; ans_idx = i;
                 n = sel_convert(s, i, cov);
-                if (s.err) { set_status(w, c, -6); return; }
+                if (s.err) { if (L0) set_status(w, c, -6); return; }
                 max_cov = cov;
-                for (int32_t t = 0; t < n; t++) ao[t] = cur[t];
-                w.alt_len[c] = n;
+                for (int32_t t = k.lane; t < n; t += AASM_WAVE) ao[t] = cur[t];
+                if (L0) w.alt_len[c] = n;
             } else {
                 const Dist da = kd[ans_idx];
                 if (dd.qry + dd.ref == da.qry + da.ref && dd.anom == da.anom) {
                     n = sel_convert(s, i, cov);
-                    if (s.err) { set_status(w, c, -6); return; }
+                    if (s.err) { if (L0) set_status(w, c, -6); return; }
                     if (cov > max_cov) {
                         max_cov = cov;
-                        for (int32_t t = 0; t < n; t++) ao[t] = cur[t];
-                        w.alt_len[c] = n;
+                        for (int32_t t = k.lane; t < n; t += AASM_WAVE) ao[t] = cur[t];
+                        if (L0) w.alt_len[c] = n;
                     }
                 }
             }
         }
     }
-    atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
-    atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
+    if (k.lane == 0) {
+        atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
+        atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
+    }
 }
 
 // compaction of main/alt into ragged arrays: one wave per contig

@@ -82,6 +82,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 #define CHECK_ALLOC() do { if (be.failed()) return AASM_E_NOMEM; } while (0)
 
     AZ(status, int32_t, C, "status");
+    AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel");
     AZ(counters, int64_t, CNT_N, "counters");
 
     // ---- K1 sort + parts

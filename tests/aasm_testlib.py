@@ -213,7 +213,7 @@ def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None):
         chk("heap_count", [h_cnt[c]], o["heap_nodes"])
         hn = hnodes[int(hoff[c]):int(hoff[c]) + int(h_cnt[c])]
         chk("heap_key_qry", hn["kq"], o["heap_key_qry"]); chk("heap_left", hn["left"], o["heap_left"]); chk("heap_right", hn["right"], o["heap_right"])
-        chk("heap_u", hn["u"], o["heap_u"]); chk("heap_v", hn["v"], o["heap_v"]); chk("heap_rank", hn["rank"], o["heap_rank"])
+        chk("heap_u", hn["u"], o["heap_u"]); chk("heap_v", hn["v"], o["heap_v"]); chk("heap_rank", hn["rank"] & 0xff, o["heap_rank"])   # upper bytes cache the child ranks
         chk("heap_root", h_root[vb:vb + V], o["heap_root"])
     return bad
 

@@ -36,7 +36,8 @@ struct EmuBackend {
         for (int64_t b = 0; b < nblocks; b++) {
             // one logical thread per block slot: bodies index with bid*nthreads+tid
             for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {
-                KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0};
+                alignas(16) static char lds[AASM_LDS_BYTES];
+                KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0, lds};
                 run_kernel_body(kn, k, w);
             }
         }

@@ -1,0 +1,17 @@
+"""Diagnostic: per-section cycle sums of aasm_k7_heap / aasm_k9_select (needs the -DAASM_KPROF build)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["AASM_LIB_OVERRIDE"] = os.path.join(ROOT, "alignasm_amd", "libalignasm_amd_kprof.so")
+sys.path.insert(0, ROOT)
+import numpy as np, alignasm_amd as A
+nc, nr, K, dense, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+paf = A.Paf.synth(nc, nr, seed, dense=bool(dense), no_cs=True)
+db = A.DeviceBatch(paf)
+for _ in range(2):
+    res = db.solve(max_paths=K, timing=True, keep_debug=True)
+st = res.stats()
+for name in ("prof_heap", "prof_sel"):
+    p = res.debug(name, np.int64)[: nc * 8].reshape(nc, 8)
+    print(name, "mean cycles/contig per section:", np.round(p.mean(0)).astype(int).tolist(), "sum", int(p.sum(1).mean()))
+print(json.dumps({k: round(v, 3) for k, v in st["phase_ms"].items() if v > 0}))
+print("V/contig", st["n_vertices"] / nc, "E/contig", st["n_edges"] / nc, "H/contig", st["n_heap_nodes"] / nc)
