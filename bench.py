@@ -168,6 +168,9 @@ def main():
                       "device_MB": stats["device_bytes"] >> 20},
             "setup": {"gen_s": round(gen_s, 2), "upload_s": round(upload_s, 2)},
         }
+        pmc = pmc_traffic(args.workload, custom, dom_name)
+        if pmc:
+            out["roofline"].update(pmc)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(paf, nc, K, args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -176,6 +179,26 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, custom, kernel):
+    """HBM traffic of the dominant kernel from the committed OFFLINE rocprofv3 --pmc passes
+    (profiles/r01_c3_pmc_fetch_write.json: one pass per counter, --kernel-trace only).
+    FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half
+    the bytes of a wide (16 B/lane) coalesced stream and is uncalibrated for other widths; these
+    kernels gather 4-48 B per access, so the raw value is reported and the x2 figure is given
+    as the upper bound.  Only attached when the run IS the profiled workload."""
+    path = os.path.join(ROOT, "profiles", "r01_c3_pmc_fetch_write.json")
+    if custom or workload != "c3" or not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    for name, v in data.items():
+        if kernel in name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            f, w_ = v["FETCH_SIZE"]["mean_per_launch"] * 1024, v["WRITE_SIZE"]["mean_per_launch"] * 1024
+            return {"traffic": int(f + w_), "traffic_fetch_raw": int(f), "traffic_write": int(w_),
+                    "traffic_upper_fetch_x2": int(2 * f + w_),
+                    "traffic_source": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c3_pmc_fetch_write.json"}
+    return None
 
 
 def cpu_baseline(paf, nc, K, sample):

@@ -1,0 +1,82 @@
+"""GPU tier at BASELINE.json's full single-GPU size (C3: 5 000 contigs x 1 000 records,
+K = 4): size-independent properties of the result + exact comparison with the oracle on a
+sample of contigs (the oracle needs seconds per hundred contigs, not per five thousand)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3(T):
+    api = T.api()
+    paf = api.Paf.synth(5000, 1000, 21, no_cs=True)
+    db = api.DeviceBatch(paf)
+    res = db.solve(max_paths=4, timing=True)
+    out = res.fetch()
+    st = res.stats()
+    yield paf, db, out, st
+    res.close(); db.close(); paf.close()
+
+
+def test_c3_chain_properties(T, c3):
+    paf, db, out, st = c3
+    assert (out["status"] == 0).all() and st["n_internal_errors"] == 0 and st["n_unconnectable"] == 0
+    view = paf.view()
+    from alignasm_amd._abi import _np_from
+    rec_off = _np_from(view.ctg_rec_off, 5001, np.int64)
+    qs_in = _np_from(view.qry_str, int(view.n_records), np.int64)
+    qe_in = _np_from(view.qry_end, int(view.n_records), np.int64)
+    m, off = out["main"], out["main_off"]
+    assert (np.diff(off) >= 1).all()
+    ctg = np.repeat(np.arange(5000), np.diff(off))
+    rec = rec_off[ctg] + m["ctg_index"]
+    # every element stays inside its record and keeps at least one base
+    assert (m["ctg_index"] >= 0).all() and (rec < rec_off[ctg + 1]).all()
+    assert (qs_in[rec] <= m["qs"]).all() and (m["qs"] <= m["qe"]).all() and (m["qe"] <= qe_in[rec]).all()
+    # chain: strictly increasing, non-overlapping query intervals inside a contig (clipping worked)
+    same = ctg[1:] == ctg[:-1]
+    assert (m["qe"][:-1][same] < m["qs"][1:][same]).all()
+    # main path elements were all seen on the un-upgraded path or flagged as alternative
+    assert set(np.unique(m["is_alt"])) <= {0, 1}
+    # alt list: either empty or a valid chain too
+    a, aoff = out["alt"], out["alt_off"]
+    actg = np.repeat(np.arange(5000), np.diff(aoff))
+    asame = actg[1:] == actg[:-1]
+    assert (a["qe"][:-1][asame] < a["qs"][1:][asame]).all()
+
+
+def test_c3_idempotent_and_deterministic(T, c3):
+    paf, db, out, st = c3
+    res2 = db.solve(max_paths=4)
+    out2 = res2.fetch(); res2.close()
+    assert T.diff_outputs(out, out2, stats=False) == []
+
+
+def test_c3_sample_matches_oracle(T, c3):
+    paf, db, out, st = c3
+    from alignasm_amd._abi import HostBatch
+    rng = np.random.default_rng(3)
+    starts = sorted(int(x) for x in rng.choice(4990, size=6, replace=False))
+    for c0 in starts:                                  # 6 windows of 8 contigs
+        hb = HostBatch.from_view_range(paf.view(), c0, c0 + 8)
+        want = T.oracle_solve(hb, 4)
+        mo, ao = out["main_off"], out["alt_off"]
+        got_main = out["main"][mo[c0]:mo[c0 + 8]]
+        got_alt = out["alt"][ao[c0]:ao[c0 + 8]]
+        assert np.array_equal(want["main"], got_main), c0
+        assert np.array_equal(want["alt"], got_alt), c0
+        assert np.array_equal(want["main_off"], mo[c0:c0 + 9] - mo[c0]), c0
+
+
+def test_multi_device_entry_equals_single(T):
+    """aasm_solve_batch_multi with one device is the plain path; with n > available devices it
+    must fail loudly rather than fall back."""
+    api = T.api()
+    hb = T.synth(12, 80, 5, heavy_tail=True)
+    a = api.solve_batch(hb, max_paths=16)
+    b = api.solve_batch(hb, max_paths=16, n_devices=1)
+    assert T.diff_outputs(a, b, stats=False) == []
+    if api.device_count() == 1:
+        with pytest.raises(api.AlignasmError):
+            api.solve_batch(hb, max_paths=16, n_devices=2)
