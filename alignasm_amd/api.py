@@ -47,7 +47,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_parse_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_parse_mem", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text",
 ]
 
@@ -90,6 +90,10 @@ class Paf:
         h = C.c_void_p()
         _check(LIB.aasm_synth_paf(C.byref(cfg), C.byref(h)))
         return Paf(h)
+
+    def merge_alt(self, text: bytes, alt_baseline=0.5):
+        """--alt: merge a second PAF (sub-contig re-alignments), alignasm.cpp:186-332."""
+        _check(LIB.aasm_paf_merge_alt_mem(self._h, text, C.c_int64(len(text)), C.c_double(alt_baseline)))
 
     @property
     def n_contigs(self):

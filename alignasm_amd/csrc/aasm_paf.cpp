@@ -233,6 +233,141 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
     return AASM_OK;
 }
 
+// ---- --alt merge (alignasm.cpp:186-332) ------------------------------------------------
+// Rows of the second PAF are re-alignments of sub-contig pieces named "<contig>:<start>-<end>".
+// Each row is shifted back into contig coordinates; inside a group (same contig, same start)
+// every row whose aln_len / piece_length exceeds ALT_BASELINE is appended to the contig, and
+// if none does, the row with the best ratio is appended when the group ends.
+struct AltRec {
+    int64_t qs, qe, rs, re, qtot, rtot;
+    int32_t chr, mat, aln, row;
+    uint8_t fwd, mq;
+    std::string cs;
+    std::vector<int64_t> ql, qr, rl;
+};
+
+static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aasm_paf &paf) {
+    const int64_t C = paf.n_contigs();
+    std::unordered_map<std::string, int32_t> chr_map, paf_map;
+    for (size_t i = 0; i < paf.chr_name.size(); i++) chr_map.emplace(paf.chr_name[i], (int32_t)i);
+    for (int64_t c = 0; c < C; c++) paf_map[paf.ctg_name[c]] = (int32_t)c;          // last index wins (:136)
+    std::vector<std::vector<AltRec>> added(C);
+    std::vector<std::string_view> f;
+    std::vector<CsOp> ops;
+    // per-contig qry_total of the LAST record (the reference copies it from .back(), :267-272)
+    auto last_qtot = [&](int32_t c) -> int64_t {
+        if (!added[c].empty()) return added[c].back().qtot;
+        return paf.qry_total[paf.ctg_rec_off[c + 1] - 1];
+    };
+    std::string tar_real;
+    int64_t tar_off = -1;
+    bool tar_flag = false, tar_init = false;
+    double tar_ratio = 0;
+    AltRec ratio_max;
+    int32_t ratio_max_ctg = 0;
+    auto flush_group = [&]() {                                                      // :244-252
+        if (!tar_init || tar_flag) return;
+        auto it = paf_map.find(tar_real);
+        added[it == paf_map.end() ? 0 : it->second].push_back(ratio_max);
+        (void)ratio_max_ctg;
+    };
+    int32_t row = 0;
+    int64_t p = 0;
+    while (p < len) {
+        const char *nl = (const char *)std::memchr(text + p, '\n', len - p);
+        int64_t e = nl ? (nl - text) : len, le = e;
+        if (le > p && text[le - 1] == '\r') le--;
+        if (le > p) {
+            f.clear();
+            int64_t st = p;
+            for (int64_t i = p; i <= le; i++)
+                if (i == le || text[i] == '\t') { f.emplace_back(text + st, i - st); st = i + 1; }
+            if (f.size() < 12) { paf.error = "alt PAF row " + std::to_string(row) + " has fewer than 12 columns"; return AASM_E_PARSE; }
+            std::string qry_chr(f[0]), ref_chr(f[5]);
+            auto ci = chr_map.find(ref_chr);
+            int32_t chr_id;
+            if (ci == chr_map.end()) { chr_id = (int32_t)paf.chr_name.size(); chr_map.emplace(ref_chr, chr_id); paf.chr_name.push_back(ref_chr); }
+            else chr_id = ci->second;
+            // parseString (:209-233): "<name>:<start>-<end>" -> (name, start - 1)
+            size_t colon = qry_chr.find(':');
+            if (colon == std::string::npos) { paf.error = "Invalid input string format"; return AASM_E_PARSE; }
+            std::string real = qry_chr.substr(0, colon);
+            size_t dash = qry_chr.find('-', colon + 1);
+            if (dash == std::string::npos) dash = qry_chr.size();
+            int64_t second;
+            if (!parse_i64(std::string_view(qry_chr).substr(colon + 1, dash - colon - 1), second)) { paf.error = "Error parsing number"; return AASM_E_PARSE; }
+            const int64_t qry_offset = second - 1;
+            auto pm = paf_map.find(real);
+            const int32_t ctg = pm == paf_map.end() ? 0 : pm->second;               // operator[] default (:267)
+            int64_t qtot_piece, qs, qe, rtot, rs, re, mq, mat, aln;
+            if (!parse_i64(f[1], qtot_piece) || !parse_i64(f[2], qs) || !parse_i64(f[3], qe) || !parse_i64(f[6], rtot) ||
+                !parse_i64(f[7], rs) || !parse_i64(f[8], re) || !parse_i64(f[9], mat) || !parse_i64(f[10], aln) || !parse_i64(f[11], mq)) {
+                paf.error = "alt PAF row " + std::to_string(row) + ": non-numeric field";
+                return AASM_E_PARSE;
+            }
+            AltRec r;
+            r.qtot = last_qtot(ctg);
+            r.qs = qs + qry_offset; r.qe = qe + qry_offset - 1;                       // :273-275
+            r.rtot = rtot; r.rs = rs; r.re = re - 1;
+            r.chr = chr_id;
+            r.fwd = (!f[4].empty() && f[4][0] == '+') ? 1 : 0;
+            if (!r.fwd) std::swap(r.rs, r.re);
+            r.mq = (uint8_t)mq;
+            std::string_view cs;
+            for (size_t i = 12; i < f.size(); i++)
+                if (f[i].size() >= 5 && f[i].substr(0, 5) == "cs:Z:") { cs = f[i]; break; }
+            if (cs.empty()) { paf.error = "Missing cs:Z tag in alternative PAF record for query '" + qry_chr + "'"; return AASM_E_PARSE; }
+            r.cs.assign(cs.data(), cs.size());
+            r.mat = (int32_t)mat; r.aln = (int32_t)aln; r.row = row;
+            std::string err;
+            if (match_ranges(cs.data(), (int64_t)cs.size(), r.fwd != 0, r.qs, r.qe, r.rs, r.re, &r.ql, &r.qr, &r.rl, ops, err) < 0) {
+                paf.error = err + " (alt row " + std::to_string(row) + ")";
+                return AASM_E_PARSE;
+            }
+            if (!tar_init || tar_off != qry_offset || tar_real != real) {           // :305-314
+                flush_group();
+                tar_init = true; tar_flag = false; tar_ratio = 0; tar_off = qry_offset; tar_real = real;
+                ratio_max = AltRec();
+            }
+            const double aln_ratio = (double)aln / (double)qtot_piece;                // :316
+            if (aln_ratio > tar_ratio) { tar_ratio = aln_ratio; ratio_max = r; }
+            if (aln_ratio > ALT_BASELINE) { added[ctg].push_back(r); tar_flag = true; }   // :323-327
+            row++;
+        }
+        p = e + 1;
+    }
+    flush_group();
+    // rebuild the flat arrays: every contig = its main records followed by the appended ones
+    aasm_paf n;
+    n.ctg_name = paf.ctg_name; n.chr_name = paf.chr_name; n.has_cs = paf.has_cs;
+    n.ctg_rec_off.assign(1, 0); n.cs_off.assign(1, 0); n.rec_rng_off.assign(1, 0);
+    for (int64_t c = 0; c < C; c++) {
+        for (int64_t r = paf.ctg_rec_off[c]; r < paf.ctg_rec_off[c + 1]; r++) {
+            n.qry_str.push_back(paf.qry_str[r]); n.qry_end.push_back(paf.qry_end[r]); n.ref_str.push_back(paf.ref_str[r]); n.ref_end.push_back(paf.ref_end[r]);
+            n.qry_total.push_back(paf.qry_total[r]); n.ref_total.push_back(paf.ref_total[r]); n.ref_chr.push_back(paf.ref_chr[r]);
+            n.mat_num.push_back(paf.mat_num[r]); n.aln_len.push_back(paf.aln_len[r]); n.row_index.push_back(paf.row_index[r]);
+            n.cord_type.push_back(paf.cord_type[r]); n.aln_fwd.push_back(paf.aln_fwd[r]); n.map_qul.push_back(paf.map_qul[r]);
+            n.cs_pool.append(paf.cs_pool, (size_t)paf.cs_off[r], (size_t)(paf.cs_off[r + 1] - paf.cs_off[r]));
+            n.cs_off.push_back((int64_t)n.cs_pool.size());
+            for (int64_t t = paf.rec_rng_off[r]; t < paf.rec_rng_off[r + 1]; t++) { n.rng_qry_l.push_back(paf.rng_qry_l[t]); n.rng_qry_r.push_back(paf.rng_qry_r[t]); n.rng_ref_l.push_back(paf.rng_ref_l[t]); }
+            n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
+        }
+        for (const AltRec &a : added[c]) {
+            n.qry_str.push_back(a.qs); n.qry_end.push_back(a.qe); n.ref_str.push_back(a.rs); n.ref_end.push_back(a.re);
+            n.qry_total.push_back(a.qtot); n.ref_total.push_back(a.rtot); n.ref_chr.push_back(a.chr);
+            n.mat_num.push_back(a.mat); n.aln_len.push_back(a.aln); n.row_index.push_back(a.row);
+            n.cord_type.push_back(1); n.aln_fwd.push_back(a.fwd); n.map_qul.push_back(a.mq);   // TYPE_ALT (:302)
+            n.cs_pool += a.cs; n.cs_off.push_back((int64_t)n.cs_pool.size());
+            n.rng_qry_l.insert(n.rng_qry_l.end(), a.ql.begin(), a.ql.end()); n.rng_qry_r.insert(n.rng_qry_r.end(), a.qr.begin(), a.qr.end());
+            n.rng_ref_l.insert(n.rng_ref_l.end(), a.rl.begin(), a.rl.end());
+            n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
+        }
+        n.ctg_rec_off.push_back((int64_t)n.qry_str.size());
+    }
+    paf = std::move(n);
+    return AASM_OK;
+}
+
 // ---- writers (alignasm.cpp:398-490) ---------------------------------------------------
 static inline void put_i64(std::string &s, int64_t v) {
     char buf[24];
@@ -305,6 +440,26 @@ int aasm_paf_read(const char *path, aasm_paf **out) {
     while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, n);
     std::fclose(fp);
     return aasm_paf_parse_mem(data.data(), (int64_t)data.size(), out);
+}
+
+// --alt: merge a second PAF of sub-contig re-alignments (alignasm.cpp:186-332)
+int aasm_paf_merge_alt_mem(aasm_paf *paf, const char *text, int64_t len, double alt_baseline) {
+    if (!paf || !text) return AASM_E_INVAL;
+    if (len == 0) return AASM_OK;                                   // empty file == no --alt (:196-200)
+    int rc = merge_alt_text(text, len, alt_baseline, *paf);
+    if (rc != AASM_OK) set_last_error(paf->error);
+    return rc;
+}
+int aasm_paf_merge_alt(aasm_paf *paf, const char *path, double alt_baseline) {
+    if (!paf || !path) return AASM_E_INVAL;
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) { set_last_error(std::string("cannot open ") + path); return AASM_E_IO; }
+    std::string data;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, n);
+    std::fclose(fp);
+    return aasm_paf_merge_alt_mem(paf, data.data(), (int64_t)data.size(), alt_baseline);
 }
 
 void aasm_paf_free(aasm_paf *paf) { delete paf; }

@@ -34,7 +34,8 @@ int main(int argc, char **argv) {
     std::memset(&opts, 0, sizeof(opts));
     opts.max_paths = 10000;
     int gpus = 1;
-    bool bad = false;
+    double alt_baseline = 0.5;
+    bool bad = false, use_alt = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *what) -> const char * {
@@ -45,7 +46,7 @@ int main(int argc, char **argv) {
         else if (a == "-v" || a == "--version") { std::cout << "0.1.0\n"; return 0; }
         else if (a == "-t" || a == "--thread") (void)std::atoi(need("--thread"));
         else if (a == "-a" || a == "--alt") alt_loc = need("--alt");
-        else if (a == "-b" || a == "--alt_baseline") (void)std::atof(need("--alt_baseline"));
+        else if (a == "-b" || a == "--alt_baseline") alt_baseline = std::atof(need("--alt_baseline"));
         else if (a == "--non_skip_linkable") opts.non_skip_linkable = 1;
         else if (a == "--max-paths") opts.max_paths = std::atoi(need("--max-paths"));
         else if (a == "--gpus") gpus = std::atoi(need("--gpus"));
@@ -61,22 +62,23 @@ int main(int argc, char **argv) {
         usage(std::cerr);
         return 1;
     }
-    if (!alt_loc.empty()) {
-        std::error_code ec;
-        auto sz = std::filesystem::file_size(alt_loc, ec);
+    if (!alt_loc.empty()) {                                                     // :186-201
         if (std::filesystem::path(alt_loc).extension() != ".paf") {
             std::cerr << "Wrong PAF file : " << std::filesystem::absolute(alt_loc);
             usage(std::cerr);
             return 1;
         }
-        if (ec || sz != 0) {                                                    // empty file == no --alt (:196-200)
-            std::cerr << "--alt merge (src/alignasm.cpp:186-332) is not implemented in this build\n";
-            return 1;
-        }
+        std::error_code ec;
+        auto sz = std::filesystem::file_size(alt_loc, ec);
+        use_alt = !(!ec && sz == 0);                                            // empty file == no --alt
     }
     aasm_paf *paf = nullptr;
     int rc = aasm_paf_read(std::filesystem::absolute(p).c_str(), &paf);
     if (rc != AASM_OK) { std::cerr << aasm_last_error() << "\n"; return 1; }    // e.g. "Missing cs:Z tag ..." (:165-168)
+    if (use_alt) {
+        rc = aasm_paf_merge_alt(paf, std::filesystem::absolute(alt_loc).c_str(), alt_baseline);
+        if (rc != AASM_OK) { std::cerr << aasm_last_error() << "\n"; aasm_paf_free(paf); return 1; }
+    }
     std::cout << "File read complete" << std::endl;                              // :340
     aasm_batch_in view;
     aasm_paf_batch(paf, &view);

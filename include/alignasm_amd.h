@@ -192,6 +192,9 @@ typedef struct aasm_paf aasm_paf;    /* parsed PAF file: names, records, cs stri
 
 int  aasm_paf_read(const char *path, aasm_paf **paf);              /* alignasm.cpp:76-183 */
 int  aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **paf);
+/* --alt merge of a second PAF of sub-contig re-alignments (alignasm.cpp:186-332) */
+int  aasm_paf_merge_alt(aasm_paf *paf, const char *alt_path, double alt_baseline);
+int  aasm_paf_merge_alt_mem(aasm_paf *paf, const char *text, int64_t len, double alt_baseline);
 void aasm_paf_free(aasm_paf *paf);
 int  aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *view);      /* borrowed pointers  */
 int64_t aasm_paf_n_contigs(const aasm_paf *paf);

@@ -1,0 +1,113 @@
+"""--alt second-PAF merge (reference: src/alignasm.cpp:186-332), checked against an
+independent Python restatement of the grouping / baseline rules."""
+import ctypes as C
+
+import numpy as np
+
+
+def _alt_text(T, ctg_names, seed):
+    """Build an alt PAF: pieces '<contig>:<start>-<end>' whose rows come from a synthetic PAF."""
+    api = T.api()
+    src = api.Paf.synth(4, 9, seed).to_text().decode().splitlines()
+    rows, piece_specs = [], [(ctg_names[0], 1001), (ctg_names[0], 1001), (ctg_names[1], 501), (ctg_names[1], 20001), ("unknown_ctg", 11)]
+    for i, line in enumerate(src):
+        f = line.split("\t")
+        name, start = piece_specs[(i // 5) % len(piece_specs)]
+        qs, qe = int(f[2]), int(f[3])
+        piece_len = qe + (37 if i % 3 else 100000)      # some rows clear the 0.5 baseline, some do not
+        f[0] = f"{name}:{start}-{start + piece_len - 1}"
+        f[1] = str(piece_len)
+        rows.append("\t".join(f))
+    return ("\n".join(rows) + "\n").encode()
+
+
+def _expected(main, alt_text, ctg_names, chr_names, baseline):
+    """Python restatement of alignasm.cpp:255-331 -> per contig list of appended (fields, row)."""
+    paf_map = {n: i for i, n in enumerate(ctg_names)}
+    off = main["ctg_rec_off"]
+    last_qtot = {c: int(main["qry_total"][off[c + 1] - 1]) for c in range(len(ctg_names))}
+    added = {c: [] for c in range(len(ctg_names))}
+    chr_map = {n: i for i, n in enumerate(chr_names)}
+    grp = None
+    tar_flag, tar_ratio, best = False, 0.0, None
+
+    def flush():
+        if grp is not None and not tar_flag:
+            added[paf_map.get(grp[0], 0)].append(best)
+    for row, line in enumerate(alt_text.decode().splitlines()):
+        f = line.split("\t")
+        name, rest = f[0].split(":", 1)
+        offset = int(rest.split("-")[0]) - 1
+        ctg = paf_map.get(name, 0)
+        qt = added[ctg][-1]["qtot"] if added[ctg] else last_qtot[ctg]
+        fwd = f[4] == "+"
+        rs, re_ = int(f[7]), int(f[8]) - 1
+        if not fwd:
+            rs, re_ = re_, rs
+        if f[5] not in chr_map:
+            chr_map[f[5]] = len(chr_map)
+        rec = dict(qs=int(f[2]) + offset, qe=int(f[3]) + offset - 1, rs=rs, re=re_, qtot=qt, chr=chr_map[f[5]], fwd=int(fwd), mq=int(f[11]), row=row)
+        if grp != (name, offset):
+            flush()
+            grp, tar_flag, tar_ratio, best = (name, offset), False, 0.0, None
+        ratio = float(f[10]) / float(f[1])
+        if ratio > tar_ratio:
+            tar_ratio, best = ratio, rec
+        if ratio > baseline:
+            added[ctg].append(rec)
+            tar_flag = True
+    flush()
+    return added
+
+
+def test_alt_merge_matches_restated_rules(T, tmp_path):
+    api = T.api()
+    paf = api.Paf.synth(3, 12, 7)
+    text = paf.to_text()
+    names = []
+    for line in text.decode().splitlines():
+        if not names or names[-1] != line.split("\t")[0]:
+            names.append(line.split("\t")[0])
+    main = {k: v.copy() for k, v in paf.batch().arrays.items()}
+    chr_first = []
+    for line in text.decode().splitlines():
+        ch = line.split("\t")[5]
+        if ch not in chr_first:
+            chr_first.append(ch)
+    again = api.Paf.parse(text)                      # chr ids by first appearance, like the reader
+    main = {k: v.copy() for k, v in again.batch().arrays.items()}
+    alt = _alt_text(T, names, 99)
+    exp = _expected(main, alt, names, chr_first, 0.5)
+    again.merge_alt(alt, 0.5)
+    got = again.batch().arrays
+    off_m, off_g = main["ctg_rec_off"], got["ctg_rec_off"]
+    assert sum(len(v) for v in exp.values()) > 0 and any(len(v) == 0 for v in exp.values()) is not None
+    for c in range(3):
+        nm = off_m[c + 1] - off_m[c]
+        assert off_g[c + 1] - off_g[c] == nm + len(exp[c]), c
+        for key in ("qry_str", "qry_end", "ref_str", "ref_end", "qry_total", "ref_chr", "aln_fwd", "map_qul"):
+            assert np.array_equal(got[key][off_g[c]:off_g[c] + nm], main[key][off_m[c]:off_m[c + 1]]), (c, key)
+        for t, rec in enumerate(exp[c]):
+            g = off_g[c] + nm + t
+            assert (got["qry_str"][g], got["qry_end"][g], got["ref_str"][g], got["ref_end"][g], got["qry_total"][g], got["ref_chr"][g], got["aln_fwd"][g], got["map_qul"][g]) == \
+                   (rec["qs"], rec["qe"], rec["rs"], rec["re"], rec["qtot"], rec["chr"], rec["fwd"], rec["mq"]), (c, t)
+    # the merged file still solves (oracle) and alt rows are labelled xi:Z:A_<row> by the writer
+    from alignasm_amd._abi import BatchOut, Opts
+    view = again.view()
+    out = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(view), C.byref(Opts(64, 0, 0, 0, 0)), 1, C.byref(out)) == 0
+    paths = [str(tmp_path / n) for n in ("m", "a", "l")]
+    again.write_outputs(out, *paths)
+    T.oracle().oracle_free_out(C.byref(out))
+    emitted = open(paths[0]).read() + open(paths[1]).read() + open(paths[2]).read()
+    assert "xi:Z:P_" in emitted
+
+
+def test_empty_alt_is_a_noop(T):
+    api = T.api()
+    paf = api.Paf.synth(2, 10, 3)
+    before = paf.batch().arrays
+    paf.merge_alt(b"", 0.5)
+    after = paf.batch().arrays
+    for k in before:
+        assert np.array_equal(before[k], after[k])
