@@ -462,6 +462,47 @@ void aasm_upload_free(aasm_upload *up) {
     delete up;
 }
 
+// concatenate per-range results (contiguous contig ranges cut[d]..cut[d+1]) in contig order
+static void concat_parts(std::vector<aasm_batch_out> &parts, const std::vector<int64_t> &cut, int64_t C, aasm_batch_out *out) {
+    const int n_devices = (int)parts.size();
+    std::memset(out, 0, sizeof(*out));
+    out->n_contigs = C;
+    int64_t nm = 0, na = 0, np = 0, ne = 0;
+    for (auto &p : parts) { nm += p.main_off[p.n_contigs]; na += p.alt_off[p.n_contigs]; np += p.n_all_paths; ne += p.all_elem_off[p.n_all_paths]; }
+    out->main_off = (int64_t *)calloc(C + 1, 8); out->alt_off = (int64_t *)calloc(C + 1, 8); out->all_path_off = (int64_t *)calloc(C + 1, 8);
+    out->all_elem_off = (int64_t *)calloc(np + 1, 8); out->ctg_status = (int32_t *)calloc(C + 1, 4);
+    out->main_elems = (aasm_out_elem *)calloc(nm + 1, sizeof(aasm_out_elem));
+    out->alt_elems = (aasm_out_elem *)calloc(na + 1, sizeof(aasm_out_elem));
+    out->all_elems = (aasm_out_elem *)calloc(ne + 1, sizeof(aasm_out_elem));
+    out->n_all_paths = np;
+    int64_t bm = 0, ba = 0, bp = 0, be_ = 0;
+    for (int d = 0; d < n_devices; d++) {
+        aasm_batch_out &p = parts[d];
+        const int64_t pc = p.n_contigs, c0 = cut[d];
+        for (int64_t c = 0; c < pc; c++) {
+            out->main_off[c0 + c + 1] = bm + p.main_off[c + 1];
+            out->alt_off[c0 + c + 1] = ba + p.alt_off[c + 1];
+            out->all_path_off[c0 + c + 1] = bp + p.all_path_off[c + 1];
+            out->ctg_status[c0 + c] = p.ctg_status[c];
+        }
+        for (int64_t q = 0; q < p.n_all_paths; q++) out->all_elem_off[bp + q + 1] = be_ + p.all_elem_off[q + 1];
+        std::memcpy(out->main_elems + bm, p.main_elems, sizeof(aasm_out_elem) * (size_t)p.main_off[pc]);
+        std::memcpy(out->alt_elems + ba, p.alt_elems, sizeof(aasm_out_elem) * (size_t)p.alt_off[pc]);
+        std::memcpy(out->all_elems + be_, p.all_elems, sizeof(aasm_out_elem) * (size_t)p.all_elem_off[p.n_all_paths]);
+        bm += p.main_off[pc]; ba += p.alt_off[pc]; bp += p.n_all_paths; be_ += p.all_elem_off[p.n_all_paths];
+        aasm_stats &a = out->stats; const aasm_stats &b = p.stats;
+        a.n_vertices += b.n_vertices; a.n_pairs += b.n_pairs; a.n_edges += b.n_edges; a.n_heap_nodes += b.n_heap_nodes;
+        a.n_paths_found += b.n_paths_found; a.n_paths_converted += b.n_paths_converted; a.n_unconnectable += b.n_unconnectable;
+        a.n_internal_errors += b.n_internal_errors; a.n_single += b.n_single; a.range_steps += b.range_steps;
+        a.ispr_edges += b.ispr_edges; a.ispr_vertices += b.ispr_vertices; a.path_edges += b.path_edges; a.out_elems += b.out_elems; a.pq_pushes += b.pq_pushes;
+        if (b.device_bytes > a.device_bytes) a.device_bytes = b.device_bytes;
+        for (int i = 0; i < AASM_N_PHASES; i++) if (b.phase_ms[i] > a.phase_ms[i]) a.phase_ms[i] = b.phase_ms[i];
+        if (b.total_ms > a.total_ms) a.total_ms = b.total_ms;
+        for (int i = 0; i < 3; i++) if (b.reserved_f[i] > a.reserved_f[i]) a.reserved_f[i] = b.reserved_f[i];
+        aasm_free_out(&p);
+    }
+}
+
 static int validate_batch(const aasm_batch_in *in) {
     if (!in || in->n_contigs <= 0 || !in->ctg_rec_off || in->ctg_rec_off[0] != 0 || in->ctg_rec_off[in->n_contigs] != in->n_records) {
         set_last_error("inconsistent contig offsets");
@@ -472,7 +513,21 @@ static int validate_batch(const aasm_batch_in *in) {
     return AASM_OK;
 }
 
-static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
+static void ctx_release_arena(int device) {
+    DevCtx &cx = g_ctx[device];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    hipSetDevice(device);
+    hipStreamSynchronize(cx.stream);
+    for (auto &b : cx.blocks) hipFree(b.p);
+    cx.blocks.clear();
+    cx.generation++;
+}
+
+static int solve_range_once(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
+    if (const char *lim = std::getenv("AASM_TEST_MAX_CONTIGS")) {      // test hook: pretend larger ranges do not fit
+        const long long n = std::atoll(lim);
+        if (n > 0 && c1 - c0 > n) { set_last_error("range exceeds AASM_TEST_MAX_CONTIGS"); return AASM_E_NOMEM; }
+    }
     aasm_upload *up = nullptr;
     aasm_batch_in dv;
     auto t0 = std::chrono::steady_clock::now();
@@ -494,6 +549,38 @@ static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aa
     aasm_result_free(res);
     aasm_upload_free(up);
     return rc;
+}
+
+static void add_stats(aasm_stats &a, const aasm_stats &b, bool sum_time) {
+    a.n_vertices += b.n_vertices; a.n_pairs += b.n_pairs; a.n_edges += b.n_edges; a.n_heap_nodes += b.n_heap_nodes;
+    a.n_paths_found += b.n_paths_found; a.n_paths_converted += b.n_paths_converted; a.n_unconnectable += b.n_unconnectable;
+    a.n_internal_errors += b.n_internal_errors; a.n_single += b.n_single; a.range_steps += b.range_steps;
+    a.ispr_edges += b.ispr_edges; a.ispr_vertices += b.ispr_vertices; a.path_edges += b.path_edges; a.out_elems += b.out_elems; a.pq_pushes += b.pq_pushes;
+    if (b.device_bytes > a.device_bytes) a.device_bytes = b.device_bytes;
+    for (int i = 0; i < AASM_N_PHASES; i++) a.phase_ms[i] = sum_time ? a.phase_ms[i] + b.phase_ms[i] : (b.phase_ms[i] > a.phase_ms[i] ? b.phase_ms[i] : a.phase_ms[i]);
+    a.total_ms = sum_time ? a.total_ms + b.total_ms : (b.total_ms > a.total_ms ? b.total_ms : a.total_ms);
+    for (int i = 0; i < 3; i++) a.reserved_f[i] = sum_time ? a.reserved_f[i] + b.reserved_f[i] : (b.reserved_f[i] > a.reserved_f[i] ? b.reserved_f[i] : a.reserved_f[i]);
+}
+
+// A contig range that does not fit in device memory is split in halves (contigs are
+// independent) after the arena of the failed attempt has been given back.
+static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
+    int rc = solve_range_once(in, c0, c1, o, out);
+    if (rc != AASM_E_NOMEM || c1 - c0 < 2) return rc;
+    ctx_release_arena(o.device);
+    const int64_t mid = c0 + (c1 - c0) / 2;
+    std::vector<aasm_batch_out> parts(2);
+    std::memset(&parts[0], 0, sizeof(aasm_batch_out)); std::memset(&parts[1], 0, sizeof(aasm_batch_out));
+    rc = solve_range(in, c0, mid, o, &parts[0]);
+    if (rc == AASM_OK) rc = solve_range(in, mid, c1, o, &parts[1]);
+    if (rc != AASM_OK) { aasm_free_out(&parts[0]); aasm_free_out(&parts[1]); return rc; }
+    std::vector<int64_t> cut{0, mid - c0, c1 - c0};
+    aasm_stats st;
+    std::memset(&st, 0, sizeof(st));
+    add_stats(st, parts[0].stats, true); add_stats(st, parts[1].stats, true);
+    concat_parts(parts, cut, c1 - c0, out);
+    out->stats = st;
+    return AASM_OK;
 }
 
 int aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
@@ -553,43 +640,7 @@ int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n
             for (auto &p : parts) aasm_free_out(&p);
             return rcs[d];
         }
-    // concatenate
-    std::memset(out, 0, sizeof(*out));
-    out->n_contigs = C;
-    int64_t nm = 0, na = 0, np = 0, ne = 0;
-    for (auto &p : parts) { nm += p.main_off[p.n_contigs]; na += p.alt_off[p.n_contigs]; np += p.n_all_paths; ne += p.all_elem_off[p.n_all_paths]; }
-    out->main_off = (int64_t *)calloc(C + 1, 8); out->alt_off = (int64_t *)calloc(C + 1, 8); out->all_path_off = (int64_t *)calloc(C + 1, 8);
-    out->all_elem_off = (int64_t *)calloc(np + 1, 8); out->ctg_status = (int32_t *)calloc(C + 1, 4);
-    out->main_elems = (aasm_out_elem *)calloc(nm + 1, sizeof(aasm_out_elem));
-    out->alt_elems = (aasm_out_elem *)calloc(na + 1, sizeof(aasm_out_elem));
-    out->all_elems = (aasm_out_elem *)calloc(ne + 1, sizeof(aasm_out_elem));
-    out->n_all_paths = np;
-    int64_t bm = 0, ba = 0, bp = 0, be_ = 0;
-    for (int d = 0; d < n_devices; d++) {
-        aasm_batch_out &p = parts[d];
-        const int64_t pc = p.n_contigs, c0 = cut[d];
-        for (int64_t c = 0; c < pc; c++) {
-            out->main_off[c0 + c + 1] = bm + p.main_off[c + 1];
-            out->alt_off[c0 + c + 1] = ba + p.alt_off[c + 1];
-            out->all_path_off[c0 + c + 1] = bp + p.all_path_off[c + 1];
-            out->ctg_status[c0 + c] = p.ctg_status[c];
-        }
-        for (int64_t q = 0; q < p.n_all_paths; q++) out->all_elem_off[bp + q + 1] = be_ + p.all_elem_off[q + 1];
-        std::memcpy(out->main_elems + bm, p.main_elems, sizeof(aasm_out_elem) * (size_t)p.main_off[pc]);
-        std::memcpy(out->alt_elems + ba, p.alt_elems, sizeof(aasm_out_elem) * (size_t)p.alt_off[pc]);
-        std::memcpy(out->all_elems + be_, p.all_elems, sizeof(aasm_out_elem) * (size_t)p.all_elem_off[p.n_all_paths]);
-        bm += p.main_off[pc]; ba += p.alt_off[pc]; bp += p.n_all_paths; be_ += p.all_elem_off[p.n_all_paths];
-        aasm_stats &a = out->stats; const aasm_stats &b = p.stats;
-        a.n_vertices += b.n_vertices; a.n_pairs += b.n_pairs; a.n_edges += b.n_edges; a.n_heap_nodes += b.n_heap_nodes;
-        a.n_paths_found += b.n_paths_found; a.n_paths_converted += b.n_paths_converted; a.n_unconnectable += b.n_unconnectable;
-        a.n_internal_errors += b.n_internal_errors; a.n_single += b.n_single; a.range_steps += b.range_steps;
-        a.ispr_edges += b.ispr_edges; a.ispr_vertices += b.ispr_vertices; a.path_edges += b.path_edges; a.out_elems += b.out_elems; a.pq_pushes += b.pq_pushes;
-        if (b.device_bytes > a.device_bytes) a.device_bytes = b.device_bytes;
-        for (int i = 0; i < AASM_N_PHASES; i++) if (b.phase_ms[i] > a.phase_ms[i]) a.phase_ms[i] = b.phase_ms[i];
-        if (b.total_ms > a.total_ms) a.total_ms = b.total_ms;
-        for (int i = 0; i < 3; i++) if (b.reserved_f[i] > a.reserved_f[i]) a.reserved_f[i] = b.reserved_f[i];
-        aasm_free_out(&p);
-    }
+    concat_parts(parts, cut, C, out);
     return AASM_OK;
 }
 

@@ -58,3 +58,18 @@ def test_repeat_solve_is_deterministic(T):
         outs.append(r.fetch()); r.close()
     db.close()
     assert T.diff_outputs(outs[0], outs[1]) == [] and T.diff_outputs(outs[0], outs[2]) == []
+
+
+def test_out_of_memory_ranges_are_split_and_concatenated(T, monkeypatch):
+    """A contig range that does not fit is halved recursively (contigs are independent); the
+    concatenated result must equal the unsplit one.  AASM_TEST_MAX_CONTIGS simulates the
+    hipMalloc failure."""
+    api = T.api()
+    hb = T.synth(23, 70, 41, heavy_tail=True, dup_every=6)
+    whole = api.solve_batch(hb, max_paths=32)
+    monkeypatch.setenv("AASM_TEST_MAX_CONTIGS", "4")
+    split = api.solve_batch(hb, max_paths=32)
+    monkeypatch.delenv("AASM_TEST_MAX_CONTIGS")
+    assert T.diff_outputs(whole, split, stats=False) == []
+    for k in ("n_vertices", "n_edges", "n_heap_nodes", "n_paths_found", "n_pairs"):
+        assert whole["stats"][k] == split["stats"][k], k
