@@ -19,6 +19,8 @@ CASES = [
     (5, 1, 3, 10000, False, 0, False, False, False),
     (5, 2, 3, 10000, False, 0, False, False, False),
     (8, 40, 13, 10000, True, 1, True, False, False),
+    (2, 20000, 77, 16, False, 0, False, False, False),      # giant contigs (row f4): one wave still walks each
+    (2, 6000, 77, 16, True, 0, False, False, False),
 ]
 
 
