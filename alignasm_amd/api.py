@@ -61,8 +61,10 @@ def device_count():
     return int(LIB.aasm_device_count())
 
 
-def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False):
-    return Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
+def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False):
+    o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
+    o.reserved[0] = 1 if sequential_select else 0      # bit 0: force the one-wave-per-contig selection kernel
+    return o
 
 
 class Paf:
@@ -141,14 +143,14 @@ def free_out(out: BatchOut):
     LIB.aasm_free_out(C.byref(out))
 
 
-def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1):
+def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False):
     """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
     view = batch.view if isinstance(batch, HostBatch) else batch.view()
     if n_devices > 1:
         out = BatchOut()
-        _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(make_opts(max_paths, non_skip_linkable, device, timing)), int(n_devices), C.byref(out)))
+        _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select)), int(n_devices), C.byref(out)))
     else:
-        out = solve_batch_raw(view, make_opts(max_paths, non_skip_linkable, device, timing))
+        out = solve_batch_raw(view, make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select))
     try:
         return unpack_out(out)
     finally:

@@ -43,6 +43,7 @@ template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return f
 AASM_DEV void block_sync() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
+AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
 AASM_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __builtin_ffsll((long long)m); }
 #else
@@ -68,6 +69,7 @@ template <class T> AASM_DEV T atomic_add(T *p, T v) { return atomicAdd(p, v); }
 AASM_DEV unsigned long long atomic_add(int64_t *p, int64_t v) {
     return atomicAdd((unsigned long long *)p, (unsigned long long)v);
 }
+AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { return atomicMin(p, v); }
 AASM_DEV int popc64(uint64_t m) { return __popcll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __ffsll((long long)m); }
 #endif

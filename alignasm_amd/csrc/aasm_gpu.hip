@@ -31,9 +31,9 @@ namespace aasm {
     }
 // kernels whose wave keeps a working set in LDS (AASM_LDS_BYTES per 64-thread block);
 // launch bound 5 waves/SIMD (<= 96 VGPRs) so that 20 contigs are resident per CU
-#define AASM_DEF_KERNEL_LDS(name, KN, TPB)                                                    \
+#define AASM_DEF_KERNEL_LDS(name, KN, TPB, BYTES)                                             \
     __global__ void __launch_bounds__(TPB, 5) name(WS w) {                                    \
-        __shared__ __attribute__((aligned(16))) char smem[AASM_LDS_BYTES];                    \
+        __shared__ __attribute__((aligned(16))) char smem[BYTES];                             \
         KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
                (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
@@ -57,9 +57,15 @@ AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
-AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64)
+AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_LDS_BYTES)
 AASM_DEF_KERNEL(aasm_k8_enum, KN_ENUM, 64)
-AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64)
+AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES)
+AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 256)
+AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 256)
+AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES)
+AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
+AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
+AASM_DEF_KERNEL(aasm_k9_topo_fill, KN_TOPO_FILL, 64)
 AASM_DEF_KERNEL(aasm_k9_gather_out, KN_GATHER_OUT, 64)
 
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
@@ -196,6 +202,7 @@ struct GpuBackend {
     }
     bool failed() const { return fail; }
     void zero(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void fill_byte(void *p, int v, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, v, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
     void fill_ff(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
         if (fail || nblocks <= 0) return;
@@ -209,7 +216,8 @@ struct GpuBackend {
             L(KN_SORT_ROWS_REV, aasm_k6_sort_rows_rev) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep)
             L(KN_CHILD_COUNT, aasm_k7_child_count) L(KN_CHILD_FILL, aasm_k7_child_fill) L(KN_SORT_ROWS_CHILD, aasm_k7_sort_rows_child)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_HEAP, aasm_k7_heap) L(KN_ENUM, aasm_k8_enum) L(KN_SELECT, aasm_k9_select)
-            L(KN_GATHER_OUT, aasm_k9_gather_out)
+            L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
+            L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L
             default: break;
         }

@@ -49,6 +49,10 @@ struct WS {
     // ---- sweeps
     Dist *sp_d;
     int32_t *sp_best, *rev_order, *cnt_tmp, *fwd_order, *fwd_pos, *an, *anom_dest, *cnt_tmp2;
+    // ---- CSR copy in forward-topological order (positions contiguous; heads as positions)
+    int32_t *tp_deg, *tp_vj, *te_tgt, *te_wr;
+    int64_t *tp_ptr, *te_wq;
+    uint8_t *te_fl;
     // ---- SP-tree children CSR
     int32_t *ccnt, *ccur, *cval;
     int64_t *cptr;
@@ -65,6 +69,13 @@ struct WS {
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;    // (u,v) pairs, 2*(N+2) ints per contig
     Dist *dist2;
     uint8_t *notalt;
+    int32_t *mark_time;                               // per sorted record: first conversion ordinal that marked it
+    // ---- parallel conversions (one wave per converted path)
+    int32_t *nconv, *cv_ctg, *cv_k, *cv_ord, *cv_kind, *cv_szr, *cv_szv, *cv_n, *cv_err, *cv_path, *cv_pre2, *cv_stamp;
+    int64_t *conv_off, *cv_roff, *cv_voff, *cv_cov;
+    OutElem *cv_out;
+    Dist *cv_dist2;
+    int64_t NCONV;
     OutElem *cur_out, *main_out, *alt_out, *pool;
     int32_t *main_len, *alt_len, *all_gen, *all_seq;
     int32_t *ar_ctg, *ar_gen, *ar_seq, *ar_len;      // .all path records
@@ -824,6 +835,49 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
 }
 
 // ====================================================================================
+// CSR copy in forward-topological order, used by internal_shortest_path_recover (K9):
+// its windows are runs of consecutive topological positions, so with this layout a window's
+// vertices AND all their edges are two contiguous, coalesced reads, and edge heads are stored
+// as topological positions (what the DP needs) instead of vertex ids.
+// ====================================================================================
+AASM_DEV void kb_topo_count(const KCtx &k, const WS &w) {           // thread per (contig, position)
+    const int64_t gp = k.bid * k.nthreads + k.tid;
+    if (gp >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gp]];
+    const int32_t u = w.fwd_order[gp];
+    w.tp_deg[gp] = (int32_t)(w.rowptr[vb + u + 1] - w.rowptr[vb + u]);
+    w.tp_vj[gp] = w.v_j[vb + u];                                     // src / dest carry -1 / -2: never a whitelist match
+}
+AASM_DEV void kb_topo_fill(const KCtx &k, const WS &w) {            // wave per 64 positions
+    const int64_t gp = k.bid * AASM_WAVE + k.lane;
+    const bool act = gp < w.VT;
+    int64_t vb = 0, r0 = 0, t0 = 0;
+    int32_t deg = 0;
+    if (act) {
+        vb = w.voff[w.v_ctg[gp]];
+        const int32_t u = w.fwd_order[gp];
+        r0 = w.rowptr[vb + u]; deg = w.tp_deg[gp]; t0 = w.tp_ptr[gp];
+    }
+    const bool big = deg > AASM_LONG_ROW;
+    if (act && !big)
+        for (int32_t t = 0; t < deg; t++) {
+            w.te_tgt[t0 + t] = w.fwd_pos[vb + w.e_col[r0 + t]];
+            w.te_wq[t0 + t] = w.e_wq[r0 + t]; w.te_wr[t0 + t] = w.e_wr[r0 + t]; w.te_fl[t0 + t] = w.e_fl[r0 + t];
+        }
+    uint64_t bigmask = wave_ballot(big);
+    while (bigmask) {
+        const int src = ffs64(bigmask) - 1;
+        bigmask &= bigmask - 1;
+        const int64_t vb2 = wave_bcast(vb, src), r02 = wave_bcast(r0, src), t02 = wave_bcast(t0, src);
+        const int32_t deg2 = wave_bcast(deg, src);
+        for (int32_t t = k.lane; t < deg2; t += AASM_WAVE) {
+            w.te_tgt[t02 + t] = w.fwd_pos[vb2 + w.e_col[r02 + t]];
+            w.te_wq[t02 + t] = w.e_wq[r02 + t]; w.te_wr[t02 + t] = w.e_wr[r02 + t]; w.te_fl[t02 + t] = w.e_fl[r02 + t];
+        }
+    }
+}
+
+// ====================================================================================
 // K7  sidetrack heaps (k_shortest_walks.hpp:191-215; leftist_heap.hpp:29-40)
 // ====================================================================================
 AASM_DEV void kb_child_count(const KCtx &k, const WS &w) {          // thread per vertex
@@ -1149,12 +1203,76 @@ struct SelCtx {
     int32_t src, dest;
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
     Dist *dist2;
+    OutElem *cur;                    // where sel_convert leaves its elements
     int32_t epoch, last_head;
-    bool err;
+    int32_t *out_dst;
+    int32_t out_n, out_flushed, pa_base;
+    bool err, res_lds;
     int lane;
     char *lds;
     int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    int64_t kp_t0, kp_acc[8];
+#endif
 };
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+#define SPROF(s, i) do { __builtin_amdgcn_s_waitcnt(0); const int64_t t1_ = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); (s).kp_acc[i] += t1_ - (s).kp_t0; (s).kp_t0 = t1_; } while (0)
+#else
+#define SPROF(s, i) do {} while (0)
+#endif
+
+// ---- LDS working set of kb_select ----------------------------------------------------
+// vmcnt is in-order over loads and stores, so a global store directly ahead of a dependent
+// global load costs a full store round trip.  The selection therefore keeps its small
+// intermediate lists in LDS: the ISPR window + result, a 64-edge read window over the
+// recovered path and a 64-edge write buffer that is flushed by one coalesced store.
+#define ISPR_MAX_E 192
+#define SEL_WIN 64
+struct SelLds {
+    int64_t wq[ISPR_MAX_E];
+    int32_t wr[ISPR_MAX_E];
+    int8_t tgt[ISPR_MAX_E];
+    uint8_t fl[ISPR_MAX_E];
+    Dist dist[64];
+    int32_t excl[64], u[64], vj[64];
+    int8_t pre[64];
+    uint8_t reach[64];
+    int32_t res[2 * 64];           // ISPR result edges (u, v), reverse order
+    int32_t pa_win[2 * SEL_WIN];   // read window over pathA
+    int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
+};
+#define AASM_SEL_LDS_BYTES 7168
+static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
+
+AASM_DEV void sel_out_flush(SelCtx &s) {
+    SelLds *L = (SelLds *)s.lds;
+    block_sync();
+    const int32_t n = s.out_n - s.out_flushed;
+    for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) s.out_dst[2 * s.out_flushed + t] = L->pb_buf[t];
+    s.out_flushed = s.out_n;
+    block_sync();
+}
+AASM_DEV void sel_out_begin(SelCtx &s, int32_t *dst) { s.out_dst = dst; s.out_n = 0; s.out_flushed = 0; }
+AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
+    SelLds *L = (SelLds *)s.lds;
+    if (s.out_n >= s.cap) { s.err = true; return; }
+    const int32_t slot = s.out_n - s.out_flushed;
+    if (s.lane == 0) { L->pb_buf[2 * slot] = u; L->pb_buf[2 * slot + 1] = v; }
+    s.out_n++;
+    s.last_head = v;
+    if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
+}
+AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v) {
+    SelLds *L = (SelLds *)s.lds;
+    if (it < s.pa_base || it >= s.pa_base + SEL_WIN) {
+        block_sync();
+        s.pa_base = it;
+        const int32_t n = (la - it < SEL_WIN) ? (la - it) : SEL_WIN;
+        for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) L->pa_win[t] = s.pathA[2 * it + t];
+        block_sync();
+    }
+    u = uni(L->pa_win[2 * (it - s.pa_base)]); v = uni(L->pa_win[2 * (it - s.pa_base) + 1]);
+}
 
 // k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
 AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
@@ -1174,57 +1292,48 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
         cur = kprev[cur];
     }
     wave_fence();
-    int32_t idx = ns - 1, la = 0, cv = s.src;
+    sel_out_begin(s, s.pathA);
+    int32_t idx = ns - 1, cv = s.src;
+    int32_t st_u = -1, st_v = -1;                                   // next sidetrack (tail, head)
+    if (idx >= 0) { st_u = uni(s.pathT[2 * idx]); st_v = uni(s.pathT[2 * idx + 1]); }
     while (cv != s.dest || idx >= 0) {
-        if (la >= s.cap) { s.err = true; return -1; }
-        if (idx >= 0 && cv == s.pathT[2 * idx]) {
-            const int32_t hv = s.pathT[2 * idx + 1];
-            if (s.lane == 0) { s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = hv; }
-            la++;
-            cv = hv; idx--;
+        if (s.err) return -1;
+        if (idx >= 0 && cv == st_u) {
+            sel_push(s, cv, st_v);
+            cv = st_v; idx--;
+            if (idx >= 0) { st_u = uni(s.pathT[2 * idx]); st_v = uni(s.pathT[2 * idx + 1]); }
         } else {
-            const int32_t nx = best[cv];
+            const int32_t nx = uni(best[cv]);
             if (nx < 0) { s.err = true; return -1; }
-            if (s.lane == 0) { s.pathA[2 * la] = cv; s.pathA[2 * la + 1] = nx; }
-            la++;
+            sel_push(s, cv, nx);
             cv = nx;
         }
     }
-    return la;
+    if (s.err) return -1;
+    sel_out_flush(s);
+    return s.out_n;
 }
 
 // internal_shortest_path_recover (paf_data.cpp:750-792): QRY_SCORE-mode DAG DP over the
-// forward topological window [order[a], order[b)).  Result edges are left in pathT in
-// REVERSE order; returns their count, 0 when a == b, -1 on "must not happen".
+// forward topological window [order[a], order[b)).  The result edges are left in REVERSE
+// order in LDS (res_lds) or in pathT; returns their count, 0 when a == b, -1 on "must not
+// happen".
 //
 // Targets beyond position order[b] are never expanded and never lie on the returned path,
 // so relaxing them (as the reference's hash map does) is unobservable and is skipped.
 // Two forms:
-//  * window of <= 63 vertices and <= ISPR_MAX_E edges (the common case): the window is
-//    staged in LDS by the whole wave in four parallel load rounds (order -> rowptr -> edges ->
-//    position of heads), then the DP runs on LDS state, lanes sharing one source's edges;
+//  * window of <= 63 vertices and <= ISPR_MAX_E edges (the common case): staged in LDS from
+//    the topologically ordered CSR copy by two coalesced load rounds, then the DP runs on
+//    LDS state, lanes sharing one source's edges;
 //  * otherwise: same DP on epoch-stamped global arrays, lanes sharing one source's edges.
 // Inside a row targets are distinct, so the lane-parallel relaxation is conflict-free and
 // the sequential source order keeps the reference's strict-`<` first-wins behaviour.
-#define ISPR_MAX_E 192
-struct IsprLds {
-    int64_t wq[ISPR_MAX_E];
-    int32_t wr[ISPR_MAX_E];
-    int8_t tgt[ISPR_MAX_E];
-    uint8_t fl[ISPR_MAX_E];
-    Dist dist[64];
-    int64_t r0[64];
-    int32_t excl[64], u[64];
-    int8_t pre[64];
-    uint8_t reach[64];
-};
-static_assert(sizeof(IsprLds) <= AASM_LDS_BYTES, "LDS budget");
-
 AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
     const WS &w = *s.w;
     const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
     const int32_t ep = ++s.epoch;
     const int32_t pb = pos[bd];
+    s.res_lds = false;
     if (s.lane == 0) { s.dist2[a] = dist_zero(); s.pre2[a] = -1; s.stamp[a] = ep; }
     wave_fence();
     for (int32_t i = pos[a]; i < pb; i++) {
@@ -1259,130 +1368,117 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
 AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
     const WS &w = *s.w;
     if (a == bd) return 0;
-    const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
-    const int32_t pa = pos[a], pb = pos[bd];
+    const int32_t *pos = w.fwd_pos + s.vb;
+    const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
     const int32_t W = pb - pa;
     if (W <= 0) { s.err = true; return -1; }
     if (W > 63) return sel_ispr_generic(s, a, bd, wl_flag, wl);
-    IsprLds *L = (IsprLds *)s.lds;
-    // round 1+2: window vertices and their rows, one lane per vertex
-    int32_t u_t = 0, deg = 0, T = 0;
-#if defined(AASM_HOST_EMUL)
-    {   // one lane: plain prefix loop
-        int32_t run = 0;
-        for (int32_t t = 0; t < W; t++) {
-            const int32_t uu = order[pa + t];
-            const int64_t r0 = w.rowptr[s.vb + uu];
-            L->u[t] = uu; L->r0[t] = r0; L->excl[t] = run;
-            run += (int32_t)(w.rowptr[s.vb + uu + 1] - r0);
-        }
-        T = run; (void)u_t; (void)deg;
-    }
-#else
-    {
-        int64_t r0 = 0;
-        if (s.lane < W) { u_t = order[pa + s.lane]; r0 = w.rowptr[s.vb + u_t]; deg = (int32_t)(w.rowptr[s.vb + u_t + 1] - r0); }
-        const int incl = wave_incl_add(deg);
-        T = wave_bcast(incl, AASM_WAVE - 1);
-        if (s.lane < W) { L->u[s.lane] = u_t; L->r0[s.lane] = r0; L->excl[s.lane] = incl - deg; }
-    }
-#endif
+    SPROF(s, 5);
+    SelLds *L = (SelLds *)s.lds;
+    // round 1: the window's vertices (consecutive topological positions)
+    const int64_t e_start = uni(w.tp_ptr[s.vb + pa]);
+    const int32_t T = (int32_t)(uni(w.tp_ptr[s.vb + pb]) - e_start);
     if (T > ISPR_MAX_E) return sel_ispr_generic(s, a, bd, wl_flag, wl);
-    block_sync();
-    // round 3+4: every window edge, one lane per edge (source found by binary search in LDS)
-    for (int32_t idx = s.lane; idx < T; idx += AASM_WAVE) {
-        int lo = 0, hi = W - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L->excl[mid] <= idx) lo = mid; else hi = mid - 1; }
-        const int32_t su = L->u[lo];
-        const int64_t e = L->r0[lo] + (idx - L->excl[lo]);
-        const int32_t v = w.e_col[e];
-        int32_t rel = pos[v] - pa;
-        if (rel > W) rel = -1;
-        if (rel >= 0 && wl_flag && v == bd) {                        // :767-773
-            if (su == s.src || su == s.dest || w.v_j[s.vb + su] != wl) rel = -1;
-        }
-        L->tgt[idx] = (int8_t)rel; L->wq[idx] = w.e_wq[e]; L->wr[idx] = w.e_wr[e]; L->fl[idx] = w.e_fl[e];
+    for (int32_t t = s.lane; t < W; t += AASM_WAVE) {
+        L->excl[t] = (int32_t)(w.tp_ptr[s.vb + pa + t] - e_start);
+        L->u[t] = w.fwd_order[s.vb + pa + t];
+        L->vj[t] = w.tp_vj[s.vb + pa + t];
     }
+    // round 2: all their edges, one contiguous run of the topologically ordered copy
+    for (int32_t idx = s.lane; idx < T; idx += AASM_WAVE) {
+        int32_t rel = w.te_tgt[e_start + idx] - pa;
+        if (rel > W) rel = -1;
+        L->tgt[idx] = (int8_t)rel; L->wq[idx] = w.te_wq[e_start + idx]; L->wr[idx] = w.te_wr[e_start + idx]; L->fl[idx] = w.te_fl[e_start + idx];
+    }
+    SPROF(s, 2);                                                     // ISPR staging
     for (int32_t t = s.lane; t <= W; t += AASM_WAVE) L->reach[t] = (t == 0) ? 1 : 0;
     if (s.lane == 0) { L->dist[0] = dist_zero(); L->pre[0] = -1; }
     block_sync();
     // DP over the window, source by source
     for (int32_t t = 0; t < W; t++) {
-        if (!L->reach[t]) continue;
+        if (!uni((int32_t)L->reach[t])) continue;
         const Dist cd = L->dist[t];
-        const int32_t e0 = L->excl[t], e1 = (t + 1 < W) ? L->excl[t + 1] : T;
+        const int32_t e0 = uni(L->excl[t]), e1 = (t + 1 < W) ? uni(L->excl[t + 1]) : T;
         s.n_ispr_v++; s.n_ispr_e += e1 - e0;
+        const bool to_dest_ok = !wl_flag || (uni(L->vj[t]) == wl);   // :767-773 (src / dest have vj < 0)
         for (int32_t idx = e0 + s.lane; idx < e1; idx += AASM_WAVE) {
             const int32_t tg = L->tgt[idx];
-            if (tg < 0) continue;
+            if (tg < 0 || (tg == W && !to_dest_ok)) continue;
             const Dist nd = dist_add(cd, edge_dist(L->wq[idx], L->wr[idx], L->fl[idx]));
             if (!L->reach[tg] || dist_lt<QRY_SCORE_MODE>(nd, L->dist[tg])) { L->dist[tg] = nd; L->pre[tg] = (int8_t)t; L->reach[tg] = 1; }
         }
         block_sync();
     }
-    if (!L->reach[W]) { s.err = true; return -1; }                   // :783
+    SPROF(s, 3);                                                     // ISPR DP on LDS
+    if (!uni((int32_t)L->reach[W])) { s.err = true; return -1; }     // :783
     int32_t n = 0, last = W;
     while (last != 0) {
-        if (n >= s.cap) { s.err = true; return -1; }
-        const int32_t pv = L->pre[last];
-        if (s.lane == 0) { s.pathT[2 * n] = L->u[pv]; s.pathT[2 * n + 1] = (last == W) ? bd : L->u[last]; }
+        if (n >= 64) { s.err = true; return -1; }
+        const int32_t pv = uni((int32_t)L->pre[last]);
+        if (s.lane == 0) { L->res[2 * n] = L->u[pv]; L->res[2 * n + 1] = (last == W) ? bd : L->u[last]; }
         n++;
         last = pv;
     }
-    wave_fence();
+    s.res_lds = true;
+    block_sync();
+    SPROF(s, 4);                                                     // ISPR backtrack
     return n;
 }
-AASM_DEV void sel_push(SelCtx &s, int32_t &lb, int32_t u, int32_t v) {
-    if (lb >= s.cap) { s.err = true; return; }
-    if (s.lane == 0) { s.pathB[2 * lb] = u; s.pathB[2 * lb + 1] = v; }
-    lb++;
-    s.last_head = v;
-}
-// append the ISPR result (reverse order in pathT), optionally without its last edge
-AASM_DEV void sel_append_alt(SelCtx &s, int32_t &lb, int32_t n, bool drop_last) {
-    for (int32_t t = n - 1; t >= (drop_last ? 1 : 0); t--) sel_push(s, lb, s.pathT[2 * t], s.pathT[2 * t + 1]);
+// append the ISPR result (reverse order), optionally without its last edge
+AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last) {
+    SelLds *L = (SelLds *)s.lds;
+    for (int32_t t = n - 1; t >= (drop_last ? 1 : 0); t--) {
+        int32_t u, v;
+        if (s.res_lds) { u = uni(L->res[2 * t]); v = uni(L->res[2 * t + 1]); }
+        else { u = uni(s.pathT[2 * t]); v = uni(s.pathT[2 * t + 1]); }
+        sel_push(s, u, v);
+    }
 }
 
 // upgrade_edge_path_with_alt_path (paf_data.cpp:795-921): pathA[la] -> pathB; returns lb
 AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
     const WS &w = *s.w;
-    int32_t lb = 0;
+    sel_out_begin(s, s.pathB);
+    s.pa_base = -SEL_WIN - 1;
     for (int32_t it = 0; it < la && !s.err; ++it) {
-        const int32_t u = s.pathA[2 * it], v = s.pathA[2 * it + 1];
+        int32_t u, v;
+        sel_pa_get(s, it, la, u, v);
         const bool from_src = (u == s.src);
         if (from_src || v != s.dest) {
             int32_t start;
             if (from_src) start = u;                                 // :804
             else {
-                if (lb == 0) { s.err = true; break; }
+                if (s.out_n == 0) { s.err = true; break; }
                 start = s.last_head;                                 // continuation_src (:863)
-                if (w.v_i[s.vb + v] != w.v_j[s.vb + v]) { sel_push(s, lb, u, v); continue; }   // :866-873
+                if (w.v_i[s.vb + v] != w.v_j[s.vb + v]) { sel_push(s, u, v); continue; }   // :866-873
             }
-            const int32_t y = w.v_j[s.vb + v];
+            const int32_t y = uni(w.v_j[s.vb + v]);
             if (it + 1 >= la) { s.err = true; break; }
-            const int32_t nv = s.pathA[2 * (it + 1) + 1];
+            int32_t nu, nv;
+            sel_pa_get(s, it + 1, la, nu, nv);
             const bool nv_single = (nv == s.dest) || (w.v_i[s.vb + nv] == w.v_j[s.vb + nv]);
             if (nv_single) {                                         // :812-833 / :879-899
                 const int32_t n = sel_ispr(s, start, nv, true, y);
                 if (n < 0) break;
-                if (n == 0) sel_push(s, lb, u, v);
-                else sel_append_alt(s, lb, n, true);
+                if (n == 0) sel_push(s, u, v);
+                else sel_append_alt(s, n, true);
             } else {                                                 // :834-843 / :900-909
                 const int32_t n = sel_ispr(s, start, nv, false, -1);
                 if (n < 0) break;
-                if (n == 0) { sel_push(s, lb, u, v); sel_push(s, lb, s.pathA[2 * (it + 1)], nv); }
-                else sel_append_alt(s, lb, n, false);
+                if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                else sel_append_alt(s, n, false);
                 ++it;
             }
         } else {                                                     // v == dest (:845-858)
-            if (lb == 0) { s.err = true; break; }
+            if (s.out_n == 0) { s.err = true; break; }
             const int32_t start = s.last_head;
             const int32_t n = sel_ispr(s, start, v, false, -1);
             if (n < 0) break;
-            if (n > 0) sel_append_alt(s, lb, n, false);
+            if (n > 0) sel_append_alt(s, n, false);
         }
     }
-    return lb;
+    sel_out_flush(s);
+    return s.out_n;
 }
 
 AASM_DEV OutElem out_from_rec(const WS &w, int64_t g) {             // PafOutputData(rec), paf_data.hpp:101-104
@@ -1391,21 +1487,29 @@ AASM_DEV OutElem out_from_rec(const WS &w, int64_t g) {             // PafOutput
 }
 
 // edge_path_to_paf_path (paf_data.cpp:1489-1568): path k -> cur_out; returns #elements, coverage in cov
-AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
+// The tp flag (:1560-1566) depends on every path converted BEFORE this one (hazard B5):
+// mark_time[r] = smallest conversion ordinal whose un-upgraded path touched record r, and an
+// element of conversion `ord` is_alt iff mark_time[r] > ord.  sel_convert leaves the SORTED
+// record index in is_alt; copy_resolved() turns it into the flag.
+AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int32_t ord, int64_t &cov) {
     const WS &w = *s.w;
-    OutElem *out = w.cur_out + s.b;
-    uint8_t *notalt = w.notalt + s.b;
+    OutElem *out = s.cur;
+    int32_t *mark = w.mark_time + s.b;
     cov = 0;
+    SPROF(s, 7);
     const int32_t la = sel_recover(s, kidx);
     if (la <= 0) { s.err = true; return 0; }
     wave_fence();
+    SPROF(s, 0);                                                     // recover
     for (int32_t t = s.lane; t < la; t += AASM_WAVE) {               // :1490-1496
         const int32_t v = s.pathA[2 * t + 1];
-        if (v != s.dest) { notalt[w.v_i[s.vb + v]] = 1; notalt[w.v_j[s.vb + v]] = 1; }
+        if (v != s.dest) { atomic_min_i32(&mark[w.v_i[s.vb + v]], ord); atomic_min_i32(&mark[w.v_j[s.vb + v]], ord); }
     }
     wave_fence();
+    SPROF(s, 1);                                                     // marking
     const int32_t lb = sel_upgrade(s, la);                           // :1500-1501
     wave_fence();
+    SPROF(s, 5);                                                     // upgrade: control + appends (ISPR parts stamped inside)
     if (s.err) return 0;
     s.n_path_e += la + lb;
     // :1503-1557 as a map over path edges: edge t = (u, v) emits record cur(v) (nothing for
@@ -1422,7 +1526,7 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
         if (v == s.dest) { bad = true; continue; }
         const int32_t y1 = w.v_i[s.vb + v], y2 = w.v_j[s.vb + v];
         OutElem o = out_from_rec(w, s.b + y2);
-        o.is_alt = notalt[y2] ? 0 : 1;                               // :1560-1566 (the map only grows at :1490-1496)
+        o.is_alt = y2;                                               // resolved by copy_resolved()
         if (y1 != y2) { const int64_t sl = w.v_slot[s.vb + v]; o.qs = w.ov_stq[sl]; o.rs = w.ov_str[sl]; }
         if (nv != s.dest && w.v_i[s.vb + nv] != w.v_j[s.vb + nv]) { const int64_t sl = w.v_slot[s.vb + nv]; o.qe = w.ov_peq[sl]; o.re = w.ov_per[sl]; }
         out[t] = o;
@@ -1430,9 +1534,151 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int64_t &cov) {
     }
     if (wave_ballot(bad)) { s.err = true; return 0; }
     cov = wave_sum(part);
+    SPROF(s, 6);                                                     // conversion
     if (s.lane == 0) atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
     s.n_out_e += n;
     return n;
+}
+
+AASM_DEV void copy_resolved(OutElem *dst, const OutElem *src, int32_t n, const int32_t *mark, int32_t ord, int lane) {
+    for (int32_t t = lane; t < n; t += AASM_WAVE) { OutElem o = src[t]; o.is_alt = (mark[o.is_alt] > ord) ? 1 : 0; dst[t] = o; }
+}
+AASM_DEV bool dist_sel_equal(const Dist &a, const Dist &b) { return a.qry + a.ref == b.qry + b.ref && a.anom == b.anom; }   // :1581-1583
+
+// ---- K9 as plan -> convert -> final ----------------------------------------------------
+// WHICH paths get converted, and in what order, is a pure function of the K distances
+// (paf_data.cpp:1596-1649: tie run, then alt candidates), so the expensive conversions
+// (recover + upgrade + clip) run as independent waves and the per-contig tail of the
+// sequential form disappears.  kinds: 0 main, 1 tie, 2 alt (new best ratio), 3 alt (equal).
+template <class F> AASM_DEV int32_t sel_plan_walk(const WS &w, int64_t c, F emit) {
+    const int32_t found = w.kfound[c];
+    const Dist *kd = w.kd + c * (int64_t)w.K;
+    const Dist mind = kd[0];
+    int32_t n = 0;
+    emit(n++, 0, 0);
+    for (int32_t idx = 1; idx < found; idx++) {                     // :1596-1611
+        if (!dist_sel_equal(mind, kd[idx])) break;
+        emit(n++, idx, 1);
+    }
+    if (found >= 2 && mind.anom != w.anom_dest[c]) {                // :1613-1649
+        int64_t ans_up = 0, ans_down = 0;
+        int32_t ans_idx = -1;
+        for (int32_t i = 1; i < found; i++) {
+            const Dist dd = kd[i];
+            if (dd.anom >= mind.anom) continue;
+            const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref), down = (int64_t)mind.anom - dd.anom;
+            if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; emit(n++, i, 2); }
+            else if (dist_sel_equal(dd, kd[ans_idx])) emit(n++, i, 3);
+        }
+    }
+    return n;
+}
+AASM_DEV bool sel_has_graph(const WS &w, int64_t c) {
+    return (w.rec_off[c + 1] - w.rec_off[c]) > 1 && w.status[c] == 0 && w.kfound[c] > 0;
+}
+AASM_DEV void kb_sel_plan(const KCtx &k, const WS &w) {             // thread per contig
+    const int64_t c = k.bid * k.nthreads + k.tid;
+    if (c >= w.C) return;
+    w.nconv[c] = sel_has_graph(w, c) ? sel_plan_walk(w, c, [](int32_t, int32_t, int32_t) {}) : 0;
+}
+AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // thread per contig
+    const int64_t c = k.bid * k.nthreads + k.tid;
+    if (c >= w.C || !sel_has_graph(w, c)) return;
+    const int64_t j0 = w.conv_off[c];
+    const int32_t N = (int32_t)(w.rec_off[c + 1] - w.rec_off[c]), V = w.ctgV[c];
+    sel_plan_walk(w, c, [&](int32_t ord, int32_t kidx, int32_t kind) {
+        const int64_t j = j0 + ord;
+        w.cv_ctg[j] = (int32_t)c; w.cv_k[j] = kidx; w.cv_ord[j] = ord; w.cv_kind[j] = kind; w.cv_szr[j] = N + 2; w.cv_szv[j] = V;
+    });
+}
+
+AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
+    const int64_t gb = w.rec_off[c];
+    s.w = &w; s.c = c; s.b = gb - w.R0; s.N = w.rec_off[c + 1] - gb; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
+    s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
+    s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
+    s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
+}
+AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
+    if (s.lane == 0) {
+        atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
+        atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
+    }
+}
+
+AASM_DEV void kb_sel_convert(const KCtx &k, const WS &w) {          // one wave per conversion
+    const int64_t j = k.bid;
+    const int64_t c = w.cv_ctg[j];
+    SelCtx s;
+    sel_ctx_init(s, k, w, c);
+    const int64_t ro = w.cv_roff[j], vo = w.cv_voff[j];
+    s.pathA = w.cv_path + 6 * ro; s.pathB = s.pathA + 2 * s.cap; s.pathT = s.pathB + 2 * s.cap;
+    s.pre2 = w.cv_pre2 + vo; s.stamp = w.cv_stamp + vo; s.dist2 = w.cv_dist2 + vo;
+    s.cur = w.cv_out + ro;
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    for (int i_ = 0; i_ < 8; i_++) s.kp_acc[i_] = 0;
+    __builtin_amdgcn_s_waitcnt(0); s.kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0);
+#endif
+    int64_t cov = 0;
+    const int32_t n = sel_convert(s, w.cv_k[j], w.cv_ord[j], cov);
+    if (k.lane == 0) { w.cv_n[j] = n; w.cv_cov[j] = cov; w.cv_err[j] = s.err ? 1 : 0; }
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    if (k.lane == 0 && w.cv_ord[j] == 0) for (int i_ = 0; i_ < 8; i_++) w.prof_sel[c * 8 + i_] = s.kp_acc[i_];
+#endif
+    sel_flush_counters(s, w);
+}
+
+AASM_DEV void sel_all_append(const KCtx &k, const WS &w, int64_t c, const OutElem *src, int32_t n, const int32_t *mark, int32_t ord) {
+    int64_t off = 0, r = 0;
+    if (k.lane == 0) { off = (int64_t)atomic_add(&w.counters[CNT_POOL], (int64_t)n); r = (int64_t)atomic_add(&w.counters[CNT_AR], (int64_t)1); }
+    off = wave_bcast(off, 0); r = wave_bcast(r, 0);
+    if (off + n <= w.pool_cap && r < w.ar_cap) {
+        copy_resolved(w.pool + off, src, n, mark, ord, k.lane);
+        if (k.lane == 0) { w.ar_ctg[r] = (int32_t)c; w.ar_gen[r] = w.all_gen[c]; w.ar_seq[r] = w.all_seq[c]; w.ar_off[r] = off; w.ar_len[r] = n; }
+    } else if (k.lane == 0) {
+        atomic_add(&w.counters[CNT_OVF], (int64_t)1);               // demand keeps being counted; the host re-runs with an exact-size pool
+    }
+    if (k.lane == 0) w.all_seq[c] += 1;
+    wave_fence();
+}
+
+AASM_DEV void kb_sel_final(const KCtx &k, const WS &w) {            // one wave per contig
+    const int64_t c = k.bid;
+    const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    const bool L0 = (k.lane == 0);
+    if (L0) { w.main_len[c] = 0; w.alt_len[c] = 0; }
+    if (N <= 0) return;
+    if (N == 1) {                                                   // paf_data.cpp:235-239
+        OutElem o; o.qs = w.in_qs[gb]; o.qe = w.in_qe[gb]; o.rs = w.in_rs[gb]; o.re = w.in_re[gb]; o.ctg_index = 0; o.is_alt = 0;
+        if (L0) { w.main_out[b] = o; w.main_len[c] = 1; }
+        return;
+    }
+    if (w.status[c] != 0) return;
+    const int32_t nc = w.nconv[c];
+    if (nc <= 0) { if (L0) set_status(w, c, -6); return; }                  // :732
+    const int64_t j0 = w.conv_off[c];
+    for (int32_t t = 0; t < nc; t++) if (w.cv_err[j0 + t]) { if (L0) set_status(w, c, -6); return; }
+    const int32_t *mark = w.mark_time + b;
+    // main + .all: the list is cleared whenever a strictly better coverage appears (:1603-1609)
+    int32_t main_t = 0, alt_t = -1;
+    int64_t max_cov = w.cv_cov[j0];
+    int32_t ties_end = 1;
+    while (ties_end < nc && w.cv_kind[j0 + ties_end] == 1) ties_end++;
+    for (int32_t t = 1; t < ties_end; t++) if (w.cv_cov[j0 + t] > max_cov) { max_cov = w.cv_cov[j0 + t]; main_t = t; }
+    for (int32_t t = main_t + 1; t < ties_end; t++)
+        if (w.cv_cov[j0 + t] == max_cov) sel_all_append(k, w, c, w.cv_out + w.cv_roff[j0 + t], w.cv_n[j0 + t], mark, t);
+    int64_t alt_cov = -1;                                           // :1613-1649
+    for (int32_t t = ties_end; t < nc; t++) {
+        const int32_t kind = w.cv_kind[j0 + t];
+        if (kind == 2) { alt_t = t; alt_cov = w.cv_cov[j0 + t]; }
+        else if (kind == 3 && w.cv_cov[j0 + t] > alt_cov) { alt_t = t; alt_cov = w.cv_cov[j0 + t]; }
+    }
+    copy_resolved(w.main_out + b, w.cv_out + w.cv_roff[j0 + main_t], w.cv_n[j0 + main_t], mark, main_t, k.lane);
+    if (L0) w.main_len[c] = w.cv_n[j0 + main_t];
+    if (alt_t >= 0) {
+        copy_resolved(w.alt_out + b, w.cv_out + w.cv_roff[j0 + alt_t], w.cv_n[j0 + alt_t], mark, alt_t, k.lane);
+        if (L0) w.alt_len[c] = w.cv_n[j0 + alt_t];
+    }
 }
 
 AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // one wave per contig
@@ -1452,44 +1698,40 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // one wave 
     const int32_t found = w.kfound[c];
     if (found <= 0) { if (L0) set_status(w, c, -6); return; }               // :732
     SelCtx s;
-    s.w = &w; s.c = c; s.b = b; s.N = N; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = N + 2;
-    s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
+    sel_ctx_init(s, k, w, c);
     const int64_t pb = 2 * (b + 2 * c);                             // (N+2) pairs per contig
     s.pathA = w.pathA + pb; s.pathB = w.pathB + pb; s.pathT = w.pathT + pb;
     s.pre2 = w.pre2 + s.vb; s.stamp = w.stamp + s.vb; s.dist2 = w.dist2 + s.vb;
-    s.epoch = 0; s.last_head = -1; s.err = false; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    __builtin_amdgcn_s_waitcnt(0);
+    const int64_t kp_mt0 = (int64_t)__builtin_amdgcn_s_memtime(), kp_rt0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+    for (int i_ = 0; i_ < 8; i_++) s.kp_acc[i_] = 0;
+    __builtin_amdgcn_s_waitcnt(0); s.kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0);
+#endif
+    s.cur = w.cur_out + b;
+    const int32_t *mark = w.mark_time + b;
+    int32_t ord = 0;                                                // conversion ordinal (hazard B5)
     const Dist *kd = w.kd + c * (int64_t)w.K;
     OutElem *cur = w.cur_out + b, *mo = w.main_out + b, *ao = w.alt_out + b;
     const Dist mind = kd[0];                                        // :1585
     int64_t cov = 0, max_cov = 0;
-    int32_t n = sel_convert(s, 0, cov);                             // :1589-1593
+    int32_t n = sel_convert(s, 0, ord, cov);                        // :1589-1593
     if (s.err) { if (L0) set_status(w, c, -6); return; }
     max_cov = cov;
-    for (int32_t t = k.lane; t < n; t += AASM_WAVE) mo[t] = cur[t];
+    copy_resolved(mo, cur, n, mark, ord, k.lane);
     if (L0) w.main_len[c] = n;
     for (int32_t idx = 1; idx < found; idx++) {                     // ties, :1596-1611
         const Dist dd = kd[idx];
         if (!(mind.qry + mind.ref == dd.qry + dd.ref && mind.anom == dd.anom)) break;
-        n = sel_convert(s, idx, cov);
+        n = sel_convert(s, idx, ++ord, cov);
         if (s.err) { if (L0) set_status(w, c, -6); return; }
         if (cov > max_cov) {
             max_cov = cov;
-            for (int32_t t = k.lane; t < n; t += AASM_WAVE) mo[t] = cur[t];
+            copy_resolved(mo, cur, n, mark, ord, k.lane);
             if (L0) { w.main_len[c] = n; w.all_gen[c] += 1; }       // paf_ctg_max_out.clear()
             wave_fence();
         } else if (cov == max_cov) {
-            int64_t off = 0, r = 0;
-            if (k.lane == 0) { off = (int64_t)atomic_add(&w.counters[CNT_POOL], (int64_t)n); r = (int64_t)atomic_add(&w.counters[CNT_AR], (int64_t)1); }
-            off = wave_bcast(off, 0); r = wave_bcast(r, 0);
-            if (off + n <= w.pool_cap && r < w.ar_cap) {
-                for (int32_t t = k.lane; t < n; t += AASM_WAVE) w.pool[off + t] = cur[t];
-                if (L0) { w.ar_ctg[r] = (int32_t)c; w.ar_gen[r] = w.all_gen[c]; w.ar_seq[r] = w.all_seq[c]; w.ar_off[r] = off; w.ar_len[r] = n; }
-            } else if (k.lane == 0) {
-                // keep counting the demand; the host re-runs the selection with an exact-size pool
-                atomic_add(&w.counters[CNT_OVF], (int64_t)1);
-            }
-            if (L0) w.all_seq[c] += 1;
-            wave_fence();
+            sel_all_append(k, w, c, cur, n, mark, ord);
         }
     }
     max_cov = -1;                                                   // alt path, :1613-1649
@@ -1503,29 +1745,35 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // one wave 
             const int64_t down = (int64_t)mind.anom - dd.anom;
             if (ans_idx == -1 || up * ans_down < down * ans_up) {
                 ans_up = up; ans_down = down; ans_idx = i;
-                n = sel_convert(s, i, cov);
+                n = sel_convert(s, i, ++ord, cov);
                 if (s.err) { if (L0) set_status(w, c, -6); return; }
                 max_cov = cov;
-                for (int32_t t = k.lane; t < n; t += AASM_WAVE) ao[t] = cur[t];
+                copy_resolved(ao, cur, n, mark, ord, k.lane);
                 if (L0) w.alt_len[c] = n;
             } else {
                 const Dist da = kd[ans_idx];
                 if (dd.qry + dd.ref == da.qry + da.ref && dd.anom == da.anom) {
-                    n = sel_convert(s, i, cov);
+                    n = sel_convert(s, i, ++ord, cov);
                     if (s.err) { if (L0) set_status(w, c, -6); return; }
                     if (cov > max_cov) {
                         max_cov = cov;
-                        for (int32_t t = k.lane; t < n; t += AASM_WAVE) ao[t] = cur[t];
+                        copy_resolved(ao, cur, n, mark, ord, k.lane);
                         if (L0) w.alt_len[c] = n;
                     }
                 }
             }
         }
     }
-    if (k.lane == 0) {
-        atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
-        atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    {   // slot 6/7: elapsed shader cycles and elapsed 100 MHz ticks of this wave -> effective clock
+        __builtin_amdgcn_s_waitcnt(0);
+        const int64_t mt1 = (int64_t)__builtin_amdgcn_s_memtime(), rt1 = (int64_t)__builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0);
+        s.kp_acc[6] = mt1 - kp_mt0; s.kp_acc[7] = rt1 - kp_rt0;
     }
+    if (k.lane == 0) for (int i_ = 0; i_ < 8; i_++) w.prof_sel[c * 8 + i_] = s.kp_acc[i_];
+#endif
+    sel_flush_counters(s, w);
 }
 
 // compaction of main/alt into ragged arrays: one wave per contig

@@ -22,7 +22,8 @@ namespace aasm {
 enum Kern {
     KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_SWEEP, KN_FWD_SWEEP,
-    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT
+    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -51,6 +52,12 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ENUM: kb_enum(k, w); break;
         case KN_SELECT: kb_select(k, w); break;
         case KN_GATHER_OUT: kb_gather_out(k, w); break;
+        case KN_TOPO_COUNT: kb_topo_count(k, w); break;
+        case KN_TOPO_FILL: kb_topo_fill(k, w); break;
+        case KN_SEL_PLAN: kb_sel_plan(k, w); break;
+        case KN_SEL_PLANFILL: kb_sel_planfill(k, w); break;
+        case KN_SEL_CONVERT: kb_sel_convert(k, w); break;
+        case KN_SEL_FINAL: kb_sel_final(k, w); break;
         default: break;
     }
 }
@@ -174,6 +181,15 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_FWD);
         be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_FWD);
+        // CSR copy in forward-topological order for K9's windows
+        be.phase_begin(AASM_PH_TOPO);
+        A(tp_deg, int32_t, VT, "tp_deg"); A(tp_vj, int32_t, VT, "tp_vj"); A(tp_ptr, int64_t, VT + 1, "tp_ptr");
+        A(te_tgt, int32_t, ET, "te_tgt"); A(te_wq, int64_t, ET, "te_wq"); A(te_wr, int32_t, ET, "te_wr"); A(te_fl, uint8_t, ET, "te_fl");
+        CHECK_ALLOC();
+        be.launch(KN_TOPO_COUNT, cdiv(VT, 256), 256, w);
+        be.scan_i32(w.tp_deg, VT, w.tp_ptr);
+        be.launch(KN_TOPO_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        be.phase_end(AASM_PH_TOPO);
 
         // ---- K7 heaps
         be.phase_begin(AASM_PH_HEAP_PREP);
@@ -207,25 +223,79 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     }
 
     // ---- K9 selection (also emits the N == 1 contigs)
-    A(pathA, int32_t, 2 * (R + 2 * C), "pathA"); A(pathB, int32_t, 2 * (R + 2 * C), "pathB"); A(pathT, int32_t, 2 * (R + 2 * C), "pathT");
-    A(pre2, int32_t, VT, "pre2"); AZ(stamp, int32_t, VT, "stamp"); A(dist2, Dist, VT, "dist2"); AZ(notalt, uint8_t, R, "notalt");
+    // Default: plan -> one wave per converted path -> per-contig final pick.  Falls back to the
+    // sequential one-wave-per-contig kernel when the per-conversion scratch would not fit
+    // (tie-heavy inputs at large K) or when opts.reserved[0] bit 0 asks for it (tests).
+    A(mark_time, int32_t, R, "mark_time");
+    AZ(nconv, int32_t, C, "nconv"); A(conv_off, int64_t, C + 1, "conv_off");
     CHECK_ALLOC();
-    be.phase_begin(AASM_PH_SELECT);
-    be.launch(KN_SELECT, C, AASM_WAVE, w);
-    be.phase_end(AASM_PH_SELECT);
-    {   // .all pool overflow (tie-heavy inputs): demand is now known exactly -> one re-run
+    be.fill_byte(w.mark_time, 0x7F, sizeof(int32_t) * (size_t)R);
+    bool sequential = (opts.reserved[0] & 1) != 0;
+    int64_t NCONV = 0, SR = 0, SV = 0;
+    if (!sequential) {
+        be.phase_begin(AASM_PH_MISC);
+        if (VT > 0) be.launch(KN_SEL_PLAN, cdiv(C, 256), 256, w);
+        be.scan_i32(w.nconv, C, w.conv_off);
+        NCONV = be.read_i64(w.conv_off + C);
+        w.NCONV = NCONV;
+        if (NCONV > 0) {
+            A(cv_ctg, int32_t, NCONV, "cv_ctg"); A(cv_k, int32_t, NCONV, "cv_k"); A(cv_ord, int32_t, NCONV, "cv_ord"); A(cv_kind, int32_t, NCONV, "cv_kind");
+            A(cv_szr, int32_t, NCONV, "cv_szr"); A(cv_szv, int32_t, NCONV, "cv_szv"); A(cv_roff, int64_t, NCONV + 1, "cv_roff"); A(cv_voff, int64_t, NCONV + 1, "cv_voff");
+            AZ(cv_n, int32_t, NCONV, "cv_n"); AZ(cv_err, int32_t, NCONV, "cv_err"); AZ(cv_cov, int64_t, NCONV, "cv_cov");
+            CHECK_ALLOC();
+            be.launch(KN_SEL_PLANFILL, cdiv(C, 256), 256, w);
+            be.scan_i32(w.cv_szr, NCONV, w.cv_roff);
+            be.scan_i32(w.cv_szv, NCONV, w.cv_voff);
+            SR = be.read_i64(w.cv_roff + NCONV); SV = be.read_i64(w.cv_voff + NCONV);
+            const int64_t bytes = SR * (24 + (int64_t)sizeof(OutElem)) + SV * ((int64_t)sizeof(Dist) + 8);
+            if (bytes > ((int64_t)24 << 30)) sequential = true;
+        }
+        be.phase_end(AASM_PH_MISC);
+    }
+    if (!sequential) {
+        if (NCONV > 0) {
+            A(cv_path, int32_t, 6 * SR, "cv_path"); A(cv_out, OutElem, SR, "cv_out");
+            A(cv_dist2, Dist, SV, "cv_dist2"); A(cv_pre2, int32_t, SV, "cv_pre2"); AZ(cv_stamp, int32_t, SV, "cv_stamp");
+            CHECK_ALLOC();
+            be.phase_begin(AASM_PH_SELECT);
+            be.launch(KN_SEL_CONVERT, NCONV, AASM_WAVE, w);
+            be.phase_end(AASM_PH_SELECT);
+        }
+        be.phase_begin(AASM_PH_GATHER);
+        be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
         const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
-        if (need_pool > w.pool_cap || need_ar > w.ar_cap) {
+        if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow: exact-size re-run of the pick only
+            w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
+            A(pool, OutElem, w.pool_cap, "pool");
+            A(ar_ctg, int32_t, w.ar_cap, "ar_ctg"); A(ar_gen, int32_t, w.ar_cap, "ar_gen"); A(ar_seq, int32_t, w.ar_cap, "ar_seq");
+            A(ar_len, int32_t, w.ar_cap, "ar_len"); A(ar_off, int64_t, w.ar_cap, "ar_off");
+            CHECK_ALLOC();
+            be.zero(w.all_seq, sizeof(int32_t) * (size_t)C);
+            be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
+            be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
+        }
+        be.phase_end(AASM_PH_GATHER);
+    } else {
+        A(pathA, int32_t, 2 * (R + 2 * C), "pathA"); A(pathB, int32_t, 2 * (R + 2 * C), "pathB"); A(pathT, int32_t, 2 * (R + 2 * C), "pathT");
+        A(pre2, int32_t, VT, "pre2"); AZ(stamp, int32_t, VT, "stamp"); A(dist2, Dist, VT, "dist2");
+        CHECK_ALLOC();
+        be.phase_begin(AASM_PH_SELECT);
+        be.launch(KN_SELECT, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_SELECT);
+        const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
+        if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow (tie-heavy inputs): one exact-size re-run
             w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
             A(pool, OutElem, w.pool_cap, "pool");
             A(ar_ctg, int32_t, w.ar_cap, "ar_ctg"); A(ar_gen, int32_t, w.ar_cap, "ar_gen"); A(ar_seq, int32_t, w.ar_cap, "ar_seq");
             A(ar_len, int32_t, w.ar_cap, "ar_len"); A(ar_off, int64_t, w.ar_cap, "ar_off");
             CHECK_ALLOC();
             be.zero(w.stamp, sizeof(int32_t) * (size_t)(VT > 0 ? VT : 1));
-            be.zero(w.notalt, (size_t)R);
+            be.fill_byte(w.mark_time, 0x7F, sizeof(int32_t) * (size_t)R);
             be.zero(w.all_gen, sizeof(int32_t) * (size_t)C); be.zero(w.all_seq, sizeof(int32_t) * (size_t)C);
             be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t));
             be.zero(w.counters + CNT_CONVERTED, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
+            be.zero(w.counters + CNT_ISPR_E, sizeof(int64_t)); be.zero(w.counters + CNT_ISPR_V, sizeof(int64_t));
+            be.zero(w.counters + CNT_PATH_E, sizeof(int64_t)); be.zero(w.counters + CNT_OUT_E, sizeof(int64_t));
             be.phase_begin(AASM_PH_MISC);
             be.launch(KN_SELECT, C, AASM_WAVE, w);
             be.phase_end(AASM_PH_MISC);

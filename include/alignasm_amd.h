@@ -79,7 +79,7 @@ typedef struct aasm_opts {
     int32_t device;            /* HIP device ordinal                                  */
     int32_t collect_timing;    /* 1: bracket every kernel with HIP events            */
     int32_t keep_debug;        /* 1: keep device intermediates for aasm_debug_fetch   */
-    int32_t reserved[3];
+    int32_t reserved[3];       /* [0] bit 0: force the sequential selection kernel (tests)  */
 } aasm_opts;
 
 /* ---- output ---------------------------------------------------------------------
@@ -127,6 +127,7 @@ enum {
     AASM_PH_SELECT,       /* K9 aasm_k9_select alone                      */
     AASM_PH_GATHER,       /* output compaction                            */
     AASM_PH_HEAP_PREP,    /* SP-tree children CSR + arena sizing          */
+    AASM_PH_TOPO,         /* topologically ordered CSR copy for K9        */
     AASM_PH_MISC
 };
 

@@ -31,12 +31,13 @@ struct EmuBackend {
     bool failed() const { return fail; }
     void zero(void *p, size_t n) { memset(p, 0, n); }
     void fill_ff(void *p, size_t n) { memset(p, 0xFF, n); }
+    void fill_byte(void *p, int v, size_t n) { memset(p, v, n); }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
         (void)nthreads;
         for (int64_t b = 0; b < nblocks; b++) {
             // one logical thread per block slot: bodies index with bid*nthreads+tid
             for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {
-                alignas(16) static char lds[AASM_LDS_BYTES];
+                alignas(16) static char lds[AASM_SEL_LDS_BYTES > AASM_LDS_BYTES ? AASM_SEL_LDS_BYTES : AASM_LDS_BYTES];
                 KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0, lds};
                 run_kernel_body(kn, k, w);
             }
@@ -46,7 +47,7 @@ struct EmuBackend {
     static int nthreads_emul(int kn, int nthreads) {
         switch (kn) {
             case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_SORT_ROWS_CHILD:
-            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_HEAP: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT:
+            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_HEAP: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_CONVERT: case KN_SEL_FINAL:
                 return 1;
             default: return nthreads;
         }

@@ -32,3 +32,13 @@ def test_outputs_and_intermediates(T, case):
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
     assert want["stats"]["n_internal_errors"] == 0
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[4], CASES[7], CASES[12]], ids=lambda c: "seq_c%dx%d_s%d" % (c[0], c[1], c[2]))
+def test_sequential_select_fallback(T, case):
+    """The one-wave-per-contig selection kernel (fallback for huge conversion counts)."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = T.emul_solve(hb, K, nsl, sequential_select=True)
+    assert T.diff_outputs(want, got) == []

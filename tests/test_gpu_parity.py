@@ -75,3 +75,13 @@ def test_out_of_memory_ranges_are_split_and_concatenated(T, monkeypatch):
     assert T.diff_outputs(whole, split, stats=False) == []
     for k in ("n_vertices", "n_edges", "n_heap_nodes", "n_paths_found", "n_pairs"):
         assert whole["stats"][k] == split["stats"][k], k
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[5], CASES[8], CASES[13]], ids=_id)
+def test_sequential_select_fallback_on_gpu(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, sequential_select=True)
+    assert T.diff_outputs(want, got) == []
