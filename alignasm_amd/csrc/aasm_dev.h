@@ -101,6 +101,18 @@ AASM_DEV int64_t uni(int64_t x) {
 }
 AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
 
+// a 64-entry int stack held in ONE vector register (entry i lives in lane i): push is a
+// compare + select, pop a v_readlane with a scalar index
+#if defined(AASM_HOST_EMUL)
+struct LaneStack { int32_t a[64]; };
+AASM_DEV void lstack_set(LaneStack &s, int i, int32_t v, int) { s.a[i] = v; }
+AASM_DEV int32_t lstack_get(const LaneStack &s, int i) { return s.a[i]; }
+#else
+struct LaneStack { int32_t r; };
+AASM_DEV void lstack_set(LaneStack &s, int i, int32_t v, int lane) { s.r = (lane == i) ? v : s.r; }
+AASM_DEV int32_t lstack_get(const LaneStack &s, int i) { return __builtin_amdgcn_readlane(s.r, i); }
+#endif
+
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 
 // inclusive wave scans (Hillis-Steele over 64 lanes; identity with one lane)

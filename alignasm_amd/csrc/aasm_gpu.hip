@@ -130,7 +130,10 @@ struct ArenaBlock { char *p; size_t cap, used; };
 struct DevCtx {
     int device = -1;
     bool ready = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_fork, ev_join;
+    int64_t *d_scratch2 = nullptr;      // scan tile sums of the side stream
+    size_t d_scratch2_cap = 0;
     std::vector<ArenaBlock> blocks;
     int64_t *pinned = nullptr;          // host-pinned scalar read-back buffer
     int64_t *d_scratch = nullptr;       // scan tile sums
@@ -159,6 +162,8 @@ static int ctx_init(int device) {
     if (device >= n) { set_last_error("device ordinal beyond hipGetDeviceCount"); return AASM_E_NODEVICE; }
     if ((e = hipSetDevice(device)) != hipSuccess) { set_last_error(hip_err("hipSetDevice", e)); return AASM_E_NODEVICE; }
     if ((e = hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking)) != hipSuccess) { set_last_error(hip_err("hipStreamCreate", e)); return AASM_E_NODEVICE; }
+    if ((e = hipStreamCreateWithFlags(&cx.side, hipStreamNonBlocking)) != hipSuccess) { set_last_error(hip_err("hipStreamCreate", e)); return AASM_E_NODEVICE; }
+    hipEventCreateWithFlags(&cx.ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&cx.ev_join, hipEventDisableTiming);
     if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t))) != hipSuccess) { set_last_error(hip_err("hipHostMalloc", e)); return AASM_E_NODEVICE; }
     for (int i = 0; i < AASM_N_PHASES; i++) { hipEventCreate(&cx.ev_b[i]); hipEventCreate(&cx.ev_e[i]); }
     hipEventCreate(&cx.ev_t0); hipEventCreate(&cx.ev_t1);
@@ -170,13 +175,14 @@ static int ctx_init(int device) {
 
 struct GpuBackend {
     DevCtx &cx;
-    hipStream_t stream;
+    hipStream_t stream, main_stream;
+    bool on_side = false, forked = false;
     bool timing;
     bool fail = false;
     bool phase_used[AASM_N_PHASES] = {false};
     size_t cur_block = 0, bytes = 0;
     std::map<std::string, std::pair<void *, size_t>> named;
-    GpuBackend(DevCtx &c, hipStream_t s, bool t) : cx(c), stream(s), timing(t) {
+    GpuBackend(DevCtx &c, hipStream_t s, bool t) : cx(c), stream(s), main_stream(s), timing(t) {
         for (auto &b : cx.blocks) b.used = 0;
         cx.generation++;
     }
@@ -228,15 +234,18 @@ struct GpuBackend {
         if (fail) return;
         if (n <= 0) { zero(out, 8); return; }
         const int64_t nt = cdiv(n, SCAN_TILE);
-        if ((size_t)nt + 8 > cx.d_scratch_cap) {
-            if (cx.d_scratch) hipFree(cx.d_scratch);
-            cx.d_scratch_cap = (size_t)nt * 2 + 1024;
-            hipError_t e = hipMalloc((void **)&cx.d_scratch, cx.d_scratch_cap * 8);
-            if (e != hipSuccess) { cx.d_scratch = nullptr; cx.d_scratch_cap = 0; hip_fail("hipMalloc(scan)", e); return; }
+        int64_t *&scr = on_side ? cx.d_scratch2 : cx.d_scratch;
+        size_t &scr_cap = on_side ? cx.d_scratch2_cap : cx.d_scratch_cap;
+        if ((size_t)nt + 8 > scr_cap) {
+            hipDeviceSynchronize();                                  // rare growth: nothing may still use the old buffer
+            if (scr) hipFree(scr);
+            scr_cap = (size_t)nt * 2 + 1024;
+            hipError_t e = hipMalloc((void **)&scr, scr_cap * 8);
+            if (e != hipSuccess) { scr = nullptr; scr_cap = 0; hip_fail("hipMalloc(scan)", e); return; }
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_tiles<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, cx.d_scratch);
-        hipLaunchKernelGGL(aasm_scan_sums, dim3(1), dim3(SCAN_TPB), 0, stream, cx.d_scratch, nt, out + n);
-        hipLaunchKernelGGL(aasm_scan_add, dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, out, n, cx.d_scratch);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_tiles<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, scr);
+        hipLaunchKernelGGL(aasm_scan_sums, dim3(1), dim3(SCAN_TPB), 0, stream, scr, nt, out + n);
+        hipLaunchKernelGGL(aasm_scan_add, dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, out, n, scr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) hip_fail("scan launch", e);
     }
@@ -260,6 +269,10 @@ struct GpuBackend {
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) hip_fail("hipMemcpy H2D", e);
     }
+    // second stream: fork = side waits for the main stream's work so far; join = main waits for side
+    void fork() { if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
+    void use_side(bool on) { on_side = on; stream = on ? cx.side : main_stream; }
+    void join() { if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
     void phase_begin(int ph) { if (timing && !fail) { hipEventRecord(cx.ev_b[ph], stream); phase_used[ph] = true; } }
     void phase_end(int ph) { if (timing && !fail) hipEventRecord(cx.ev_e[ph], stream); }
 };
@@ -288,7 +301,9 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     if (timing) hipEventRecord(cx.ev_t0, stream);
     int rc = run_pipeline(*be, dev_in, opts, res->w, res->sz);
     if (timing) hipEventRecord(cx.ev_t1, stream);
+    be->join();
     hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(cx.side);
     if (rc == AASM_OK && be->failed()) rc = AASM_E_HIP;
     if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }
     if (rc != AASM_OK) { delete res; return rc; }

@@ -171,25 +171,27 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         be.phase_end(AASM_PH_REVCSR);
 
-        // ---- K6 / K5 sweeps
+        // ---- K6 / K5 sweeps.  The forward sweep + the topologically ordered CSR copy only feed
+        // K9, so they run on a second stream beside rev_sweep -> heaps -> enumeration.
         A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(rev_order, int32_t, VT, "rev_order"); A(cnt_tmp, int32_t, VT, "cnt_tmp");
         A(fwd_order, int32_t, VT, "fwd_order"); A(fwd_pos, int32_t, VT, "fwd_pos"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
-        CHECK_ALLOC();
-        be.phase_begin(AASM_PH_SPTREE);
-        be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
-        be.phase_end(AASM_PH_SPTREE);
-        be.phase_begin(AASM_PH_FWD);
-        be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
-        be.phase_end(AASM_PH_FWD);
-        // CSR copy in forward-topological order for K9's windows
-        be.phase_begin(AASM_PH_TOPO);
         A(tp_deg, int32_t, VT, "tp_deg"); A(tp_vj, int32_t, VT, "tp_vj"); A(tp_ptr, int64_t, VT + 1, "tp_ptr");
         A(te_tgt, int32_t, ET, "te_tgt"); A(te_wq, int64_t, ET, "te_wq"); A(te_wr, int32_t, ET, "te_wr"); A(te_fl, uint8_t, ET, "te_fl");
         CHECK_ALLOC();
+        be.fork();                                                   // side stream waits for everything enqueued so far
+        be.use_side(true);
+        be.phase_begin(AASM_PH_FWD);
+        be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_FWD);
+        be.phase_begin(AASM_PH_TOPO);
         be.launch(KN_TOPO_COUNT, cdiv(VT, 256), 256, w);
         be.scan_i32(w.tp_deg, VT, w.tp_ptr);
         be.launch(KN_TOPO_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         be.phase_end(AASM_PH_TOPO);
+        be.use_side(false);
+        be.phase_begin(AASM_PH_SPTREE);
+        be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_SPTREE);
 
         // ---- K7 heaps
         be.phase_begin(AASM_PH_HEAP_PREP);
@@ -222,6 +224,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_end(AASM_PH_ENUM);
     }
 
+    be.join();                                                       // forward order / topo copy ready
     // ---- K9 selection (also emits the N == 1 contigs)
     // Default: plan -> one wave per converted path -> per-contig final pick.  Falls back to the
     // sequential one-wave-per-contig kernel when the per-conversion scratch would not fit

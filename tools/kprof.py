@@ -12,6 +12,7 @@ for _ in range(2):
 st = res.stats()
 for name in ("prof_heap", "prof_sel"):
     p = res.debug(name, np.int64)[: nc * 8].reshape(nc, 8)
+    print(name, "per-contig sum mean/max:", int(p.sum(1).mean()), int(p.sum(1).max()))
     print(name, "mean cycles/contig per section:", np.round(p.mean(0)).astype(int).tolist(), "sum", int(p.sum(1).mean()))
 ps = res.debug("prof_sel", np.int64)[: nc * 8].reshape(nc, 8)
 print("select: elapsed shader cycles / 100MHz ticks -> GHz:", float((ps[:,6] / np.maximum(ps[:,7],1)).mean()) * 0.1, " wave elapsed ms (mean/max):", ps[:,7].mean() / 1e5, ps[:,7].max() / 1e5)
