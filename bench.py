@@ -50,7 +50,7 @@ def kernel_bytes(st):
         "fwd": ("aasm_k5_fwd_sweep", 24 * E + 2 * 8 * V),
         "heap": ("aasm_k7_heap", 24 * E + 40 * V + 24 * H),
         "enum": ("aasm_k8_enum", 64 * st["pq_pushes"] + 40 * st["n_paths_found"]),
-        "select": ("aasm_k9_select", 24 * st["ispr_edges"] + 40 * st["ispr_vertices"] + 8 * st["path_edges"] + 40 * st["out_elems"]),
+        "select": ("aasm_k9_sel_convert", 24 * st["ispr_edges"] + 40 * st["ispr_vertices"] + 8 * st["path_edges"] + 40 * st["out_elems"]),
     }
 
 
