@@ -40,6 +40,7 @@ struct KCtx {
 AASM_DEV uint64_t wave_ballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> AASM_DEV T wave_bcast(T x, int) { return x; }
 template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return fill; }
+template <class T> AASM_DEV T wave_shfl_xor(T x, int) { return x; }
 AASM_DEV void block_sync() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
@@ -61,6 +62,11 @@ AASM_DEV int64_t wave_shfl_up(int64_t x, int d, int64_t fill) {
     int lo = __shfl_up((int)(x & 0xffffffffll), d, 64), hi = __shfl_up((int)(x >> 32), d, 64);
     int64_t y = ((int64_t)hi << 32) | (uint32_t)lo;
     return ((int)(threadIdx.x & 63) >= d) ? y : fill;
+}
+AASM_DEV int wave_shfl_xor(int x, int m) { return __shfl_xor(x, m, 64); }
+AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
+    int lo = __shfl_xor((int)(x & 0xffffffffll), m, 64), hi = __shfl_xor((int)(x >> 32), m, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 AASM_DEV void block_sync() { __syncthreads(); }
 // order this wave's global-memory writes before its later reads (same CU, same L1)
@@ -100,18 +106,6 @@ AASM_DEV int64_t uni(int64_t x) {
     return (int64_t)(((uint64_t)(uint32_t)uni((int32_t)((uint64_t)x >> 32)) << 32) | (uint32_t)uni((int32_t)(uint32_t)(uint64_t)x));
 }
 AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
-
-// a 64-entry int stack held in ONE vector register (entry i lives in lane i): push is a
-// compare + select, pop a v_readlane with a scalar index
-#if defined(AASM_HOST_EMUL)
-struct LaneStack { int32_t a[64]; };
-AASM_DEV void lstack_set(LaneStack &s, int i, int32_t v, int) { s.a[i] = v; }
-AASM_DEV int32_t lstack_get(const LaneStack &s, int i) { return s.a[i]; }
-#else
-struct LaneStack { int32_t r; };
-AASM_DEV void lstack_set(LaneStack &s, int i, int32_t v, int lane) { s.r = (lane == i) ? v : s.r; }
-AASM_DEV int32_t lstack_get(const LaneStack &s, int i) { return __builtin_amdgcn_readlane(s.r, i); }
-#endif
 
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 

@@ -58,10 +58,10 @@ AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_LDS_BYTES)
-AASM_DEF_KERNEL(aasm_k8_enum, KN_ENUM, 64)
+AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_LDS_BYTES)
 AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES)
-AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 256)
-AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 256)
+AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
+AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
 AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES)
 AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)

@@ -1116,81 +1116,151 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 // real walks (non-negative components), on which operator< is a strict weak order, so the
 // tuple order is total and any correct min-queue pops the same sequence.  The pointer is
 // replaced by the arena index (DESIGN.md "hazard B3").
-AASM_DEV bool pq_less(const PQEnt &a, const PQEnt &b) {
-    if (dist_lt<CALC_SUM_MODE>(a.d, b.d)) return true;
-    if (dist_lt<CALC_SUM_MODE>(b.d, a.d)) return false;
+//
+// The queue is a wave-cooperative 8-ARY heap: the children of a node are 8 consecutive
+// 48-byte entries, fetched by 8 lanes in one coalesced load and min-reduced by a 3-step
+// butterfly, so a pop descends log8(n) levels (6 for the 30 001 entries of K = 10 000) instead
+// of log2(n) = 15 pointer-dependent steps; its top three levels (1 + 8 + 64 entries) live in LDS.
+#define PQ8_LDS_N 73
+struct PqKey { int64_t sum; int32_t anom, qnz, qtot, node, cur, slot, valid; };
+AASM_DEV PqKey pqkey_of(const PQEnt &e, int32_t slot) {
+    PqKey k; k.sum = e.d.qry + e.d.ref; k.anom = e.d.anom; k.qnz = e.d.qnz; k.qtot = e.d.qtot; k.node = e.node; k.cur = e.cur; k.slot = slot; k.valid = 1;
+    return k;
+}
+// std::tuple order of (Distance, node, cur) for distances of real walks (never max(), all
+// components >= 0): paf_data.hpp:142-159 then node index then insertion index.  invalid = +inf.
+AASM_DEV bool pqkey_less(const PqKey &a, const PqKey &b) {
+    if (!b.valid) return a.valid != 0;
+    if (!a.valid) return false;
+    if (a.sum != b.sum) return a.sum < b.sum;
+    if (a.anom != b.anom) return a.anom < b.anom;
+    const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
+    const int64_t l = (int64_t)a.qnz * (int64_t)tb, r = (int64_t)b.qnz * (int64_t)ta;
+    if (l != r) return l > r;
     if (a.node != b.node) return a.node < b.node;
     return a.cur < b.cur;
 }
-AASM_DEV void pq_push(PQEnt *hp, int32_t &n, const PQEnt &x) {
-    int32_t i = n++;
+AASM_DEV PqKey pqkey_shfl_xor(const PqKey &k, int m) {
+    PqKey o; o.sum = wave_shfl_xor(k.sum, m); o.anom = wave_shfl_xor(k.anom, m); o.qnz = wave_shfl_xor(k.qnz, m); o.qtot = wave_shfl_xor(k.qtot, m);
+    o.node = wave_shfl_xor(k.node, m); o.cur = wave_shfl_xor(k.cur, m); o.slot = wave_shfl_xor(k.slot, m); o.valid = wave_shfl_xor(k.valid, m);
+    return o;
+}
+struct Pq8 { PQEnt *g, *l; int32_t n; int32_t pc_idx; PQEnt pc_ent; };   // pc_*: last parent read by a push
+AASM_DEV PQEnt pq8_get(const Pq8 &q, int32_t i) {
+    PQEnt e;
+    if (i < PQ8_LDS_N) e = q.l[i];
+    else { e = q.g[i]; asm volatile("" ::: "memory"); }              // keep LDS and global reads apart (no flat access)
+    return e;
+}
+AASM_DEV void pq8_set(Pq8 &q, int32_t i, const PQEnt &e, int lane) {
+    if (lane == 0) { if (i < PQ8_LDS_N) q.l[i] = e; else q.g[i] = e; }
+    if (i == q.pc_idx) q.pc_idx = -1;
+}
+AASM_DEV PQEnt pqent_bcast(const PQEnt &e, int src) {
+    PQEnt o;
+    o.d.qry = wave_bcast(e.d.qry, src); o.d.ref = wave_bcast(e.d.ref, src); o.d.anom = wave_bcast(e.d.anom, src); o.d.qnz = wave_bcast(e.d.qnz, src);
+    o.d.qtot = wave_bcast(e.d.qtot, src); o.d.pad = 0; o.node = wave_bcast(e.node, src); o.cur = wave_bcast(e.cur, src); o.pad0 = o.pad1 = 0;
+    return o;
+}
+AASM_DEV void pq8_push(Pq8 &q, const PQEnt &x, int lane) {
+    int32_t i = q.n++;
+    const PqKey xk = pqkey_of(x, 0);
     while (i > 0) {
-        const int32_t p = (i - 1) >> 1;
-        if (!pq_less(x, hp[p])) break;
-        hp[i] = hp[p];
+        const int32_t p = (i - 1) >> 3;
+        // the <= 3 pushes of one iteration land side by side and almost always share a parent
+        if (p != q.pc_idx) { q.pc_ent = pq8_get(q, p); q.pc_idx = p; }
+        const PQEnt pe = q.pc_ent;
+        if (!uni(pqkey_less(xk, pqkey_of(pe, 0)))) break;
+        pq8_set(q, i, pe, lane);
         i = p;
     }
-    hp[i] = x;
+    pq8_set(q, i, x, lane);
+    block_sync();
 }
-AASM_DEV PQEnt pq_pop(PQEnt *hp, int32_t &n) {
-    const PQEnt top = hp[0];
-    const PQEnt x = hp[--n];
+AASM_DEV PQEnt pq8_pop(Pq8 &q, int lane) {
+    const PQEnt top = pq8_get(q, 0);
+    const PQEnt x = pq8_get(q, --q.n);
+    q.pc_idx = -1;
+    if (q.n == 0) return top;
+    const PqKey xk = pqkey_of(x, 0);
     int32_t i = 0;
     while (true) {
-        int32_t l = 2 * i + 1;
-        if (l >= n) break;
-        if (l + 1 < n && pq_less(hp[l + 1], hp[l])) l++;
-        if (!pq_less(hp[l], x)) break;
-        hp[i] = hp[l];
-        i = l;
+        const int32_t c0 = 8 * i + 1;
+        if (c0 >= q.n) break;
+        const int32_t nchild = (q.n - c0 < 8) ? (q.n - c0) : 8;
+        PqKey best; best.valid = 0; best.sum = 0; best.anom = best.qnz = best.qtot = best.node = best.cur = best.slot = 0;
+        PQEnt mine = x;                                               // the child this lane fetched (lanes 0..7: one each)
+        for (int32_t j = lane; j < nchild; j += AASM_WAVE) {
+            const PQEnt e = pq8_get(q, c0 + j);
+            const PqKey kj = pqkey_of(e, j);
+            if (pqkey_less(kj, best)) { best = kj; mine = e; }
+        }
+        for (int m = 1; m < 8 && m < AASM_WAVE; m <<= 1) {            // butterfly min over lanes 0..7
+            const PqKey o = pqkey_shfl_xor(best, m);
+            if (pqkey_less(o, best)) best = o;
+        }
+        const int32_t bslot = uni(best.slot);
+        if (!uni(pqkey_less(best, xk))) break;
+        const PQEnt be = pqent_bcast(mine, AASM_WAVE > 1 ? bslot : 0);  // winner's entry straight from its lane
+        pq8_set(q, i, be, lane);
+        i = c0 + bslot;
+        block_sync();
     }
-    if (n > 0) hp[i] = x;
+    pq8_set(q, i, x, lane);
+    block_sync();
     return top;
 }
 
-AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // wave per contig, lane 0 works
+AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
-    if (k.lane != 0) return;
-    w.kfound[c] = 0;
+    if (k.lane == 0) w.kfound[c] = 0;
     if (V == 0 || w.status[c] != 0) return;
     const int64_t vb = w.voff[c];
     const int64_t K = w.K;
     Dist *kd = w.kd + c * K;
     int32_t *klast = w.klast + c * K, *knodes = w.knodes + c * (3 * K + 1), *kprev = w.kprev + c * (3 * K + 1);
-    PQEnt *hp = w.pq + c * (3 * K + 1);
+    Pq8 q; q.g = w.pq + c * (3 * K + 1); q.l = (PQEnt *)k.lds; q.n = 0; q.pc_idx = -1;
+    static_assert(PQ8_LDS_N * sizeof(PQEnt) <= AASM_LDS_BYTES, "LDS budget");
     const HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
-    int32_t found = 0, nn = 0, pn = 0;
-    kd[found] = w.sp_d[vb + src]; klast[found] = -1; found++;        // :217-220
-    const int32_t hs = h[src];
+    const bool L0 = k.lane == 0;
+    int32_t found = 0, nn = 0;
+    const Dist dsrc = w.sp_d[vb + src];
+    if (L0) { kd[0] = dsrc; klast[0] = -1; }                         // :217-220
+    found = 1;
+    const int32_t hs = uni(h[src]);
+    auto emplace = [&](const Dist &dd, int32_t hp, int32_t pre) {    // :232-237
+        PQEnt x; x.d = dd; x.node = hp; x.cur = nn; x.pad0 = x.pad1 = 0;
+        if (L0) { knodes[nn] = hp; kprev[nn] = pre; }
+        pq8_push(q, x, k.lane);
+        nn++;
+    };
     if (hs >= 0) {                                                  // :227-228
-        PQEnt x; x.d = dist_add(w.sp_d[vb + src], hnode_key(nodes[hs])); x.node = hs; x.cur = nn; x.pad0 = x.pad1 = 0;
-        pq_push(hp, pn, x); knodes[nn] = hs; kprev[nn] = -1; nn++;   // :239
-        while (pn > 0 && found < K) {                               // :240-248
-            const PQEnt top = pq_pop(hp, pn);
-            const HNode ch = nodes[top.node];
-            kd[found] = top.d; klast[found] = top.cur; found++;
-            const int32_t hv = h[ch.v];
-            if (hv >= 0) {
-                PQEnt y; y.d = dist_add(top.d, hnode_key(nodes[hv])); y.node = hv; y.cur = nn; y.pad0 = y.pad1 = 0;
-                pq_push(hp, pn, y); knodes[nn] = hv; kprev[nn] = top.cur; nn++;
-            }
+        emplace(dist_add(dsrc, hnode_key(nodes[hs])), hs, -1);       // :239
+        int32_t prev_of_top = -1;
+        while (q.n > 0 && found < K) {                              // :240-248
+            const PQEnt top = pq8_pop(q, k.lane);
+            const int32_t tcur = uni(top.cur), tnode = uni(top.node);
+            const HNode ch = nodes[tnode];
+            if (L0) { kd[found] = top.d; klast[found] = tcur; }
+            found++;
+            wave_fence();
+            prev_of_top = uni(kprev[tcur]);
+            const int32_t hv = uni(h[ch.v]);
+            if (hv >= 0) emplace(dist_add(top.d, hnode_key(nodes[hv])), hv, tcur);
             const Dist chk = hnode_key(ch);
-            if (ch.left >= 0) {
-                PQEnt y; y.d = dist_sub(dist_add(top.d, hnode_key(nodes[ch.left])), chk); y.node = ch.left; y.cur = nn; y.pad0 = y.pad1 = 0;
-                pq_push(hp, pn, y); knodes[nn] = ch.left; kprev[nn] = kprev[top.cur]; nn++;
-            }
-            if (ch.right >= 0) {
-                PQEnt y; y.d = dist_sub(dist_add(top.d, hnode_key(nodes[ch.right])), chk); y.node = ch.right; y.cur = nn; y.pad0 = y.pad1 = 0;
-                pq_push(hp, pn, y); knodes[nn] = ch.right; kprev[nn] = kprev[top.cur]; nn++;
-            }
+            const int32_t cl = uni(ch.left), cr = uni(ch.right);
+            if (cl >= 0) emplace(dist_sub(dist_add(top.d, hnode_key(nodes[cl])), chk), cl, prev_of_top);
+            if (cr >= 0) emplace(dist_sub(dist_add(top.d, hnode_key(nodes[cr])), chk), cr, prev_of_top);
         }
     }
-    w.kfound[c] = found;
-    atomic_add(&w.counters[CNT_PATHS], (int64_t)found);
-    atomic_add(&w.counters[CNT_PQ_PUSH], (int64_t)nn);
+    if (L0) {
+        w.kfound[c] = found;
+        atomic_add(&w.counters[CNT_PATHS], (int64_t)found);
+        atomic_add(&w.counters[CNT_PQ_PUSH], (int64_t)nn);
+    }
 }
 
 // ====================================================================================
@@ -1550,46 +1620,66 @@ AASM_DEV bool dist_sel_equal(const Dist &a, const Dist &b) { return a.qry + a.re
 // (paf_data.cpp:1596-1649: tie run, then alt candidates), so the expensive conversions
 // (recover + upgrade + clip) run as independent waves and the per-contig tail of the
 // sequential form disappears.  kinds: 0 main, 1 tie, 2 alt (new best ratio), 3 alt (equal).
-template <class F> AASM_DEV int32_t sel_plan_walk(const WS &w, int64_t c, F emit) {
+AASM_DEV bool sel_has_graph(const WS &w, int64_t c) {
+    return (w.rec_off[c + 1] - w.rec_off[c]) > 1 && w.status[c] == 0 && w.kfound[c] > 0;
+}
+// One wave per contig scans the K distances 64 at a time (ballot): the tie run is the maximal
+// prefix of paths equal to the best one (:1596-1611); alt candidates are the paths with fewer
+// anomalies (:1613-1649), visited in index order because the "best ratio so far" is sequential.
+// fill == false only counts; fill == true writes the conversion records at conv_off[c].
+AASM_DEV int32_t sel_plan_wave(const KCtx &k, const WS &w, int64_t c, bool fill) {
     const int32_t found = w.kfound[c];
     const Dist *kd = w.kd + c * (int64_t)w.K;
     const Dist mind = kd[0];
+    const int64_t j0 = fill ? w.conv_off[c] : 0;
+    const int32_t N = (int32_t)(w.rec_off[c + 1] - w.rec_off[c]), V = w.ctgV[c];
+    auto put = [&](int32_t ord, int32_t kidx, int32_t kind) {
+        const int64_t j = j0 + ord;
+        w.cv_ctg[j] = (int32_t)c; w.cv_k[j] = kidx; w.cv_ord[j] = ord; w.cv_kind[j] = kind; w.cv_szr[j] = N + 2; w.cv_szv[j] = V;
+    };
     int32_t n = 0;
-    emit(n++, 0, 0);
-    for (int32_t idx = 1; idx < found; idx++) {                     // :1596-1611
-        if (!dist_sel_equal(mind, kd[idx])) break;
-        emit(n++, idx, 1);
+    if (fill && k.lane == 0) put(0, 0, 0);
+    n = 1;
+    for (int32_t base = 1; base < found; base += AASM_WAVE) {       // tie run
+        const int32_t idx = base + k.lane;
+        const bool in = idx < found;
+        const bool eq = in && dist_sel_equal(mind, kd[idx]);
+        const uint64_t m = wave_ballot(eq), full = wave_ballot(in);
+        const int lead = (~m == 0ull) ? 64 : (ffs64(~m) - 1);
+        if (fill && k.lane < lead) put(n + k.lane, idx, 1);
+        n += lead;
+        if (lead < popc64(full)) break;
     }
-    if (found >= 2 && mind.anom != w.anom_dest[c]) {                // :1613-1649
+    if (found >= 2 && mind.anom != w.anom_dest[c]) {
         int64_t ans_up = 0, ans_down = 0;
         int32_t ans_idx = -1;
-        for (int32_t i = 1; i < found; i++) {
-            const Dist dd = kd[i];
-            if (dd.anom >= mind.anom) continue;
-            const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref), down = (int64_t)mind.anom - dd.anom;
-            if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; emit(n++, i, 2); }
-            else if (dist_sel_equal(dd, kd[ans_idx])) emit(n++, i, 3);
+        Dist ans_d = mind;
+        for (int32_t base = 1; base < found; base += AASM_WAVE) {
+            const int32_t idx = base + k.lane;
+            uint64_t m = wave_ballot(idx < found && kd[idx].anom < mind.anom);
+            while (m) {
+                const int bit = ffs64(m) - 1;
+                m &= m - 1;
+                const int32_t i = base + bit;
+                const Dist dd = kd[i];
+                const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref), down = (int64_t)mind.anom - dd.anom;
+                int32_t kind = -1;
+                if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; ans_d = dd; kind = 2; }
+                else if (dist_sel_equal(dd, ans_d)) kind = 3;
+                if (kind >= 0) { if (fill && k.lane == 0) put(n, i, kind); n++; }
+            }
         }
     }
     return n;
 }
-AASM_DEV bool sel_has_graph(const WS &w, int64_t c) {
-    return (w.rec_off[c + 1] - w.rec_off[c]) > 1 && w.status[c] == 0 && w.kfound[c] > 0;
+AASM_DEV void kb_sel_plan(const KCtx &k, const WS &w) {             // one wave per contig
+    const int64_t c = k.bid;
+    const int32_t n = sel_has_graph(w, c) ? sel_plan_wave(k, w, c, false) : 0;
+    if (k.lane == 0) w.nconv[c] = n;
 }
-AASM_DEV void kb_sel_plan(const KCtx &k, const WS &w) {             // thread per contig
-    const int64_t c = k.bid * k.nthreads + k.tid;
-    if (c >= w.C) return;
-    w.nconv[c] = sel_has_graph(w, c) ? sel_plan_walk(w, c, [](int32_t, int32_t, int32_t) {}) : 0;
-}
-AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // thread per contig
-    const int64_t c = k.bid * k.nthreads + k.tid;
-    if (c >= w.C || !sel_has_graph(w, c)) return;
-    const int64_t j0 = w.conv_off[c];
-    const int32_t N = (int32_t)(w.rec_off[c + 1] - w.rec_off[c]), V = w.ctgV[c];
-    sel_plan_walk(w, c, [&](int32_t ord, int32_t kidx, int32_t kind) {
-        const int64_t j = j0 + ord;
-        w.cv_ctg[j] = (int32_t)c; w.cv_k[j] = kidx; w.cv_ord[j] = ord; w.cv_kind[j] = kind; w.cv_szr[j] = N + 2; w.cv_szv[j] = V;
-    });
+AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // one wave per contig
+    const int64_t c = k.bid;
+    if (sel_has_graph(w, c)) sel_plan_wave(k, w, c, true);
 }
 
 AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {

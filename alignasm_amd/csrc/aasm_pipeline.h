@@ -237,7 +237,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     int64_t NCONV = 0, SR = 0, SV = 0;
     if (!sequential) {
         be.phase_begin(AASM_PH_MISC);
-        if (VT > 0) be.launch(KN_SEL_PLAN, cdiv(C, 256), 256, w);
+        if (VT > 0) be.launch(KN_SEL_PLAN, C, AASM_WAVE, w);
         be.scan_i32(w.nconv, C, w.conv_off);
         NCONV = be.read_i64(w.conv_off + C);
         w.NCONV = NCONV;
@@ -246,7 +246,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             A(cv_szr, int32_t, NCONV, "cv_szr"); A(cv_szv, int32_t, NCONV, "cv_szv"); A(cv_roff, int64_t, NCONV + 1, "cv_roff"); A(cv_voff, int64_t, NCONV + 1, "cv_voff");
             AZ(cv_n, int32_t, NCONV, "cv_n"); AZ(cv_err, int32_t, NCONV, "cv_err"); AZ(cv_cov, int64_t, NCONV, "cv_cov");
             CHECK_ALLOC();
-            be.launch(KN_SEL_PLANFILL, cdiv(C, 256), 256, w);
+            be.launch(KN_SEL_PLANFILL, C, AASM_WAVE, w);
             be.scan_i32(w.cv_szr, NCONV, w.cv_roff);
             be.scan_i32(w.cv_szv, NCONV, w.cv_voff);
             SR = be.read_i64(w.cv_roff + NCONV); SV = be.read_i64(w.cv_voff + NCONV);
