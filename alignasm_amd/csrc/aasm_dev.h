@@ -107,6 +107,18 @@ AASM_DEV int64_t uni(int64_t x) {
 }
 AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
 
+// mask of the indices j in [0, n), n <= 64, for which pred(j) holds: lane j evaluates pred(j)
+template <class P> AASM_DEV uint64_t wave_index_mask(int n, int lane, P pred) {
+#if defined(AASM_HOST_EMUL)
+    uint64_t m = 0;
+    for (int j = 0; j < n; j++) if (pred(j)) m |= 1ull << j;
+    (void)lane;
+    return m;
+#else
+    return wave_ballot(lane < n && pred(lane));
+#endif
+}
+
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 
 // inclusive wave scans (Hillis-Steele over 64 lanes; identity with one lane)

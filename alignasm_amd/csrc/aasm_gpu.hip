@@ -57,7 +57,7 @@ AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
-AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_LDS_BYTES)
+AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES)
 AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_LDS_BYTES)
 AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)

@@ -915,26 +915,37 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.hcap_cnt[c] = (int32_t)cap;
 }
 
-// Cooperative K7.  The wave keeps its working set in LDS:
-//   ring[HEAP_RING]   the most recently allocated nodes (an insert walks the right spine from
-//                     the root, whose top nodes were copied by the previous inserts)
-//   stk[HEAP_STACK]   the nodes passed on the way down (so unwinding needs no reload; the
-//                     child ranks are cached inside each node)
-//   cbuf / vbuf       sidetrack costs + heads of one 64-edge chunk of the adjacency row,
-//                     computed by all lanes at once
-// Control flow is wave-uniform; every lane executes the same scalar walk (uniform loads).
+// Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index ==
+// allocation order, hazard B3) and keeps its working set in LDS:
+//   sp_*          the RIGHT SPINE of the heap the last insert produced.  80-96 % of the inserts
+//                 continue from exactly that heap, and an insert's descent path is a prefix of
+//                 its right spine, so the descent becomes ONE lane-parallel compare + ballot,
+//                 and the copied nodes of the path are built and stored by all lanes at once.
+//                 Only the rank chain (pure arithmetic, leftist_heap.hpp:36-38) stays sequential.
+//                 A rank swap at position t sends the new spine into an old left subtree: the
+//                 cache then holds positions 0..t plus the node where it continues (sp_tail);
+//                 the walk past the cached prefix (or after a root switch) chases pointers and
+//                 appends what it reads to the cache.
+//   ring          read cache of the newest nodes for that pointer chase
+//   cbuf / vbuf   sidetrack costs + heads of one 64-edge chunk of the adjacency row,
+//                 computed by all lanes at once
+//   bqv / bqh     BFS queue window: vertex + inherited heap root
+// Control flow is wave-uniform; uniform data is stored by lane 0 only (64 identical stores to
+// one address are 64 write requests into one L2 channel).
 #define HEAP_RING 32
-#define HEAP_STACK 40
+#define HEAP_SP 34
 #define HEAP_QN 128
-#define HEAP_FLUSH 16
+#define AASM_HEAP_LDS_BYTES 7168
 struct HeapLds {
-    HNode ring[HEAP_RING];          // newest nodes; [flushed, alloc) exist ONLY here
-    int32_t stk[HEAP_STACK];
+    HNode ring[HEAP_RING];
+    HNode sp_node[HEAP_SP];
+    int32_t sp_idx[HEAP_SP];
+    int32_t t_sw[HEAP_SP], t_rank[HEAP_SP], t_brank[HEAP_SP];   // unwinding results per path position
     Dist cbuf[AASM_WAVE];
     int32_t vbuf[AASM_WAVE];
-    int32_t bqv[HEAP_QN], bqh[HEAP_QN];   // BFS queue window: vertex + inherited heap root
+    int32_t bqv[HEAP_QN], bqh[HEAP_QN];
 };
-static_assert(sizeof(HeapLds) <= AASM_LDS_BYTES, "LDS budget");
+static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
 #define HI_PROF_ARGS , int64_t &kp_t0, int64_t *kp_acc
 #define HI_PROF_PASS , kp_t0, kp_acc
@@ -942,88 +953,90 @@ static_assert(sizeof(HeapLds) <= AASM_LDS_BYTES, "LDS budget");
 #define HI_PROF_ARGS
 #define HI_PROF_PASS
 #endif
-// One persistent insert (leftist_heap.hpp:29-40), instruction-lean: with 20 single-wave
-// contigs per CU this kernel is bound by instruction issue, not by memory.
-//  * nodes move as 16-byte quads; the ring read (ds_read) and the global read sit in
-//    separate uniform branches so neither degenerates into a flat access, and ring hits never
-//    wait on outstanding global stores (LDS counts on lgkmcnt, stores on vmcnt);
-//  * the descent compares score sums first (PafDistance::max() has sum -2) and only falls
-//    back to the full operator< on a sum tie; it pushes node INDICES on an LDS stack;
-//  * the unwinding re-reads each ancestor (ring hit) and rewrites three words with selects;
-//  * uniform data is stored by lane 0 only.
-// Write-back of the ring: vmcnt is in-order over loads AND stores, so a global store issued
-// just before a dependent global load makes that load wait for the store's acknowledgement.
-// New nodes therefore live in LDS only and are written back HEAP_FLUSH at a time by one
-// coalesced 768-byte store of 48 lanes.
-AASM_DEV void heap_flush(HNode *nodes, HeapLds *L, int32_t &flushed, int32_t upto, int lane) {
-    while (flushed < upto) {
-        const int32_t n = (upto - flushed < HEAP_FLUSH) ? (upto - flushed) : HEAP_FLUSH;
-        for (int32_t t = lane; t < 3 * n; t += AASM_WAVE) {
-            const int32_t node = flushed + t / 3, part = t % 3;
-            ((I4 *)&nodes[node])[part] = ((const I4 *)&L->ring[node & (HEAP_RING - 1)])[part];
-        }
-        flushed += n;
-    }
+struct SpineState { int32_t root, len, tail; };      // cache describes heap `root`; `tail` = node after the cached prefix (-1: complete)
+
+AASM_DEV NodeQ heap_read(const HNode *nodes, const HeapLds *L, int32_t a, int32_t alloc) {
+    NodeQ n;
+    if (a >= alloc - HEAP_RING) n = nodeq_load(&L->ring[a & (HEAP_RING - 1)]);      // ds_read, lgkmcnt only
+    else { n = nodeq_load(&nodes[a]); asm volatile("" ::: "memory"); }             // keep it a global_load (no flat access)
+    return n;
 }
-AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, int32_t &alloc, int32_t &flushed, int32_t cap, int32_t a, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
-    int depth = 0;
-    int32_t a_rank = 0;
+AASM_DEV bool nodeq_key_lt(const NodeQ &n, const Dist &key, int64_t ksum) {          // node.key < key (paf_data.hpp:142-159)
+    const Dist nk = nodeq_key(n);
+    const int64_t nsum = nk.qry + nk.ref;
+    if (nsum != ksum && nsum != -2 && ksum != -2) return nsum < ksum;                // neither side is max() (score sum -2)
+    return dist_lt<CALC_SUM_MODE>(nk, key);
+}
+
+// One persistent insert (leftist_heap.hpp:29-40) into heap `hu`; returns the new root.
+AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, SpineState &sp, int32_t &alloc, int32_t cap, int32_t hu, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
     const int64_t ksum = key.qry + key.ref;
-    while (a >= 0) {                                                        // leftist_heap.hpp:30
-        I4 q0, q1;
-        int32_t right;
-        if (a >= alloc - HEAP_RING) { const HNode *p = &L->ring[a & (HEAP_RING - 1)]; q0 = ((const I4 *)p)[0]; q1 = ((const I4 *)p)[1]; right = p->right; }
-        else { const HNode *p = &nodes[a]; q0 = ((const I4 *)p)[0]; q1 = ((const I4 *)p)[1]; right = p->right; asm volatile("" ::: "memory"); }
-#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-        if (a >= alloc - HEAP_RING) kp_acc[6]++; else kp_acc[7]++;
-#endif
-        NodeQ n; n.q0 = q0; n.q1 = q1;
-        const Dist nk = nodeq_key(n);
-        const int64_t nsum = nk.qry + nk.ref;
-        bool lt;
-        if (nsum != ksum && nsum != -2 && ksum != -2) lt = nsum < ksum;      // paf_data.hpp:142-149, neither side is max()
-        else lt = dist_lt<CALC_SUM_MODE>(nk, key);
-        if (!uni(lt)) { a_rank = q1.w & 0xff; break; }
-        if (depth >= HEAP_STACK) { ovf = true; return -1; }
-        if (lane == 0) L->stk[depth] = a;
-        depth++;
-        a = uni(right);
+    if (hu != sp.root) { sp.root = hu; sp.len = 0; sp.tail = hu; }                   // root switch: nothing cached yet
+    // ---- descent (:30): first spine position whose key is NOT < key
+    int32_t depth = -1, a_stop = -1, a_rank = 0;
+    if (sp.len > 0) {
+        const uint64_t m = wave_index_mask(sp.len, lane, [&](int j) { return !nodeq_key_lt(nodeq_load(&L->sp_node[j]), key, ksum); });
+        if (m) { depth = ffs64(m) - 1; a_stop = uni(L->sp_idx[depth]); a_rank = uni(L->sp_node[depth].rank) & 0xff; }
     }
-    KPROF_STAMP(4);                                                         // descent
+    if (depth < 0) {                                                                // past the cached prefix: chase and extend the cache
+        depth = sp.len;
+        int32_t a = sp.tail;
+        while (a >= 0) {
+            const NodeQ n = uni(heap_read(nodes, L, a, alloc));
+            if (!nodeq_key_lt(n, key, ksum)) { a_rank = n.q1.w & 0xff; break; }
+            if (depth >= HEAP_SP - 1) { ovf = true; return -1; }
+            if (lane == 0) { nodeq_store(&L->sp_node[depth], n); L->sp_idx[depth] = a; }
+            depth++;
+            a = n.q2.y;                                                             // ->right
+        }
+        a_stop = a;
+        block_sync();
+    }
+    KPROF_STAMP(4);                                                                 // descent
     if (alloc + depth + 1 > cap) { ovf = true; return -1; }
-    if (alloc - flushed >= HEAP_RING) { block_sync(); heap_flush(nodes, L, flushed, flushed + HEAP_FLUSH, lane); }
-    int32_t r = alloc;
-    if (lane == 0) {                                                        // :31-32: (1, k, v, left = a, right = null)
-        NodeQ n;
-        n.q0.x = (int32_t)(uint32_t)(uint64_t)key.qry; n.q0.y = (int32_t)((uint64_t)key.qry >> 32);
-        n.q0.z = (int32_t)(uint32_t)(uint64_t)key.ref; n.q0.w = (int32_t)((uint64_t)key.ref >> 32);
-        n.q1.x = key.anom; n.q1.y = key.qnz; n.q1.z = key.qtot; n.q1.w = 1 | (a_rank << 8);
-        n.q2.x = a; n.q2.y = -1; n.q2.z = eu; n.q2.w = ev;
-        nodeq_store(&L->ring[r & (HEAP_RING - 1)], n);
-    }
-    alloc++;
-    int32_t r_rank = 1;
-    while (depth > 0) {                                                     // :34-39, unwound
-        --depth;
-        const int32_t anc = uni(L->stk[depth]);
-        NodeQ n;
-        if (anc >= alloc - HEAP_RING) n = nodeq_load(&L->ring[anc & (HEAP_RING - 1)]);
-        else { n = nodeq_load(&nodes[anc]); asm volatile("" ::: "memory"); }
-        const int32_t l = n.q2.x, l_rank = (n.q1.w >> 8) & 0xff;
-        const bool sw = (l < 0) || (l_rank < r_rank);                       // :36-37
-        const int32_t nl = sw ? r : l, nrr = sw ? l : r;
-        const int32_t nl_rank = sw ? r_rank : l_rank, nr_rank = (nrr >= 0) ? (sw ? l_rank : r_rank) : 0;
-        const int32_t nrank = (nrr >= 0) ? nr_rank + 1 : 0;                 // :38
-        n.q2.x = nl; n.q2.y = nrr;
-        n.q1.w = nrank | (nl_rank << 8) | (nr_rank << 16);
-        if (alloc - flushed >= HEAP_RING) { block_sync(); heap_flush(nodes, L, flushed, flushed + HEAP_FLUSH, lane); }
-        r = alloc;
-        if (lane == 0) nodeq_store(&L->ring[r & (HEAP_RING - 1)], n);
-        alloc++;
+    // ---- rank chain, bottom-up (:34-38): pure arithmetic on the cached path
+    int32_t r_rank = 1;                                                             // the new leaf has rank 1 (:31)
+    for (int32_t j = depth - 1; j >= 0; j--) {
+        const int32_t l = uni(L->sp_node[j].left), l_rank = (uni(L->sp_node[j].rank) >> 8) & 0xff;
+        const bool sw = (l < 0) || (l_rank < r_rank);                               // :36-37
+        const bool has_right = sw ? (l >= 0) : true;
+        const int32_t nr_rank = has_right ? (sw ? l_rank : r_rank) : 0;
+        const int32_t nrank = has_right ? nr_rank + 1 : 0;                          // :38
+        if (lane == 0) { L->t_sw[j] = sw ? 1 : 0; L->t_rank[j] = nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16); L->t_brank[j] = r_rank; }
         r_rank = nrank;
     }
-    KPROF_STAMP(5);                                                         // leaf + unwinding stores
-    return r;
+    block_sync();
+    // ---- new nodes: leaf = alloc, copy of path position j = alloc + (depth - j)  (allocation order of the recursion)
+    for (int32_t j = lane; j <= depth; j += AASM_WAVE) {
+        NodeQ n;
+        int32_t ni;
+        if (j == depth) {                                                           // :31-32: (1, k, v, left = a, right = null)
+            ni = alloc;
+            n.q0.x = (int32_t)(uint32_t)(uint64_t)key.qry; n.q0.y = (int32_t)((uint64_t)key.qry >> 32);
+            n.q0.z = (int32_t)(uint32_t)(uint64_t)key.ref; n.q0.w = (int32_t)((uint64_t)key.ref >> 32);
+            n.q1.x = key.anom; n.q1.y = key.qnz; n.q1.z = key.qtot; n.q1.w = 1 | (a_rank << 8);
+            n.q2.x = a_stop; n.q2.y = -1; n.q2.z = eu; n.q2.w = ev;
+        } else {
+            ni = alloc + (depth - j);
+            n = nodeq_load(&L->sp_node[j]);
+            const int32_t below = ni - 1, l = n.q2.x;
+            const bool sw = L->t_sw[j] != 0;
+            n.q2.x = sw ? below : l; n.q2.y = sw ? l : below;
+            n.q1.w = L->t_rank[j];
+        }
+        nodeq_store(&nodes[ni], n);
+        nodeq_store(&L->ring[ni & (HEAP_RING - 1)], n);
+        if (j < HEAP_SP) { nodeq_store(&L->sp_node[j], n); L->sp_idx[j] = ni; }     // position j of the NEW spine (valid up to the first swap)
+    }
+    block_sync();
+    // ---- spine of the new heap: new nodes down to the first swapped position, then its old left subtree
+    const uint64_t swm = wave_index_mask(depth, lane, [&](int j) { return L->t_sw[j] != 0; });
+    if (swm) { const int t = ffs64(swm) - 1; sp.len = t + 1; sp.tail = uni(L->sp_node[t].right); }
+    else { sp.len = depth + 1; sp.tail = -1; }                                      // ... or all of them and the leaf (right == null)
+    sp.root = alloc + depth;
+    alloc += depth + 1;
+    KPROF_STAMP(5);                                                                 // chain + node construction
+    return sp.root;
 }
 
 AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
@@ -1040,7 +1053,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (k.lane == 0) w.h_cnt[c] = 0;
     if (dist_is_max(d[src])) { if (k.lane == 0) set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
-    int32_t alloc = 0, flushed = 0, head = 0, tail = 1, lds_hi = 1;
+    int32_t alloc = 0, head = 0, tail = 1, lds_hi = 1;
+    SpineState sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     bool ovf = false;
     if (k.lane == 0) { q[0] = dest; h[dest] = -1; L->bqv[0] = dest; L->bqh[0] = -1; }
     block_sync();
@@ -1082,7 +1096,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
                 const int t = ffs64(vm) - 1;
                 vm &= vm - 1;
                 const Dist cc = uni(L->cbuf[t]);
-                hu = heap_insert(nodes, L, alloc, flushed, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
+                hu = heap_insert(nodes, L, sp, alloc, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
             }
             block_sync();                                            // before the next chunk overwrites cbuf
             KPROF_STAMP(2);                                          // inserts
@@ -1102,8 +1116,6 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         block_sync();
         KPROF_STAMP(3);                                              // children
     }
-    block_sync();
-    heap_flush(nodes, L, flushed, alloc, k.lane);
     KPROF_FLUSH(w.prof_heap, c, k.lane);
     if (ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
     if (k.lane == 0) { w.h_cnt[c] = alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)alloc); }
