@@ -48,13 +48,18 @@ EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
     "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_parse_mem", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
-    "aasm_paf_write_outputs", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text",
+    "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
 
 def _check(rc):
     if rc != AASM_OK:
         raise AlignasmError(rc, (LIB.aasm_last_error() or b"").decode(errors="replace"))
+
+
+def set_host_threads(n):
+    """Threads of the PAF reader / writers (0 = all); returns the previous setting."""
+    return int(LIB.aasm_set_host_threads(int(n)))
 
 
 def device_count():
@@ -117,6 +122,10 @@ class Paf:
             return C.string_at(p, n.value)
         finally:
             C.CDLL(None).free(p)
+
+    def save(self, path):
+        """Write the batch as PAF text (rows with cs tags) to `path`."""
+        _check(LIB.aasm_paf_save(self._h, os.fsencode(path)))
 
     def write_outputs(self, out: BatchOut, main_path, alt_path, all_path):
         _check(LIB.aasm_paf_write_outputs(self._h, C.byref(out), os.fsencode(main_path), os.fsencode(alt_path), os.fsencode(all_path)))

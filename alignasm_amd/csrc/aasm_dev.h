@@ -41,7 +41,7 @@ AASM_DEV uint64_t wave_ballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> AASM_DEV T wave_bcast(T x, int) { return x; }
 template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return fill; }
 template <class T> AASM_DEV T wave_shfl_xor(T x, int) { return x; }
-AASM_DEV void block_sync() {}
+AASM_DEV void wave_lds_sync() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
 AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
@@ -68,7 +68,11 @@ AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
     int lo = __shfl_xor((int)(x & 0xffffffffll), m, 64), hi = __shfl_xor((int)(x >> 32), m, 64);
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
-AASM_DEV void block_sync() { __syncthreads(); }
+// LDS hand-off between the lanes of ONE wave (every kernel that uses it runs one wave per
+// workgroup): the DS instructions of a wave execute in issue order, so only the compiler has to
+// keep them in order.  __syncthreads() would also drain every outstanding global store
+// (s_waitcnt vmcnt(0)), a full memory round trip per call.
+AASM_DEV void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // order this wave's global-memory writes before its later reads (same CU, same L1)
 AASM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 template <class T> AASM_DEV T atomic_add(T *p, T v) { return atomicAdd(p, v); }
@@ -106,6 +110,24 @@ AASM_DEV int64_t uni(int64_t x) {
     return (int64_t)(((uint64_t)(uint32_t)uni((int32_t)((uint64_t)x >> 32)) << 32) | (uint32_t)uni((int32_t)(uint32_t)(uint64_t)x));
 }
 AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
+
+#define AASM_WAVE_MAX 64
+// LaneArr<T>: an array of <= 64 elements held one per lane in registers (element j lives in
+// lane j).  The 1-lane host emulation keeps a real array, so the same source runs in both.
+//   FOR_LANE(j, n, lane) { ... a.at(j) ... }   every element j < n, all at once on the GPU
+//   LA_GET(a, j, .field)                         read element j (wave-uniform j) into a scalar
+//   LA_SET(a, j, lane, value)                    write element j (wave-uniform j)
+#if defined(AASM_HOST_EMUL)
+template <class T> struct LaneArr { T a[AASM_WAVE_MAX]; AASM_MEM T &at(int j) { return a[j]; } };
+#define FOR_LANE(j, n, lane) for (int j = 0; j < (n); j++)
+#define LA_GET(arr, j, field) ((arr).a[j] field)
+#define LA_SET(arr, j, lane, value) ((arr).a[j] = (value))
+#else
+template <class T> struct LaneArr { T r; AASM_MEM T &at(int) { return r; } };
+#define FOR_LANE(j, n, lane) for (int j = (lane), _fl_once = 1; _fl_once && j < (n); _fl_once = 0)
+#define LA_GET(arr, j, field) __builtin_amdgcn_readlane((arr).r field, (j))
+#define LA_SET(arr, j, lane, value) do { if ((lane) == (j)) (arr).r = (value); } while (0)
+#endif
 
 // mask of the indices j in [0, n), n <= 64, for which pred(j) holds: lane j evaluates pred(j)
 template <class P> AASM_DEV uint64_t wave_index_mask(int n, int lane, P pred) {

@@ -916,31 +916,28 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index ==
-// allocation order, hazard B3) and keeps its working set in LDS:
-//   sp_*          the RIGHT SPINE of the heap the last insert produced.  80-96 % of the inserts
-//                 continue from exactly that heap, and an insert's descent path is a prefix of
-//                 its right spine, so the descent becomes ONE lane-parallel compare + ballot,
-//                 and the copied nodes of the path are built and stored by all lanes at once.
-//                 Only the rank chain (pure arithmetic, leftist_heap.hpp:36-38) stays sequential.
-//                 A rank swap at position t sends the new spine into an old left subtree: the
-//                 cache then holds positions 0..t plus the node where it continues (sp_tail);
-//                 the walk past the cached prefix (or after a root switch) chases pointers and
-//                 appends what it reads to the cache.
-//   ring          read cache of the newest nodes for that pointer chase
+// allocation order, hazard B3).  Its working set:
+//   spine (registers)  the RIGHT SPINE of the heap the last insert produced, one node per lane
+//                 (lane j = j-th node from the root).  80-96 % of the inserts continue from
+//                 exactly that heap, and an insert's descent path is a prefix of its right
+//                 spine, so the descent is ONE lane-parallel compare + ballot and the copied
+//                 nodes of the path are built and stored by all lanes at once.  Only the rank
+//                 chain (pure arithmetic, leftist_heap.hpp:36-38) is sequential, on scalars
+//                 read with v_readlane.  A rank swap at position t sends the new spine into an
+//                 old left subtree: the cache then holds positions 0..t plus the node where it
+//                 continues (tail); the walk past the cached prefix (or after a root switch)
+//                 chases pointers and appends what it reads to the cache.
+//   ring (LDS)    read cache of the newest nodes for that pointer chase
 //   cbuf / vbuf   sidetrack costs + heads of one 64-edge chunk of the adjacency row,
 //                 computed by all lanes at once
 //   bqv / bqh     BFS queue window: vertex + inherited heap root
 // Control flow is wave-uniform; uniform data is stored by lane 0 only (64 identical stores to
 // one address are 64 write requests into one L2 channel).
 #define HEAP_RING 32
-#define HEAP_SP 34
 #define HEAP_QN 128
-#define AASM_HEAP_LDS_BYTES 7168
+#define AASM_HEAP_LDS_BYTES 6144
 struct HeapLds {
     HNode ring[HEAP_RING];
-    HNode sp_node[HEAP_SP];
-    int32_t sp_idx[HEAP_SP];
-    int32_t t_sw[HEAP_SP], t_rank[HEAP_SP], t_brank[HEAP_SP];   // unwinding results per path position
     Dist cbuf[AASM_WAVE];
     int32_t vbuf[AASM_WAVE];
     int32_t bqv[HEAP_QN], bqh[HEAP_QN];
@@ -953,7 +950,12 @@ static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
 #define HI_PROF_ARGS
 #define HI_PROF_PASS
 #endif
-struct SpineState { int32_t root, len, tail; };      // cache describes heap `root`; `tail` = node after the cached prefix (-1: complete)
+struct Spine {
+    LaneArr<NodeQ> n;          // cached nodes, position j in lane j
+    LaneArr<int32_t> idx;      // their arena indices
+    LaneArr<int32_t> t;        // unwinding result of position j: rank word | swapped << 24
+    int32_t root, len, tail;   // heap the cache describes; cached positions; node after them (-1: the spine ends)
+};
 
 AASM_DEV NodeQ heap_read(const HNode *nodes, const HeapLds *L, int32_t a, int32_t alloc) {
     NodeQ n;
@@ -969,14 +971,14 @@ AASM_DEV bool nodeq_key_lt(const NodeQ &n, const Dist &key, int64_t ksum) {     
 }
 
 // One persistent insert (leftist_heap.hpp:29-40) into heap `hu`; returns the new root.
-AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, SpineState &sp, int32_t &alloc, int32_t cap, int32_t hu, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
+AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, Spine &sp, int32_t &alloc, int32_t cap, int32_t hu, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
     const int64_t ksum = key.qry + key.ref;
     if (hu != sp.root) { sp.root = hu; sp.len = 0; sp.tail = hu; }                   // root switch: nothing cached yet
     // ---- descent (:30): first spine position whose key is NOT < key
     int32_t depth = -1, a_stop = -1, a_rank = 0;
     if (sp.len > 0) {
-        const uint64_t m = wave_index_mask(sp.len, lane, [&](int j) { return !nodeq_key_lt(nodeq_load(&L->sp_node[j]), key, ksum); });
-        if (m) { depth = ffs64(m) - 1; a_stop = uni(L->sp_idx[depth]); a_rank = uni(L->sp_node[depth].rank) & 0xff; }
+        const uint64_t m = wave_index_mask(sp.len, lane, [&](int j) { return !nodeq_key_lt(sp.n.at(j), key, ksum); });
+        if (m) { depth = ffs64(m) - 1; a_stop = LA_GET(sp.idx, depth, ); a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; }
     }
     if (depth < 0) {                                                                // past the cached prefix: chase and extend the cache
         depth = sp.len;
@@ -984,30 +986,30 @@ AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, SpineState &sp, int32_t &
         while (a >= 0) {
             const NodeQ n = uni(heap_read(nodes, L, a, alloc));
             if (!nodeq_key_lt(n, key, ksum)) { a_rank = n.q1.w & 0xff; break; }
-            if (depth >= HEAP_SP - 1) { ovf = true; return -1; }
-            if (lane == 0) { nodeq_store(&L->sp_node[depth], n); L->sp_idx[depth] = a; }
+            if (depth >= AASM_WAVE_MAX - 2) { ovf = true; return -1; }
+            LA_SET(sp.n, depth, lane, n);
+            LA_SET(sp.idx, depth, lane, a);
             depth++;
             a = n.q2.y;                                                             // ->right
         }
         a_stop = a;
-        block_sync();
     }
     KPROF_STAMP(4);                                                                 // descent
     if (alloc + depth + 1 > cap) { ovf = true; return -1; }
-    // ---- rank chain, bottom-up (:34-38): pure arithmetic on the cached path
+    // ---- rank chain, bottom-up (:34-38): scalar arithmetic on the cached path
     int32_t r_rank = 1;                                                             // the new leaf has rank 1 (:31)
     for (int32_t j = depth - 1; j >= 0; j--) {
-        const int32_t l = uni(L->sp_node[j].left), l_rank = (uni(L->sp_node[j].rank) >> 8) & 0xff;
+        const int32_t l = LA_GET(sp.n, j, .q2.x), l_rank = (LA_GET(sp.n, j, .q1.w) >> 8) & 0xff;
         const bool sw = (l < 0) || (l_rank < r_rank);                               // :36-37
         const bool has_right = sw ? (l >= 0) : true;
         const int32_t nr_rank = has_right ? (sw ? l_rank : r_rank) : 0;
         const int32_t nrank = has_right ? nr_rank + 1 : 0;                          // :38
-        if (lane == 0) { L->t_sw[j] = sw ? 1 : 0; L->t_rank[j] = nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16); L->t_brank[j] = r_rank; }
+        LA_SET(sp.t, j, lane, nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16) | ((sw ? 1 : 0) << 24));
         r_rank = nrank;
     }
-    block_sync();
     // ---- new nodes: leaf = alloc, copy of path position j = alloc + (depth - j)  (allocation order of the recursion)
-    for (int32_t j = lane; j <= depth; j += AASM_WAVE) {
+    const int32_t nalloc = alloc + depth + 1;
+    FOR_LANE(j, depth + 1, lane) {
         NodeQ n;
         int32_t ni;
         if (j == depth) {                                                           // :31-32: (1, k, v, left = a, right = null)
@@ -1016,25 +1018,26 @@ AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, SpineState &sp, int32_t &
             n.q0.z = (int32_t)(uint32_t)(uint64_t)key.ref; n.q0.w = (int32_t)((uint64_t)key.ref >> 32);
             n.q1.x = key.anom; n.q1.y = key.qnz; n.q1.z = key.qtot; n.q1.w = 1 | (a_rank << 8);
             n.q2.x = a_stop; n.q2.y = -1; n.q2.z = eu; n.q2.w = ev;
+            sp.t.at(j) = 0;
         } else {
             ni = alloc + (depth - j);
-            n = nodeq_load(&L->sp_node[j]);
-            const int32_t below = ni - 1, l = n.q2.x;
-            const bool sw = L->t_sw[j] != 0;
+            n = sp.n.at(j);
+            const int32_t below = ni - 1, l = n.q2.x, tw = sp.t.at(j);
+            const bool sw = (tw >> 24) != 0;
             n.q2.x = sw ? below : l; n.q2.y = sw ? l : below;
-            n.q1.w = L->t_rank[j];
+            n.q1.w = tw & 0xffffff;
         }
         nodeq_store(&nodes[ni], n);
-        nodeq_store(&L->ring[ni & (HEAP_RING - 1)], n);
-        if (j < HEAP_SP) { nodeq_store(&L->sp_node[j], n); L->sp_idx[j] = ni; }     // position j of the NEW spine (valid up to the first swap)
+        if (ni >= nalloc - HEAP_RING) nodeq_store(&L->ring[ni & (HEAP_RING - 1)], n);
+        sp.n.at(j) = n; sp.idx.at(j) = ni;                                          // position j of the NEW spine (valid up to the first swap)
     }
-    block_sync();
+    wave_lds_sync();                                                                   // ring visible
     // ---- spine of the new heap: new nodes down to the first swapped position, then its old left subtree
-    const uint64_t swm = wave_index_mask(depth, lane, [&](int j) { return L->t_sw[j] != 0; });
-    if (swm) { const int t = ffs64(swm) - 1; sp.len = t + 1; sp.tail = uni(L->sp_node[t].right); }
+    const uint64_t swm = wave_index_mask(depth, lane, [&](int j) { return (sp.t.at(j) >> 24) != 0; });
+    if (swm) { const int t = ffs64(swm) - 1; sp.len = t + 1; sp.tail = LA_GET(sp.n, t, .q2.y); }
     else { sp.len = depth + 1; sp.tail = -1; }                                      // ... or all of them and the leaf (right == null)
     sp.root = alloc + depth;
-    alloc += depth + 1;
+    alloc = nalloc;
     KPROF_STAMP(5);                                                                 // chain + node construction
     return sp.root;
 }
@@ -1054,10 +1057,10 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     if (k.lane == 0) w.h_cnt[c] = 0;
     if (dist_is_max(d[src])) { if (k.lane == 0) set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
     int32_t alloc = 0, head = 0, tail = 1, lds_hi = 1;
-    SpineState sp; sp.root = -2; sp.len = 0; sp.tail = -1;
+    Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     bool ovf = false;
     if (k.lane == 0) { q[0] = dest; h[dest] = -1; L->bqv[0] = dest; L->bqh[0] = -1; }
-    block_sync();
+    wave_lds_sync();
     KPROF_DECL;
     KPROF_START();
     while (head < tail && !ovf) {
@@ -1085,7 +1088,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
                     L->vbuf[k.lane] = v;
                 }
             }
-            block_sync();                                            // cbuf/vbuf visible to every lane
+            wave_lds_sync();                                            // cbuf/vbuf visible to every lane
             KPROF_STAMP(1);                                          // row chunk loads + costs
             if (!seen_p) {                                           // skip the tree edge once (:207-210)
                 const uint64_t tm = wave_ballot(tree);
@@ -1098,7 +1101,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
                 const Dist cc = uni(L->cbuf[t]);
                 hu = heap_insert(nodes, L, sp, alloc, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
             }
-            block_sync();                                            // before the next chunk overwrites cbuf
+            wave_lds_sync();                                            // before the next chunk overwrites cbuf
             KPROF_STAMP(2);                                          // inserts
         }
         if (k.lane == 0) h[u] = hu;
@@ -1113,7 +1116,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         }
         lds_hi += ncache;
         tail += nch;
-        block_sync();
+        wave_lds_sync();
         KPROF_STAMP(3);                                              // children
     }
     KPROF_FLUSH(w.prof_heap, c, k.lane);
@@ -1187,7 +1190,7 @@ AASM_DEV void pq8_push(Pq8 &q, const PQEnt &x, int lane) {
         i = p;
     }
     pq8_set(q, i, x, lane);
-    block_sync();
+    wave_lds_sync();
 }
 AASM_DEV PQEnt pq8_pop(Pq8 &q, int lane) {
     const PQEnt top = pq8_get(q, 0);
@@ -1216,10 +1219,10 @@ AASM_DEV PQEnt pq8_pop(Pq8 &q, int lane) {
         const PQEnt be = pqent_bcast(mine, AASM_WAVE > 1 ? bslot : 0);  // winner's entry straight from its lane
         pq8_set(q, i, be, lane);
         i = c0 + bslot;
-        block_sync();
+        wave_lds_sync();
     }
     pq8_set(q, i, x, lane);
-    block_sync();
+    wave_lds_sync();
     return top;
 }
 
@@ -1328,11 +1331,11 @@ static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
     SelLds *L = (SelLds *)s.lds;
-    block_sync();
+    wave_lds_sync();
     const int32_t n = s.out_n - s.out_flushed;
     for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) s.out_dst[2 * s.out_flushed + t] = L->pb_buf[t];
     s.out_flushed = s.out_n;
-    block_sync();
+    wave_lds_sync();
 }
 AASM_DEV void sel_out_begin(SelCtx &s, int32_t *dst) { s.out_dst = dst; s.out_n = 0; s.out_flushed = 0; }
 AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
@@ -1347,11 +1350,11 @@ AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
 AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v) {
     SelLds *L = (SelLds *)s.lds;
     if (it < s.pa_base || it >= s.pa_base + SEL_WIN) {
-        block_sync();
+        wave_lds_sync();
         s.pa_base = it;
         const int32_t n = (la - it < SEL_WIN) ? (la - it) : SEL_WIN;
         for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) L->pa_win[t] = s.pathA[2 * it + t];
-        block_sync();
+        wave_lds_sync();
     }
     u = uni(L->pa_win[2 * (it - s.pa_base)]); v = uni(L->pa_win[2 * (it - s.pa_base) + 1]);
 }
@@ -1475,7 +1478,7 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     SPROF(s, 2);                                                     // ISPR staging
     for (int32_t t = s.lane; t <= W; t += AASM_WAVE) L->reach[t] = (t == 0) ? 1 : 0;
     if (s.lane == 0) { L->dist[0] = dist_zero(); L->pre[0] = -1; }
-    block_sync();
+    wave_lds_sync();
     // DP over the window, source by source
     for (int32_t t = 0; t < W; t++) {
         if (!uni((int32_t)L->reach[t])) continue;
@@ -1489,7 +1492,7 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
             const Dist nd = dist_add(cd, edge_dist(L->wq[idx], L->wr[idx], L->fl[idx]));
             if (!L->reach[tg] || dist_lt<QRY_SCORE_MODE>(nd, L->dist[tg])) { L->dist[tg] = nd; L->pre[tg] = (int8_t)t; L->reach[tg] = 1; }
         }
-        block_sync();
+        wave_lds_sync();
     }
     SPROF(s, 3);                                                     // ISPR DP on LDS
     if (!uni((int32_t)L->reach[W])) { s.err = true; return -1; }     // :783
@@ -1502,7 +1505,7 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
         last = pv;
     }
     s.res_lds = true;
-    block_sync();
+    wave_lds_sync();
     SPROF(s, 4);                                                     // ISPR backtrack
     return n;
 }

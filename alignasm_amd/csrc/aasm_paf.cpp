@@ -18,7 +18,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <string_view>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
+#include <climits>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace aasm {
 
@@ -71,9 +78,9 @@ bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::st
 }
 
 // paf_data.cpp:90-123.  Appends ranges; returns count or -1.
+template <class VEC>
 static int64_t match_ranges(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end,
-                            int64_t ref_str, int64_t ref_end, std::vector<int64_t> *ql, std::vector<int64_t> *qr,
-                            std::vector<int64_t> *rl, std::vector<CsOp> &ops, std::string &err) {
+                            int64_t ref_str, int64_t ref_end, VEC *ql, VEC *qr, VEC *rl, std::vector<CsOp> &ops, std::string &err) {
     if (!parse_short_cs(cs, cs_len, ops, err)) return -1;
     const int64_t ref_step = aln_fwd ? 1 : -1;
     int64_t ref_index = ref_str, qry_index = qry_str, n = 0;
@@ -221,7 +228,7 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
             paf.ref_chr.push_back(chr_id); paf.mat_num.push_back((int32_t)mat); paf.aln_len.push_back((int32_t)aln);
             paf.row_index.push_back(row_global_index); paf.cord_type.push_back(0);
             paf.aln_fwd.push_back(fwd ? 1 : 0); paf.map_qul.push_back((uint8_t)mq);
-            paf.cs_pool.append(cs.data(), cs.size());
+            paf.cs_pool.insert(paf.cs_pool.end(), cs.data(), cs.data() + cs.size());
             paf.cs_off.push_back((int64_t)paf.cs_pool.size());
             row_global_index++;
         }
@@ -230,6 +237,225 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
     if (paf.n_records() == 0) { paf.error = "empty PAF"; return AASM_E_PARSE; }
     paf.ctg_name.push_back(ctg_chr);                                   // :180-181
     paf.ctg_rec_off.push_back(paf.n_records());
+    return AASM_OK;
+}
+
+// ---- parallel reader -------------------------------------------------------------------
+// Same result as parse_text(), built for whole-genome files (GBs of cs text): the file is cut
+// at line boundaries into one chunk per host thread.  Pass 1 indexes every row (line start,
+// cs field) and counts its match ranges (= ':' operations), which fixes every offset in the
+// final arrays; pass 2 parses rows straight into those arrays with a fused cs scanner that
+// allocates nothing.  Anything the fast path does not recognise as a well-formed row sends the
+// whole file through parse_text(), which owns the error messages and the odd cases.
+static std::atomic<int> g_host_threads{0};
+int host_threads() {
+    int n = g_host_threads.load();
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n <= 0) n = 1; if (n > 64) n = 64; }
+    return n;
+}
+
+static inline bool alpha_ascii(char c) { return (unsigned)(((unsigned char)c | 32) - 'a') < 26u; }   // isalpha, "C" locale
+static inline bool fast_i64(const char *s, const char *e, int64_t &v) {       // [-]digits, <= 18 of them
+    bool neg = false;
+    if (s < e && *s == '-') { neg = true; s++; }
+    const int64_t n = e - s;
+    if (n <= 0 || n > 18) return false;
+    int64_t x = 0;
+    for (; s < e; s++) { const unsigned d = (unsigned)(*s - '0'); if (d > 9) return false; x = x * 10 + d; }
+    v = neg ? -x : x;
+    return true;
+}
+static inline bool field_i64(const char *s, const char *e, int64_t &v) {
+    return fast_i64(s, e, v) || parse_i64(std::string_view(s, (size_t)(e - s)), v);
+}
+
+// get_overlap_range (paf_data.cpp:90-123) fused with the tokenizer (:29-72): walks the cs text
+// once and writes the ranges in query order.  For a '-' strand row the reference visits the
+// operations last to first; walking them first to last from the query END gives the same
+// ranges in reverse, so they are written and then flipped in place.  Returns the count, or -1.
+static int64_t fast_ranges(const char *p, const char *e, bool fwd, int64_t qs, int64_t qe, int64_t rs, int64_t re,
+                           int64_t *ql, int64_t *qr, int64_t *rl) {
+    int64_t n = 0;
+    int64_t q = fwd ? qs : qe + 1, r = fwd ? rs : re;     // fwd: next query / ref base; rev: query end (exclusive) / lowest ref base not yet consumed
+    while (p < e) {
+        const char t = *p++;
+        if (t == ':') {
+            int64_t len = 0;
+            const char *d0 = p;
+            while (p < e && (unsigned)(*p - '0') <= 9u) { len = len * 10 + (*p - '0'); p++; }
+            if (p == d0 || p - d0 > 18 || len <= 0) return -1;
+            if (fwd) { ql[n] = q; qr[n] = q + len - 1; rl[n] = r; q += len; r += len; }
+            else { ql[n] = q - len; qr[n] = q - 1; rl[n] = r + len - 1; q -= len; r += len; }
+            n++;
+        } else if (t == '*') {
+            if (p + 2 > e || !alpha_ascii(p[0]) || !alpha_ascii(p[1])) return -1;
+            p += 2;
+            if (fwd) { q++; r++; } else { q--; r++; }
+        } else if (t == '+' || t == '-') {
+            const char *s0 = p;
+            while (p < e && alpha_ascii(*p)) p++;
+            const int64_t len = p - s0;
+            if (len == 0) return -1;
+            if (t == '+') q += fwd ? len : -len; else r += len;
+        } else return -1;
+    }
+    if (fwd ? (q != qe + 1 || r != re + 1) : (q != qs || r != rs + 1)) return -1;   // :119-122
+    if (!fwd)
+        for (int64_t a = 0, b = n - 1; a < b; a++, b--) { std::swap(ql[a], ql[b]); std::swap(qr[a], qr[b]); std::swap(rl[a], rl[b]); }
+    return n;
+}
+
+struct RowIdx { int64_t line, cs; int32_t line_len, cs_len; };
+struct ReadChunk {
+    int64_t b = 0, e = 0;                      // byte range (whole lines)
+    std::vector<RowIdx> rows;
+    int64_t n_ranges = 0, cs_bytes = 0;
+    bool bad = false;
+    // pass 2
+    std::vector<std::string_view> chr_names;   // first-appearance order inside the chunk
+    std::vector<std::pair<std::string_view, int64_t>> runs;   // (query name, first global row) of each run of equal names
+};
+
+static void read_pass1(const char *text, ReadChunk &ck) {
+    int64_t p = ck.b;
+    while (p < ck.e) {
+        const char *nl = (const char *)std::memchr(text + p, '\n', (size_t)(ck.e - p));
+        const int64_t e = nl ? (nl - text) : ck.e;
+        int64_t le = e;
+        if (le > p && text[le - 1] == '\r') le--;
+        if (le > p) {
+            // the 12 mandatory columns, then the first tag that starts with cs:Z: (find_cs_tag, alignasm.cpp:100-108)
+            const char *f = text + p, *end = text + le;
+            int nf = 0;
+            while (nf < 12) { const char *t = (const char *)std::memchr(f, '\t', (size_t)(end - f)); if (!t) break; f = t + 1; nf++; }
+            const char *cs = nullptr, *cs_end = nullptr;
+            if (nf == 12) {
+                while (f < end) {
+                    const char *t = (const char *)std::memchr(f, '\t', (size_t)(end - f));
+                    const char *fe = t ? t : end;
+                    if (fe - f >= 5 && std::memcmp(f, "cs:Z:", 5) == 0) { cs = f; cs_end = fe; break; }
+                    if (!t) break;
+                    f = t + 1;
+                }
+            }
+            if (!cs || le - p > INT32_MAX) { ck.bad = true; return; }
+            int64_t colons = 0;
+            for (const char *c = cs + 5; c < cs_end; c++) colons += (*c == ':');
+            ck.rows.push_back(RowIdx{p, (int64_t)(cs - text), (int32_t)(le - p), (int32_t)(cs_end - cs)});
+            ck.n_ranges += colons;
+            ck.cs_bytes += cs_end - cs;
+        }
+        p = e + 1;
+    }
+}
+
+static void read_pass2(const char *text, ReadChunk &ck, aasm_paf &paf, int64_t row0, int64_t rng0, int64_t cs0) {
+    std::unordered_map<std::string_view, int32_t> chr_map;
+    std::string_view last_chr, cur_ctg;
+    int32_t last_chr_id = -1;
+    bool have_ctg = false;
+    int64_t ro = rng0, co = cs0;
+    int64_t *QL = paf.rng_qry_l.data(), *QR = paf.rng_qry_r.data(), *RL = paf.rng_ref_l.data();
+    for (size_t i = 0; i < ck.rows.size(); i++) {
+        const RowIdx &ri = ck.rows[i];
+        const int64_t g = row0 + (int64_t)i;
+        const char *f[13];
+        const char *c = text + ri.line, *end = c + ri.line_len;
+        f[0] = c;
+        for (int k = 1; k <= 12; k++) { c = (const char *)std::memchr(c, '\t', (size_t)(end - c)) + 1; f[k] = c; }   // pass 1 saw 12 tabs
+        int64_t qtot, qs, qe, rtot, rs, re, mq, mat, aln;
+        if (!field_i64(f[1], f[2] - 1, qtot) || !field_i64(f[2], f[3] - 1, qs) || !field_i64(f[3], f[4] - 1, qe) ||
+            !field_i64(f[6], f[7] - 1, rtot) || !field_i64(f[7], f[8] - 1, rs) || !field_i64(f[8], f[9] - 1, re) ||
+            !field_i64(f[9], f[10] - 1, mat) || !field_i64(f[10], f[11] - 1, aln) || !field_i64(f[11], f[12] - 1, mq)) { ck.bad = true; return; }
+        qe--; re--;                                                    // closed intervals, :141-151
+        const bool fwd = f[5] - 1 > f[4] && f[4][0] == '+';
+        if (!fwd) std::swap(rs, re);                                   // :155-159
+        const std::string_view qname(f[0], (size_t)(f[1] - 1 - f[0])), rname(f[5], (size_t)(f[6] - 1 - f[5]));
+        if (!have_ctg || qname != cur_ctg) { ck.runs.emplace_back(qname, g); cur_ctg = qname; have_ctg = true; }   // :125-133
+        int32_t chr_id;
+        if (last_chr_id >= 0 && rname == last_chr) chr_id = last_chr_id;
+        else {
+            auto it = chr_map.find(rname);
+            if (it == chr_map.end()) { chr_id = (int32_t)ck.chr_names.size(); chr_map.emplace(rname, chr_id); ck.chr_names.push_back(rname); }
+            else chr_id = it->second;
+            last_chr = rname; last_chr_id = chr_id;
+        }
+        const char *cs = text + ri.cs;
+        const int64_t nr = fast_ranges(cs + 5, cs + ri.cs_len, fwd, qs, qe, rs, re, QL + ro, QR + ro, RL + ro);
+        if (nr < 0) { ck.bad = true; return; }
+        ro += nr;
+        std::memcpy(paf.cs_pool.data() + co, cs, (size_t)ri.cs_len);
+        co += ri.cs_len;
+        paf.qry_str[g] = qs; paf.qry_end[g] = qe; paf.ref_str[g] = rs; paf.ref_end[g] = re;
+        paf.qry_total[g] = qtot; paf.ref_total[g] = rtot;
+        paf.ref_chr[g] = chr_id;                                       // chunk-local id, remapped after the join
+        paf.mat_num[g] = (int32_t)mat; paf.aln_len[g] = (int32_t)aln;
+        paf.row_index[g] = (int32_t)g; paf.cord_type[g] = 0;
+        paf.aln_fwd[g] = fwd ? 1 : 0; paf.map_qul[g] = (uint8_t)mq;
+        paf.rec_rng_off[g + 1] = ro; paf.cs_off[g + 1] = co;
+    }
+    if (ro != rng0 + ck.n_ranges) ck.bad = true;                       // a ':' that was not an operation
+}
+
+template <class F> static void run_threads(int n, F fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n; t++) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+}
+
+static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf) {
+    int T = host_threads();
+    if (len < (1 << 16)) T = 1;
+    std::vector<ReadChunk> ck((size_t)T);
+    for (int t = 0; t < T; t++) {                                      // cut at line starts
+        int64_t b = len * t / T;
+        if (t > 0) { const char *nl = (const char *)std::memchr(text + b - 1, '\n', (size_t)(len - b + 1)); b = nl ? (nl - text) + 1 : len; }
+        ck[t].b = b;
+        if (t > 0) ck[t - 1].e = b;
+    }
+    ck[T - 1].e = len;
+    for (int t = 0; t + 1 < T; t++) if (ck[t].e < ck[t].b) ck[t].e = ck[t].b;
+    run_threads(T, [&](int t) { read_pass1(text, ck[t]); });
+    std::vector<int64_t> row0(T + 1, 0), rng0(T + 1, 0), cs0(T + 1, 0);
+    bool bad = false;
+    for (int t = 0; t < T; t++) {
+        bad |= ck[t].bad;
+        row0[t + 1] = row0[t] + (int64_t)ck[t].rows.size(); rng0[t + 1] = rng0[t] + ck[t].n_ranges; cs0[t + 1] = cs0[t] + ck[t].cs_bytes;
+    }
+    const int64_t R = row0[T];
+    if (bad || R == 0 || R > INT32_MAX) return parse_text(text, len, paf);   // errors / empty input: the serial reader reports
+    paf.qry_str.resize(R); paf.qry_end.resize(R); paf.ref_str.resize(R); paf.ref_end.resize(R); paf.qry_total.resize(R); paf.ref_total.resize(R);
+    paf.ref_chr.resize(R); paf.mat_num.resize(R); paf.aln_len.resize(R); paf.row_index.resize(R);
+    paf.aln_fwd.resize(R); paf.map_qul.resize(R); paf.cord_type.resize(R);
+    paf.cs_off.resize(R + 1); paf.rec_rng_off.resize(R + 1);
+    paf.cs_off[0] = 0; paf.rec_rng_off[0] = 0;
+    paf.rng_qry_l.resize(rng0[T]); paf.rng_qry_r.resize(rng0[T]); paf.rng_ref_l.resize(rng0[T]);
+    paf.cs_pool.resize(cs0[T]);
+    run_threads(T, [&](int t) { read_pass2(text, ck[t], paf, row0[t], rng0[t], cs0[t]); });
+    for (int t = 0; t < T; t++) bad |= ck[t].bad;
+    if (bad) { paf = aasm_paf(); return parse_text(text, len, paf); }
+    // reference names numbered by first appearance in the file (chr_map, :119-123)
+    std::unordered_map<std::string_view, int32_t> chr_map;
+    std::vector<std::vector<int32_t>> remap((size_t)T);
+    for (int t = 0; t < T; t++)
+        for (std::string_view nm : ck[t].chr_names) {
+            auto it = chr_map.find(nm);
+            if (it == chr_map.end()) { it = chr_map.emplace(nm, (int32_t)paf.chr_name.size()).first; paf.chr_name.emplace_back(nm); }
+            remap[t].push_back(it->second);
+        }
+    run_threads(T, [&](int t) { for (int64_t g = row0[t]; g < row0[t + 1]; g++) paf.ref_chr[g] = remap[t][paf.ref_chr[g]]; });
+    // contigs = runs of consecutive rows with one query name; a run may continue across a chunk cut
+    paf.ctg_rec_off.clear();
+    std::string_view prev;
+    bool have = false;
+    for (int t = 0; t < T; t++)
+        for (auto &run : ck[t].runs) {
+            if (have && run.first == prev) continue;
+            paf.ctg_name.emplace_back(run.first); paf.ctg_rec_off.push_back(run.second);
+            prev = run.first; have = true;
+        }
+    paf.ctg_rec_off.push_back(R);
     return AASM_OK;
 }
 
@@ -347,7 +573,7 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             n.qry_total.push_back(paf.qry_total[r]); n.ref_total.push_back(paf.ref_total[r]); n.ref_chr.push_back(paf.ref_chr[r]);
             n.mat_num.push_back(paf.mat_num[r]); n.aln_len.push_back(paf.aln_len[r]); n.row_index.push_back(paf.row_index[r]);
             n.cord_type.push_back(paf.cord_type[r]); n.aln_fwd.push_back(paf.aln_fwd[r]); n.map_qul.push_back(paf.map_qul[r]);
-            n.cs_pool.append(paf.cs_pool, (size_t)paf.cs_off[r], (size_t)(paf.cs_off[r + 1] - paf.cs_off[r]));
+            n.cs_pool.insert(n.cs_pool.end(), paf.cs_pool.data() + paf.cs_off[r], paf.cs_pool.data() + paf.cs_off[r + 1]);
             n.cs_off.push_back((int64_t)n.cs_pool.size());
             for (int64_t t = paf.rec_rng_off[r]; t < paf.rec_rng_off[r + 1]; t++) { n.rng_qry_l.push_back(paf.rng_qry_l[t]); n.rng_qry_r.push_back(paf.rng_qry_r[t]); n.rng_ref_l.push_back(paf.rng_ref_l[t]); }
             n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
@@ -357,7 +583,7 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             n.qry_total.push_back(a.qtot); n.ref_total.push_back(a.rtot); n.ref_chr.push_back(a.chr);
             n.mat_num.push_back(a.mat); n.aln_len.push_back(a.aln); n.row_index.push_back(a.row);
             n.cord_type.push_back(1); n.aln_fwd.push_back(a.fwd); n.map_qul.push_back(a.mq);   // TYPE_ALT (:302)
-            n.cs_pool += a.cs; n.cs_off.push_back((int64_t)n.cs_pool.size());
+            n.cs_pool.insert(n.cs_pool.end(), a.cs.begin(), a.cs.end()); n.cs_off.push_back((int64_t)n.cs_pool.size());
             n.rng_qry_l.insert(n.rng_qry_l.end(), a.ql.begin(), a.ql.end()); n.rng_qry_r.insert(n.rng_qry_r.end(), a.qr.begin(), a.qr.end());
             n.rng_ref_l.insert(n.rng_ref_l.end(), a.rl.begin(), a.rl.end());
             n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
@@ -371,8 +597,11 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
 // ---- writers (alignasm.cpp:398-490) ---------------------------------------------------
 static inline void put_i64(std::string &s, int64_t v) {
     char buf[24];
-    int n = std::snprintf(buf, sizeof buf, "%lld", (long long)v);
-    s.append(buf, n);
+    char *e = buf + sizeof buf, *p = e;
+    uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+    do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *--p = '-';
+    s.append(p, (size_t)(e - p));
 }
 
 static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &name, const aasm_out_elem &o,
@@ -404,13 +633,69 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     return AASM_OK;
 }
 
-static int flush_file(const char *path, const std::string &buf) {
+
+// One output file: contigs are cut into one contiguous share per host thread (balanced by
+// element count), every thread formats its share into its own buffer, and the buffers are
+// written in contig order.
+template <class EMIT>   // EMIT(contig, buf, ops, err) -> rc : appends every line of one contig
+static int write_file_mt(const aasm_paf &paf, const char *path, const std::vector<int64_t> &weight_prefix, EMIT emit) {
+    const int64_t C = paf.n_contigs();
+    int T = host_threads();
+    if (weight_prefix[C] < 4096) T = 1;
+    std::vector<std::string> bufs((size_t)T), errs((size_t)T);
+    std::vector<int> rcs((size_t)T, AASM_OK);
+    std::vector<int64_t> cut((size_t)T + 1, C);
+    cut[0] = 0;
+    for (int t = 1; t < T; t++)
+        cut[t] = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), weight_prefix[C] * t / T) - weight_prefix.begin();
+    for (int t = 1; t <= T; t++) { if (cut[t] > C) cut[t] = C; if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1]; }
+    run_threads(T, [&](int t) {
+        std::vector<CsOp> ops;
+        for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], ops, errs[t]);
+    });
+    for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { set_last_error(errs[t]); return rcs[t]; }   // first failing contig in file order
     FILE *fp = std::fopen(path, "wb");
-    if (!fp) return AASM_E_IO;
-    size_t w = buf.empty() ? 0 : std::fwrite(buf.data(), 1, buf.size(), fp);
-    int rc = (w == buf.size()) ? AASM_OK : AASM_E_IO;
+    if (!fp) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
+    int rc = AASM_OK;
+    for (int t = 0; t < T && rc == AASM_OK; t++)
+        if (!bufs[t].empty() && std::fwrite(bufs[t].data(), 1, bufs[t].size(), fp) != bufs[t].size()) rc = AASM_E_IO;
     if (std::fclose(fp) != 0) rc = AASM_E_IO;
+    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
     return rc;
+}
+
+// the batch as PAF text (12 columns + tp + cs), rows shared out over the host threads
+static void format_rows_mt(const aasm_paf &paf, std::vector<std::string> &bufs) {
+    const int64_t R = paf.n_records();
+    int T = host_threads();
+    if (R < 4096) T = 1;
+    bufs.assign((size_t)T, std::string());
+    std::vector<int32_t> ctg_of((size_t)R);
+    for (int64_t c = 0; c < paf.n_contigs(); c++) for (int64_t r = paf.ctg_rec_off[c]; r < paf.ctg_rec_off[c + 1]; r++) ctg_of[r] = (int32_t)c;
+    run_threads(T, [&](int t) {
+        std::string &buf = bufs[t];
+        const int64_t r0 = R * t / T, r1 = R * (t + 1) / T;
+        if (r1 > r0) buf.reserve((size_t)((paf.cs_off[r1] - paf.cs_off[r0]) + (r1 - r0) * 96));
+        for (int64_t r = r0; r < r1; r++) {
+            const bool fwd = paf.aln_fwd[r] != 0;
+            int64_t rs = paf.ref_str[r], re = paf.ref_end[r];
+            if (!fwd) std::swap(rs, re);
+            buf += paf.ctg_name[ctg_of[r]]; buf += '\t';
+            put_i64(buf, paf.qry_total[r]); buf += '\t';
+            put_i64(buf, paf.qry_str[r]); buf += '\t';
+            put_i64(buf, paf.qry_end[r] + 1); buf += '\t';
+            buf += fwd ? '+' : '-'; buf += '\t';
+            buf += paf.chr_name[paf.ref_chr[r]]; buf += '\t';
+            put_i64(buf, paf.ref_total[r]); buf += '\t';
+            put_i64(buf, rs); buf += '\t';
+            put_i64(buf, re + 1); buf += '\t';
+            put_i64(buf, paf.mat_num[r]); buf += '\t';
+            put_i64(buf, paf.aln_len[r]); buf += '\t';
+            put_i64(buf, paf.map_qul[r]); buf += "\ttp:A:P\t";
+            buf.append(paf.cs_pool.data() + paf.cs_off[r], (size_t)(paf.cs_off[r + 1] - paf.cs_off[r]));
+            buf += '\n';
+        }
+    });
 }
 
 }  // namespace aasm
@@ -424,7 +709,7 @@ const char *aasm_last_error(void) { return last_error_cstr(); }
 int aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **out) {
     if (!text || !out) return AASM_E_INVAL;
     aasm_paf *paf = new aasm_paf();
-    int rc = parse_text(text, len, *paf);
+    int rc = parse_text_mt(text, len, *paf);
     if (rc != AASM_OK) { set_last_error(paf->error); delete paf; *out = nullptr; return rc; }
     *out = paf;
     return AASM_OK;
@@ -432,15 +717,29 @@ int aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **out) {
 
 int aasm_paf_read(const char *path, aasm_paf **out) {
     if (!path || !out) return AASM_E_INVAL;
-    FILE *fp = std::fopen(path, "rb");
-    if (!fp) { set_last_error(std::string("cannot open ") + path); return AASM_E_IO; }
-    std::string data;
-    char buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, n);
-    std::fclose(fp);
-    return aasm_paf_parse_mem(data.data(), (int64_t)data.size(), out);
+    // the reader threads page the file in themselves: map it instead of copying it
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { set_last_error(std::string("cannot open ") + path); return AASM_E_IO; }
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {             // pipes etc.: read into memory
+        std::string data;
+        char buf[1 << 16];
+        ssize_t n;
+        while ((n = ::read(fd, buf, sizeof buf)) > 0) data.append(buf, (size_t)n);
+        ::close(fd);
+        return aasm_paf_parse_mem(data.data(), (int64_t)data.size(), out);
+    }
+    if (st.st_size == 0) { ::close(fd); return aasm_paf_parse_mem("", 0, out); }
+    void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { set_last_error(std::string("cannot map ") + path); return AASM_E_IO; }
+    ::madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+    const int rc = aasm_paf_parse_mem((const char *)m, (int64_t)st.st_size, out);
+    ::munmap(m, (size_t)st.st_size);
+    return rc;
 }
+
+int aasm_set_host_threads(int n) { const int old = g_host_threads.exchange(n < 0 ? 0 : n); return old; }
 
 // --alt: merge a second PAF of sub-contig re-alignments (alignasm.cpp:186-332)
 int aasm_paf_merge_alt_mem(aasm_paf *paf, const char *text, int64_t len, double alt_baseline) {
@@ -485,36 +784,46 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
                            const char *all_path) {
     if (!paf || !out || out->n_contigs != paf->n_contigs()) return AASM_E_INVAL;
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
-    std::vector<CsOp> ops;
-    std::string err, buf;
     const int64_t C = paf->n_contigs();
     int rc;
     if (main_path) {                                                    // process_output, :407-443
-        buf.clear();
-        for (int64_t c = 0; c < C; c++)
-            for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++)
-                if ((rc = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
-        if ((rc = flush_file(main_path, buf)) != AASM_OK) return rc;
+        std::vector<int64_t> wp(out->main_off, out->main_off + C + 1);
+        rc = write_file_mt(*paf, main_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+            for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++) {
+                const int r = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, ops, err);
+                if (r != AASM_OK) return r;
+            }
+            return (int)AASM_OK;
+        });
+        if (rc != AASM_OK) return rc;
     }
     if (alt_path) {
-        buf.clear();
-        for (int64_t c = 0; c < C; c++)
-            for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++)
-                if ((rc = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
-        if ((rc = flush_file(alt_path, buf)) != AASM_OK) return rc;
+        std::vector<int64_t> wp(out->alt_off, out->alt_off + C + 1);
+        rc = write_file_mt(*paf, alt_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+            for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
+                const int r = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, ops, err);
+                if (r != AASM_OK) return r;
+            }
+            return (int)AASM_OK;
+        });
+        if (rc != AASM_OK) return rc;
     }
     if (all_path) {                                                     // process_max_output, :445-485
-        buf.clear();
-        for (int64_t c = 0; c < C; c++) {
+        std::vector<int64_t> wp((size_t)C + 1);
+        for (int64_t c = 0; c <= C; c++) wp[c] = out->all_elem_off[out->all_path_off[c]];
+        rc = write_file_mt(*paf, all_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
             int32_t cnt = 0;
             for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
                 ++cnt;
-                std::string name = paf->ctg_name[c] + "." + std::to_string(cnt);
-                for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++)
-                    if ((rc = emit_line(*paf, c, name, out->all_elems[k], buf, ops, err)) != AASM_OK) { set_last_error(err); return rc; }
+                const std::string name = paf->ctg_name[c] + "." + std::to_string(cnt);
+                for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++) {
+                    const int r = emit_line(*paf, c, name, out->all_elems[k], buf, ops, err);
+                    if (r != AASM_OK) return r;
+                }
             }
-        }
-        if ((rc = flush_file(all_path, buf)) != AASM_OK) return rc;
+            return (int)AASM_OK;
+        });
+        if (rc != AASM_OK) return rc;
     }
     return AASM_OK;
 }
@@ -557,34 +866,31 @@ int64_t aasm_cs_edit(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_st
 int aasm_paf_to_text(const aasm_paf *paf, char **text, int64_t *len) {
     if (!paf || !text || !len) return AASM_E_INVAL;
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
-    std::string buf;
-    for (int64_t c = 0; c < paf->n_contigs(); c++) {
-        for (int64_t r = paf->ctg_rec_off[c]; r < paf->ctg_rec_off[c + 1]; r++) {
-            const bool fwd = paf->aln_fwd[r] != 0;
-            int64_t rs = paf->ref_str[r], re = paf->ref_end[r];
-            if (!fwd) std::swap(rs, re);
-            buf += paf->ctg_name[c]; buf += '\t';
-            put_i64(buf, paf->qry_total[r]); buf += '\t';
-            put_i64(buf, paf->qry_str[r]); buf += '\t';
-            put_i64(buf, paf->qry_end[r] + 1); buf += '\t';
-            buf += fwd ? '+' : '-'; buf += '\t';
-            buf += paf->chr_name[paf->ref_chr[r]]; buf += '\t';
-            put_i64(buf, paf->ref_total[r]); buf += '\t';
-            put_i64(buf, rs); buf += '\t';
-            put_i64(buf, re + 1); buf += '\t';
-            put_i64(buf, paf->mat_num[r]); buf += '\t';
-            put_i64(buf, paf->aln_len[r]); buf += '\t';
-            put_i64(buf, paf->map_qul[r]); buf += "\ttp:A:P\t";
-            buf.append(paf->cs_pool.data() + paf->cs_off[r], paf->cs_off[r + 1] - paf->cs_off[r]);
-            buf += '\n';
-        }
-    }
-    *len = (int64_t)buf.size();
-    *text = (char *)std::malloc(buf.size() + 1);
+    std::vector<std::string> bufs;
+    format_rows_mt(*paf, bufs);
+    size_t total = 0;
+    for (auto &b : bufs) total += b.size();
+    *len = (int64_t)total;
+    *text = (char *)std::malloc(total + 1);
     if (!*text) return AASM_E_NOMEM;
-    std::memcpy(*text, buf.data(), buf.size());
-    (*text)[buf.size()] = 0;
+    size_t o = 0;
+    for (auto &b : bufs) { std::memcpy(*text + o, b.data(), b.size()); o += b.size(); }
+    (*text)[total] = 0;
     return AASM_OK;
+}
+
+int aasm_paf_save(const aasm_paf *paf, const char *path) {
+    if (!paf || !path) return AASM_E_INVAL;
+    if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
+    std::vector<std::string> bufs;
+    format_rows_mt(*paf, bufs);
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
+    int rc = AASM_OK;
+    for (auto &b : bufs) if (!b.empty() && std::fwrite(b.data(), 1, b.size(), fp) != b.size()) { rc = AASM_E_IO; break; }
+    if (std::fclose(fp) != 0) rc = AASM_E_IO;
+    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
+    return rc;
 }
 
 }  // extern "C"

@@ -3,10 +3,25 @@
 // plus the per-file tables of src/alignasm.cpp:87-98 (contig names, reference names).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/alignasm_amd.h"
+
+namespace aasm {
+// resize() without the zero fill: the big arrays (match ranges, cs text: GBs at whole-genome
+// scale) are sized once and then written, and first touched, by all reader threads at once
+template <class T> struct default_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_alloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using big_i64 = std::vector<int64_t, default_init_alloc<int64_t>>;
+using big_char = std::vector<char, default_init_alloc<char>>;
+}  // namespace aasm
 
 struct aasm_paf {
     // per contig (consecutive rows with the same query name, alignasm.cpp:125-133)
@@ -17,13 +32,13 @@ struct aasm_paf {
     std::vector<int32_t> ref_chr, mat_num, aln_len, row_index;
     std::vector<uint8_t> aln_fwd, map_qul, cord_type;   // cord_type: TYPE_MAIN=0 / TYPE_ALT=1
     std::vector<int64_t> cs_off;               // [R+1] into cs_pool (each entry "cs:Z:...")
-    std::string cs_pool;
+    aasm::big_char cs_pool;
     bool has_cs = true;                        // generator may skip cs strings (bench)
     // reference names (chr_map / chr_rev_map, alignasm.cpp:90-93)
     std::vector<std::string> chr_name;
     // match ranges (get_overlap_range, paf_data.cpp:90-123)
     std::vector<int64_t> rec_rng_off;          // [R+1]
-    std::vector<int64_t> rng_qry_l, rng_qry_r, rng_ref_l;
+    aasm::big_i64 rng_qry_l, rng_qry_r, rng_ref_l;
     std::string error;
 
     int64_t n_contigs() const { return (int64_t)ctg_name.size(); }
@@ -36,4 +51,5 @@ struct CsOp { char type; int64_t length; int32_t text_off, text_len; };
 // returns false + message on malformed tags (the reference throws std::invalid_argument)
 bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err);
 void set_last_error(const std::string &msg);
+int host_threads();                          // aasm_set_host_threads (0 = all hardware threads), resolved
 }  // namespace aasm

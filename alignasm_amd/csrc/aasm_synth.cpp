@@ -238,7 +238,7 @@ extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
         paf->rng_qry_l.insert(paf->rng_qry_l.end(), p.ql.begin(), p.ql.end());
         paf->rng_qry_r.insert(paf->rng_qry_r.end(), p.qr.begin(), p.qr.end());
         paf->rng_ref_l.insert(paf->rng_ref_l.end(), p.rl.begin(), p.rl.end());
-        if (want_cs) paf->cs_pool += p.cs;
+        if (want_cs) paf->cs_pool.insert(paf->cs_pool.end(), p.cs.begin(), p.cs.end());
         paf->ctg_rec_off.push_back((int64_t)paf->qry_str.size());
         CtgOut().qs.swap(p.qs);   // release per-contig scratch early
         p = CtgOut();

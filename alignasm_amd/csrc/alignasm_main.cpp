@@ -4,10 +4,13 @@
 //   alignasm PAF_LOC [-t THREAD] [-a PAF_ALT_LOC] [-b ALT_BASELINE] [--non_skip_linkable]
 //   -> <stem>.aln.paf, <stem>.aln.alt.paf, <stem>.aln.all.paf next to the input,
 // and adds --max-paths K (MAX_PATH_COUNT, default 10000), --gpus N, --device D.
-// -t is accepted for compatibility (the per-contig parallelism now lives on the GPU).
+// -t sizes the host side (row-parallel PAF reader and writers; default: all hardware threads);
+// the per-contig parallelism the reference drives with it now lives on the GPU.
+// --timing prints the wall time of read / solve / write to stderr.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <filesystem>
 #include <iostream>
 #include <string>
@@ -16,16 +19,17 @@
 
 static void usage(std::ostream &os) {
     os << "Usage: alignasm [--help] [--version] [--thread THREAD] [--alt PAF_ALT_LOC] [--alt_baseline ALT_BASELINE] "
-          "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] PAF_LOC\n\n"
+          "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] [--timing] PAF_LOC\n\n"
           "Positional arguments:\n  PAF_LOC              Location of PAF file [required]\n\n"
           "Optional arguments:\n  -h, --help           shows help message and exits\n  -v, --version        prints version information and exits\n"
-          "  -t, --thread THREAD  Number of threads (accepted for compatibility) [default: 1]\n"
+          "  -t, --thread THREAD  Number of host threads for reading / writing PAF [default: all]\n"
           "  -a, --alt PAF_ALT_LOC  Location of alternative PAF file\n"
           "  -b, --alt_baseline ALT_BASELINE  Baseline for coverage of alternative PAF file [default: 0.5]\n"
           "  --non_skip_linkable  no edge a -> b when a -> c -> b exists\n"
           "  --max-paths K        paths enumerated per contig (reference constant MAX_PATH_COUNT) [default: 10000]\n"
           "  --gpus N             shard contigs over N GPUs of this node [default: 1]\n"
-          "  --device D           first HIP device ordinal [default: 0]\n";
+          "  --device D           first HIP device ordinal [default: 0]\n"
+          "  --timing             print read / solve / write wall time to stderr\n";
 }
 
 int main(int argc, char **argv) {
@@ -35,7 +39,7 @@ int main(int argc, char **argv) {
     opts.max_paths = 10000;
     int gpus = 1;
     double alt_baseline = 0.5;
-    bool bad = false, use_alt = false;
+    bool bad = false, use_alt = false, timing = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *what) -> const char * {
@@ -44,7 +48,8 @@ int main(int argc, char **argv) {
         };
         if (a == "-h" || a == "--help") { usage(std::cout); return 0; }
         else if (a == "-v" || a == "--version") { std::cout << "0.1.0\n"; return 0; }
-        else if (a == "-t" || a == "--thread") (void)std::atoi(need("--thread"));
+        else if (a == "-t" || a == "--thread") aasm_set_host_threads(std::atoi(need("--thread")));
+        else if (a == "--timing") timing = true;
         else if (a == "-a" || a == "--alt") alt_loc = need("--alt");
         else if (a == "-b" || a == "--alt_baseline") alt_baseline = std::atof(need("--alt_baseline"));
         else if (a == "--non_skip_linkable") opts.non_skip_linkable = 1;
@@ -72,6 +77,9 @@ int main(int argc, char **argv) {
         auto sz = std::filesystem::file_size(alt_loc, ec);
         use_alt = !(!ec && sz == 0);                                            // empty file == no --alt
     }
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = clk::now();
     aasm_paf *paf = nullptr;
     int rc = aasm_paf_read(std::filesystem::absolute(p).c_str(), &paf);
     if (rc != AASM_OK) { std::cerr << aasm_last_error() << "\n"; return 1; }    // e.g. "Missing cs:Z tag ..." (:165-168)
@@ -83,8 +91,10 @@ int main(int argc, char **argv) {
     aasm_batch_in view;
     aasm_paf_batch(paf, &view);
     std::cout << "Analyze PAF " << view.n_contigs << " data in parallel" << std::endl;   // :349
+    const auto t1 = clk::now();
     aasm_batch_out out;
     rc = aasm_solve_batch_multi(&view, &opts, gpus, &out);
+    const auto t2 = clk::now();
     if (rc != AASM_OK) { std::cerr << "alignasm: solver failed (" << rc << "): " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 2; }
     if (out.stats.n_internal_errors) std::cerr << "alignasm: " << out.stats.n_internal_errors << " contig(s) hit an internal error state\n";
     std::cout << "Write output PAF file" << std::endl;                           // :487
@@ -94,6 +104,10 @@ int main(int argc, char **argv) {
     auto f_all = ap; f_all.replace_extension(".aln.all.paf");
     rc = aasm_paf_write_outputs(paf, &out, f_main.c_str(), f_alt.c_str(), f_all.c_str());
     if (rc != AASM_OK) std::cerr << "alignasm: writing outputs failed: " << aasm_last_error() << "\n";
+    const auto t3 = clk::now();
+    if (timing)
+        std::cerr << "alignasm timing: records " << view.n_records << " contigs " << view.n_contigs << " read_s " << secs(t0, t1) << " solve_s " << secs(t1, t2)
+                  << " (upload " << out.stats.reserved_f[0] / 1e3 << " device " << out.stats.reserved_f[2] / 1e3 << " fetch " << out.stats.reserved_f[1] / 1e3 << ") write_s " << secs(t2, t3) << " total_s " << secs(t0, t3) << "\n";
     aasm_free_out(&out);
     aasm_paf_free(paf);
     return rc == AASM_OK ? 0 : 3;

@@ -192,6 +192,11 @@ int64_t aasm_debug_fetch(aasm_result *res, const char *name, void *dst, int64_t 
 typedef struct aasm_paf aasm_paf;    /* parsed PAF file: names, records, cs strings   */
 
 int  aasm_paf_read(const char *path, aasm_paf **paf);              /* alignasm.cpp:76-183 */
+/* Host threads of the PAF reader and the output writers (row-parallel; results do not depend
+ * on it).  The reference's -t/--thread (alignasm.cpp:45-49,346-352) sizes the TBB arena that
+ * runs solve_ctg_read; here that work is on the GPU and -t sizes the host codec instead.
+ * 0 = all hardware threads (default).  Returns the previous setting. */
+int  aasm_set_host_threads(int n);
 int  aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **paf);
 /* --alt merge of a second PAF of sub-contig re-alignments (alignasm.cpp:186-332) */
 int  aasm_paf_merge_alt(aasm_paf *paf, const char *alt_path, double alt_baseline);
@@ -224,6 +229,7 @@ typedef struct aasm_synth_cfg {
 } aasm_synth_cfg;
 int  aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **paf);     /* full PAF w/ cs  */
 int  aasm_paf_to_text(const aasm_paf *paf, char **text, int64_t *len); /* free()       */
+int  aasm_paf_save(const aasm_paf *paf, const char *path);          /* the same text written to a file (no 2 GiB limit on the caller's side) */
 
 #ifdef __cplusplus
 }

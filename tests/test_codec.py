@@ -110,3 +110,92 @@ def test_cli_rejects_wrong_extension(T, tmp_path):
     assert r.returncode == 1 and "Wrong PAF file" in r.stderr
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def _arrays(paf):
+    hb = paf.batch()
+    return {k: v.copy() for k, v in hb.arrays.items()}
+
+
+def test_reader_result_does_not_depend_on_thread_count(T):
+    """The row-parallel reader (chunks cut at line starts, contigs and reference names that
+    continue across a cut) gives the same batch for every thread count, and the same text back."""
+    api = T.api()
+    text = api.Paf.synth(40, 120, 5, dup_every=5, shuffle=True).to_text()
+    assert len(text) > (1 << 20)                       # several chunks
+    old = api.set_host_threads(1)
+    try:
+        ref = api.Paf.parse(text)
+        want = _arrays(ref)
+        for n in (2, 3, 7, 16, 0):
+            api.set_host_threads(n)
+            got = api.Paf.parse(text)
+            assert got.n_contigs == ref.n_contigs == 40
+            for k in want:
+                assert np.array_equal(want[k], _arrays(got)[k]), (n, k)
+            assert got.to_text() == text
+    finally:
+        api.set_host_threads(old)
+
+
+def test_fast_cs_scanner_equals_the_tokenizer_path(T):
+    """Ranges written by the reader's fused scanner == get_overlap_range through the cs
+    tokenizer (aasm_cs_match_ranges), on both strands, record by record."""
+    import ctypes as C
+    api = T.api()
+    paf = api.Paf.synth(4, 150, 9)
+    text = paf.to_text()
+    a = _arrays(api.Paf.parse(text))
+    rows = text.decode().splitlines()
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    n_rev = 0
+    for r, row in enumerate(rows):
+        cs = row.split("\t")[-1].encode()
+        lo, hi = int(a["rec_rng_off"][r]), int(a["rec_rng_off"][r + 1])
+        cap = hi - lo + 4
+        ql, qr, rl = (np.zeros(cap, np.int64) for _ in range(3))
+        n = api.LIB.aasm_cs_match_ranges(cs, C.c_int64(len(cs)), int(a["aln_fwd"][r]), C.c_int64(int(a["qry_str"][r])), C.c_int64(int(a["qry_end"][r])),
+                                         C.c_int64(int(a["ref_str"][r])), C.c_int64(int(a["ref_end"][r])), P(ql), P(qr), P(rl), C.c_int64(cap))
+        assert n == hi - lo
+        assert np.array_equal(ql[:n], a["rng_qry_l"][lo:hi]) and np.array_equal(qr[:n], a["rng_qry_r"][lo:hi]) and np.array_equal(rl[:n], a["rng_ref_l"][lo:hi])
+        n_rev += int(a["aln_fwd"][r] == 0)
+    assert n_rev >= 10
+
+
+def test_reader_line_endings_blank_lines_and_errors_in_big_files(T):
+    api = T.api()
+    text = api.Paf.synth(30, 100, 13).to_text()
+    want = _arrays(api.Paf.parse(text))
+    lines = text.split(b"\n")[:-1]
+    crlf = b"\r\n".join(lines) + b"\r\n"
+    gaps = b"\n\n".join(lines)                           # blank lines are skipped, no final newline
+    for variant in (crlf, gaps):
+        got = _arrays(api.Paf.parse(variant))
+        for k in want:
+            assert np.array_equal(want[k], got[k]), k
+    # an error deep inside a multi-chunk file is reported with its row number, as by the serial reader
+    bad_row = 2345
+    broken = list(lines)
+    broken[bad_row] = broken[bad_row].replace(b"cs:Z::", b"cs:Z::9999999", 1)
+    with pytest.raises(api.AlignasmError) as e:
+        api.Paf.parse(b"\n".join(broken) + b"\n")
+    assert "cs tag consumption does not match PAF coordinates (row %d)" % bad_row in str(e.value)
+    broken = list(lines)
+    broken[bad_row] = b"\t".join(broken[bad_row].split(b"\t")[:12])
+    with pytest.raises(api.AlignasmError) as e:
+        api.Paf.parse(b"\n".join(broken) + b"\n")
+    assert "Missing cs:Z tag" in str(e.value)
+
+
+def test_writers_do_not_depend_on_thread_count(T, tmp_path):
+    api = T.api()
+    paf = api.Paf.synth(24, 150, 21, dup_every=6)
+    old = api.set_host_threads(1)
+    try:
+        want = _solve_and_write(T, paf, tmp_path)
+        for n in (3, 8):
+            api.set_host_threads(n)
+            assert _solve_and_write(T, paf, tmp_path) == want
+    finally:
+        api.set_host_threads(old)
+    assert all(len(x) > 0 for x in (want[0], want[2]))
