@@ -612,8 +612,10 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     Edit ed;
     const char *cs = paf.cs_pool.data() + paf.cs_off[r];
     const int64_t cs_len = paf.cs_off[r + 1] - paf.cs_off[r];
-    if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
-                 o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, ops, err))
+    const bool uncut = o.edited_qry_str == paf.qry_str[r] && o.edited_qry_end == paf.qry_end[r];   // not cut: the record's own cs / mat_num / aln_len (paf_data.cpp:131-136)
+    if (uncut) { ed.mat_num = paf.mat_num[r]; ed.aln_len = paf.aln_len[r]; ed.is_cut = false; }
+    else if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
+                      o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, ops, err))
         return AASM_E_PARSE;
     buf += name; buf += '\t';
     put_i64(buf, paf.qry_total[r]); buf += '\t';
@@ -629,10 +631,33 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     put_i64(buf, paf.map_qul[r]); buf += '\t';
     buf += o.is_alt_path ? "tp:A:S" : "tp:A:P"; buf += '\t';
     buf += "xi:Z:"; buf += paf.cord_type[r] == 0 ? "P_" : "A_"; put_i64(buf, paf.row_index[r]); buf += '\t';
-    buf += ed.cs; buf += '\n';
+    if (uncut) buf.append(cs, (size_t)cs_len); else buf += ed.cs;
+    buf += '\n';
     return AASM_OK;
 }
 
+
+// buffers -> one file, in order; every thread writes its own buffer at its own offset
+static int write_buffers(const char *path, const std::vector<std::string> &bufs) {
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
+    const int T = (int)bufs.size();
+    std::vector<int64_t> off((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) off[t + 1] = off[t] + (int64_t)bufs[t].size();
+    std::atomic<int> rc{AASM_OK};
+    run_threads(T, [&](int t) {
+        const char *p = bufs[t].data();
+        int64_t left = (int64_t)bufs[t].size(), o = off[t];
+        while (left > 0) {
+            const ssize_t w = ::pwrite(fd, p, (size_t)std::min<int64_t>(left, 1 << 30), (off_t)o);
+            if (w <= 0) { rc = AASM_E_IO; return; }
+            p += w; o += w; left -= w;
+        }
+    });
+    if (::close(fd) != 0) rc = AASM_E_IO;
+    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
+    return rc;
+}
 
 // One output file: contigs are cut into one contiguous share per host thread (balanced by
 // element count), every thread formats its share into its own buffer, and the buffers are
@@ -654,14 +679,7 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
         for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], ops, errs[t]);
     });
     for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { set_last_error(errs[t]); return rcs[t]; }   // first failing contig in file order
-    FILE *fp = std::fopen(path, "wb");
-    if (!fp) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
-    int rc = AASM_OK;
-    for (int t = 0; t < T && rc == AASM_OK; t++)
-        if (!bufs[t].empty() && std::fwrite(bufs[t].data(), 1, bufs[t].size(), fp) != bufs[t].size()) rc = AASM_E_IO;
-    if (std::fclose(fp) != 0) rc = AASM_E_IO;
-    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
-    return rc;
+    return write_buffers(path, bufs);
 }
 
 // the batch as PAF text (12 columns + tp + cs), rows shared out over the host threads
@@ -884,13 +902,7 @@ int aasm_paf_save(const aasm_paf *paf, const char *path) {
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
     std::vector<std::string> bufs;
     format_rows_mt(*paf, bufs);
-    FILE *fp = std::fopen(path, "wb");
-    if (!fp) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
-    int rc = AASM_OK;
-    for (auto &b : bufs) if (!b.empty() && std::fwrite(b.data(), 1, b.size(), fp) != b.size()) { rc = AASM_E_IO; break; }
-    if (std::fclose(fp) != 0) rc = AASM_E_IO;
-    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
-    return rc;
+    return write_buffers(path, bufs);
 }
 
 }  // extern "C"

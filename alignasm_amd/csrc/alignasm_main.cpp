@@ -108,7 +108,8 @@ int main(int argc, char **argv) {
     if (timing)
         std::cerr << "alignasm timing: records " << view.n_records << " contigs " << view.n_contigs << " read_s " << secs(t0, t1) << " solve_s " << secs(t1, t2)
                   << " (upload " << out.stats.reserved_f[0] / 1e3 << " device " << out.stats.reserved_f[2] / 1e3 << " fetch " << out.stats.reserved_f[1] / 1e3 << ") write_s " << secs(t2, t3) << " total_s " << secs(t0, t3) << "\n";
-    aasm_free_out(&out);
-    aasm_paf_free(paf);
-    return rc == AASM_OK ? 0 : 3;
+    // the process ends here: the GBs of parsed text and results go back to the OS in one piece
+    // instead of vector by vector (1.7 s of page freeing for a 5M-record file)
+    std::cout.flush(); std::cerr.flush();
+    std::_Exit(rc == AASM_OK ? 0 : 3);
 }
