@@ -42,6 +42,7 @@ template <class T> AASM_DEV T wave_bcast(T x, int) { return x; }
 template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return fill; }
 template <class T> AASM_DEV T wave_shfl_xor(T x, int) { return x; }
 AASM_DEV void wave_lds_sync() {}
+AASM_DEV void block_barrier() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
 AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
@@ -73,6 +74,8 @@ AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
 // keep them in order.  __syncthreads() would also drain every outstanding global store
 // (s_waitcnt vmcnt(0)), a full memory round trip per call.
 AASM_DEV void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// barrier + LDS/global visibility inside a multi-wave workgroup (K1 sort)
+AASM_DEV void block_barrier() { __syncthreads(); }
 // order this wave's global-memory writes before its later reads (same CU, same L1)
 AASM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 template <class T> AASM_DEV T atomic_add(T *p, T v) { return atomicAdd(p, v); }

@@ -29,16 +29,17 @@ namespace aasm {
                (int)(threadIdx.x & 63), nullptr};                                             \
         run_kernel_body(KN, k, w);                                                            \
     }
-// kernels whose wave keeps a working set in LDS (AASM_LDS_BYTES per 64-thread block);
-// launch bound 5 waves/SIMD (<= 96 VGPRs) so that 20 contigs are resident per CU
-#define AASM_DEF_KERNEL_LDS(name, KN, TPB, BYTES)                                             \
-    __global__ void __launch_bounds__(TPB, 5) name(WS w) {                                    \
+// kernels whose wave keeps a working set in LDS (BYTES per 64-thread block); WAVES = waves per
+// SIMD the register budget is sized for (5: <= 96 VGPRs, 6: <= 80): residency per CU is
+// min(4 * WAVES, 160 KB / BYTES) blocks, and these kernels are latency-bound, so it is throughput
+#define AASM_DEF_KERNEL_LDS(name, KN, TPB, BYTES, WAVES)                                      \
+    __global__ void __launch_bounds__(TPB, WAVES) name(WS w) {                                    \
         __shared__ __attribute__((aligned(16))) char smem[BYTES];                             \
         KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
                (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }
-AASM_DEF_KERNEL(aasm_k1_sort, KN_SORT, 256)
+AASM_DEF_KERNEL_LDS(aasm_k1_sort, KN_SORT, 256, AASM_SORT_LDS_BYTES, 2)
 AASM_DEF_KERNEL(aasm_k1_sort_fix, KN_SORT_FIX, 64)
 AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)
 AASM_DEF_KERNEL(aasm_k2_ov_count, KN_OV_COUNT, 256)
@@ -57,12 +58,12 @@ AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
-AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES)
-AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_LDS_BYTES)
-AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES)
+AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
+AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_LDS_BYTES, 5)
+AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
 AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
-AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES)
+AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k9_topo_fill, KN_TOPO_FILL, 64)

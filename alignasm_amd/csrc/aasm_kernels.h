@@ -96,29 +96,90 @@ AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 
 // ====================================================================================
 // K1  sort (paf_data.cpp:241; comparator paf_data.hpp:69-73)
 // ====================================================================================
-// Stable rank sort: block per contig, every thread ranks its records against all N keys
-// (uniform key reads -> scalar loads).  std::sort is NOT stable, so when a contig holds
-// duplicate (qry_str, qry_end) keys and N > 16 (libstdc++ switches from pure insertion
-// sort to introsort there) kb_sort_fix replays libstdc++'s algorithm exactly (hazard B1).
+// One 256-thread block per contig.  The order wanted is the STABLE one - (qry_str, qry_end),
+// ties by input position - which is the plain order of the unique key (qry_str, qry_end,
+// index), so any comparison network gives it: chunks of 1024 records are sorted by a bitonic
+// network in LDS (55 stages, 2 compare-exchanges per thread and stage); a contig of one chunk
+// is done then, a longer one writes its sorted chunks to scratch and every record adds up its
+// lower bounds in the other chunks (binary search) to get its rank.  std::sort is NOT stable,
+// so when a contig holds duplicate (qry_str, qry_end) keys and N > 16 (libstdc++ switches from
+// pure insertion sort to introsort there) kb_sort_fix replays libstdc++'s algorithm exactly
+// (hazard B1).
+#define SORT_CHUNK 1024
+#define AASM_SORT_LDS_BYTES (SORT_CHUNK * 20)
+struct SortLds { int64_t qs[SORT_CHUNK], qe[SORT_CHUNK]; int32_t idx[SORT_CHUNK]; };
+static_assert(sizeof(SortLds) <= AASM_SORT_LDS_BYTES, "LDS budget");
+AASM_DEV bool sortkey_lt(int64_t a0, int64_t a1, int32_t a2, int64_t b0, int64_t b1, int32_t b2) {
+    if (a0 != b0) return a0 < b0;
+    if (a1 != b1) return a1 < b1;
+    return a2 < b2;
+}
 AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
     if (N <= 0) return;
+    SortLds *L = (SortLds *)k.lds;
     const int64_t *qs = w.in_qs + gb, *qe = w.in_qe + gb;
-    int dup = 0;
-    for (int64_t i = k.tid; i < N; i += k.nthreads) {
-        const int64_t a = qs[i], e = qe[i];
-        int32_t rank = 0;
-        for (int64_t j = 0; j < N; j++) {
-            const int64_t aj = qs[j], ej = qe[j];
-            const bool lt = (aj < a) || (aj == a && ej < e);
-            const bool eq = (aj == a && ej == e);
-            rank += (lt || (eq && j < i)) ? 1 : 0;
-            dup |= (eq && j != i) ? 1 : 0;
+    const int64_t nch = (N + SORT_CHUNK - 1) / SORT_CHUNK;
+    // scratch for the sorted chunks of a long contig: the sorted-record arrays K1's gather fills later
+    int64_t *t_qs = w.s_qs + b, *t_qe = w.s_qe + b;
+    int32_t *t_ix = w.s_orig + b;
+    for (int64_t ch = 0; ch < nch; ch++) {
+        const int64_t base = ch * SORT_CHUNK;
+        const int32_t n = (int32_t)((N - base < SORT_CHUNK) ? (N - base) : SORT_CHUNK);
+        int32_t P = 2;                                               // network size: next power of two >= n
+        while (P < n) P <<= 1;
+        for (int32_t t = k.tid; t < P; t += k.nthreads) {
+            if (t < n) { L->qs[t] = qs[base + t]; L->qe[t] = qe[base + t]; L->idx[t] = (int32_t)(base + t); }
+            else { L->qs[t] = INT64_MAX; L->qe[t] = INT64_MAX; L->idx[t] = INT32_MAX; }       // padding sorts last
         }
-        w.perm[b + rank] = (int32_t)i;
+        block_barrier();
+        for (int32_t kk = 2; kk <= P; kk <<= 1)
+            for (int32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (int32_t t = k.tid; t < (P >> 1); t += k.nthreads) {
+                    const int32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const bool up = (lo & kk) == 0;
+                    const int64_t a0 = L->qs[lo], a1 = L->qe[lo], b0 = L->qs[hi], b1 = L->qe[hi];
+                    const int32_t a2 = L->idx[lo], b2 = L->idx[hi];
+                    if (sortkey_lt(b0, b1, b2, a0, a1, a2) == up) {
+                        L->qs[lo] = b0; L->qe[lo] = b1; L->idx[lo] = b2;
+                        L->qs[hi] = a0; L->qe[hi] = a1; L->idx[hi] = a2;
+                    }
+                }
+                block_barrier();
+            }
+        if (nch == 1) { for (int32_t t = k.tid; t < n; t += k.nthreads) w.perm[b + t] = L->idx[t]; }
+        else for (int32_t t = k.tid; t < n; t += k.nthreads) { t_qs[base + t] = L->qs[t]; t_qe[base + t] = L->qe[t]; t_ix[base + t] = L->idx[t]; }
+        block_barrier();
     }
-    if (dup && N > 16) w.dupflag[c] = 1;
+    if (nch > 1) {                                                   // rank = place in own chunk + lower bounds in the others
+        for (int64_t g = k.tid; g < N; g += k.nthreads) {
+            const int64_t a0 = t_qs[g], a1 = t_qe[g];
+            const int32_t a2 = t_ix[g];
+            const int64_t own = g / SORT_CHUNK;
+            int64_t rank = g - own * SORT_CHUNK;
+            for (int64_t ch = 0; ch < nch; ch++) {
+                if (ch == own) continue;
+                const int64_t base = ch * SORT_CHUNK;
+                int64_t lo = 0, hi = (N - base < SORT_CHUNK) ? (N - base) : SORT_CHUNK;
+                while (lo < hi) {
+                    const int64_t m = (lo + hi) >> 1;
+                    if (sortkey_lt(t_qs[base + m], t_qe[base + m], t_ix[base + m], a0, a1, a2)) lo = m + 1; else hi = m;
+                }
+                rank += lo;
+            }
+            w.perm[b + rank] = a2;
+        }
+        block_barrier();
+    }
+    if (N > 16) {                                                    // duplicate keys are neighbours now
+        int dup = 0;
+        for (int64_t r = k.tid; r + 1 < N; r += k.nthreads) {
+            const int32_t x = w.perm[b + r], y = w.perm[b + r + 1];
+            dup |= (qs[x] == qs[y] && qe[x] == qe[y]) ? 1 : 0;
+        }
+        if (dup) w.dupflag[c] = 1;
+    }
 }
 
 // ---- libstdc++ (GCC 11) std::sort replayed on an index array ------------------------

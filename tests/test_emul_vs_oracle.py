@@ -19,6 +19,9 @@ CASES = [
     (5, 1, 3, 10000, False, 0, False, False, False),         # single-record contigs
     (5, 2, 3, 10000, False, 0, False, False, False),
     (8, 40, 13, 10000, True, 1, True, False, False),         # every record duplicated
+    (2, 2600, 17, 4, False, 3, True, False, False),          # contigs longer than one sort chunk (3 x 1024), shuffled + duplicates
+    (3, 1024, 19, 1, False, 0, True, False, False),          # exactly one full chunk
+    (2, 1025, 23, 1, False, 5, True, False, False),          # one record into the second chunk
 ]
 
 

@@ -21,6 +21,9 @@ CASES = [
     (8, 40, 13, 10000, True, 1, True, False, False),
     (2, 20000, 77, 16, False, 0, False, False, False),      # giant contigs (row f4): one wave still walks each
     (2, 6000, 77, 16, True, 0, False, False, False),
+    (2, 2600, 17, 4, False, 3, True, False, False),          # K1: contigs of 3 sort chunks, shuffled + duplicate keys
+    (2, 1025, 23, 1, False, 5, True, False, False),
+    (1, 9000, 41, 1, False, 4, True, False, False),          # 9 chunks: cross-chunk ranking + std::sort replay
 ]
 
 
