@@ -243,6 +243,7 @@ AASM_DEV Dist nodeq_key(const NodeQ &n) {
     d.anom = n.q1.x; d.qnz = n.q1.y; d.qtot = n.q1.z; d.pad = 0;
     return d;
 }
+AASM_DEV I4 uni(const I4 &q) { I4 r; r.x = uni(q.x); r.y = uni(q.y); r.z = uni(q.z); r.w = uni(q.w); return r; }
 AASM_DEV NodeQ uni(const NodeQ &n) {
     NodeQ r;
     r.q0.x = uni(n.q0.x); r.q0.y = uni(n.q0.y); r.q0.z = uni(n.q0.z); r.q0.w = uni(n.q0.w);

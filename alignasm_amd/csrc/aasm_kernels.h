@@ -87,6 +87,10 @@ struct WS {
     int32_t *status;
     int64_t *counters;
     int64_t *prof_heap, *prof_sel;    // [C * 8] cycle sums per section (diagnostic build only)
+    // ---- K7 pre-pass: sidetrack cost per edge (st_fl: 1 = insert it) and the packed per-vertex header
+    Dist *st_cost;
+    uint8_t *st_fl;
+    I4 *vhdr, *vhdr2;
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
@@ -958,6 +962,40 @@ AASM_DEV void kb_child_fill(const KCtx &k, const WS &w) {           // thread pe
         w.cval[pos] = (int32_t)(gv - vb);
     }
 }
+// K7 pre-pass, thread per vertex u (k_shortest_walks.hpp:204-210 without the insert): for
+// every out-edge the sidetrack cost c = w + d[v] - d[u] and whether it goes into the heap -
+// not when d[v] is max() (:204-205), and not the FIRST edge of the list that is u's tree edge
+// (:207-210).  Plus the header the heap wave reads per vertex, packed into two 16-byte words:
+// {row start (2), row length, #children} {first child, child-list start (2), -}.  This takes
+// d[], best[], the row pointers and, for the common single child, the child list out of the
+// wave's chain of dependent loads, and lets it prefetch the next vertex's header.
+AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gv]];
+    const Dist *d = w.sp_d + vb;
+    const Dist du = w.sp_d[gv];
+    const int32_t bu = w.sp_best[gv];
+    const int64_t r0 = w.rowptr[gv], r1 = w.rowptr[gv + 1];
+    bool seen_p = false;
+    for (int64_t e = r0; e < r1; e++) {
+        const int32_t v = w.e_col[e];
+        const Dist dv = d[v];
+        uint8_t fl = 0;
+        if (!dist_is_max(dv)) {
+            const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
+            if (!seen_p && v == bu && dist_eq(cc, dist_zero())) seen_p = true;
+            else { fl = 1; w.st_cost[e] = cc; }
+        }
+        w.st_fl[e] = fl;
+    }
+    const int64_t c0 = w.cptr[gv], c1 = w.cptr[gv + 1];
+    I4 a, b;
+    a.x = (int32_t)(uint32_t)(uint64_t)r0; a.y = (int32_t)((uint64_t)r0 >> 32); a.z = (int32_t)(r1 - r0); a.w = (int32_t)(c1 - c0);
+    b.x = (c1 > c0) ? w.cval[c0] : -1; b.y = (int32_t)(uint32_t)(uint64_t)c0; b.z = (int32_t)((uint64_t)c0 >> 32); b.w = 0;
+    w.vhdr[gv] = a; w.vhdr2[gv] = b;
+}
+
 // arena capacity per contig: an insert into a heap of s nodes allocates at most
 // floor(log2(s+1)) + 2 nodes (right-spine length + the new leaf), s < #sidetracks.
 AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread per contig
@@ -1109,14 +1147,13 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     if (V == 0) return;
     HeapLds *L = (HeapLds *)k.lds;
     const int64_t vb = w.voff[c];
-    const Dist *d = w.sp_d + vb;
-    const int32_t *best = w.sp_best + vb;
     int32_t *h = w.h_root + vb, *q = w.bq + vb;
+    const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
     HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (k.lane == 0) w.h_cnt[c] = 0;
-    if (dist_is_max(d[src])) { if (k.lane == 0) set_status(w, c, -6); return; }      // :188-189: no path (must not happen)
+    if (dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
     int32_t alloc = 0, head = 0, tail = 1, lds_hi = 1;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     bool ovf = false;
@@ -1124,37 +1161,38 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     wave_lds_sync();
     KPROF_DECL;
     KPROF_START();
+    // the header of the vertex popped next is in flight while the current one is worked on
+    int32_t pf_u = dest;
+    I4 pf_a = vh[dest], pf_b = vh2[dest];
     while (head < tail && !ovf) {
         int32_t u, hu;
         if (head < lds_hi) { u = uni(L->bqv[head & (HEAP_QN - 1)]); hu = uni(L->bqh[head & (HEAP_QN - 1)]); }
         else { wave_fence(); u = uni(q[head]); hu = uni(h[u]); }     // queue window overflow (wide trees)
         head++;
-        const Dist du = uni(d[u]);
-        const int32_t bu = uni(best[u]);
-        bool seen_p = false;
-        const int64_t r0 = uni(w.rowptr[vb + u]), r1 = uni(w.rowptr[vb + u + 1]);
-        const int64_t c0 = uni(w.cptr[vb + u]), c1 = uni(w.cptr[vb + u + 1]);
-        KPROF_STAMP(0);                                              // vertex header loads
+        I4 ha, hb;
+        if (u == pf_u) { ha = uni(pf_a); hb = uni(pf_b); }
+        else { ha = uni(vh[u]); hb = uni(vh2[u]); }
+        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)ha.y << 32) | (uint32_t)ha.x), r1 = r0 + ha.z;
+        const int32_t nch = ha.w, first_child = hb.x;
+        const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)hb.z << 32) | (uint32_t)hb.y);
+        // next pop: the queue front, or - the tree is path-like, the queue is mostly empty - this vertex's first child
+        {
+            int32_t nx = -1;
+            if (head < tail) { if (head < lds_hi) nx = uni(L->bqv[head & (HEAP_QN - 1)]); }
+            else if (nch > 0) nx = first_child;
+            if (nx >= 0) { pf_u = nx; pf_a = vh[nx]; pf_b = vh2[nx]; }
+        }
+        KPROF_STAMP(0);                                              // vertex header
         for (int64_t base = r0; base < r1 && !ovf; base += AASM_WAVE) {
             const int64_t e = base + k.lane;
-            bool valid = false, tree = false;
-            if (e < r1) {
-                const int32_t v = w.e_col[e];
-                const Dist dv = d[v];
-                if (!dist_is_max(dv)) {                              // :204-205
-                    const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
-                    valid = true;
-                    tree = (v == bu) && dist_eq(cc, dist_zero());    // :207
-                    L->cbuf[k.lane] = cc;
-                    L->vbuf[k.lane] = v;
-                }
+            bool valid = false;
+            if (e < r1 && w.st_fl[e]) {
+                valid = true;
+                L->cbuf[k.lane] = w.st_cost[e];
+                L->vbuf[k.lane] = w.e_col[e];
             }
-            wave_lds_sync();                                            // cbuf/vbuf visible to every lane
-            KPROF_STAMP(1);                                          // row chunk loads + costs
-            if (!seen_p) {                                           // skip the tree edge once (:207-210)
-                const uint64_t tm = wave_ballot(tree);
-                if (tm) { seen_p = true; if (k.lane == ffs64(tm) - 1) valid = false; }
-            }
+            wave_lds_sync();                                         // cbuf/vbuf visible to every lane
+            KPROF_STAMP(1);                                          // row chunk loads
             uint64_t vm = wave_ballot(valid);
             while (vm && !ovf) {                                     // inserts in list order
                 const int t = ffs64(vm) - 1;
@@ -1162,18 +1200,24 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
                 const Dist cc = uni(L->cbuf[t]);
                 hu = heap_insert(nodes, L, sp, alloc, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
             }
-            wave_lds_sync();                                            // before the next chunk overwrites cbuf
+            wave_lds_sync();                                         // before the next chunk overwrites cbuf
             KPROF_STAMP(2);                                          // inserts
         }
         if (k.lane == 0) h[u] = hu;
         // children adopt the heap (:213); they enter the LDS queue window while it has room
-        const int32_t nch = (int32_t)(c1 - c0);
         int32_t ncache = 0;
         if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
-        for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
-            const int32_t ch = w.cval[c0 + t];
-            h[ch] = hu; q[tail + t] = ch;
-            if (t < ncache) { L->bqv[(tail + t) & (HEAP_QN - 1)] = ch; L->bqh[(tail + t) & (HEAP_QN - 1)] = hu; }
+        if (nch == 1) {
+            if (k.lane == 0) {
+                h[first_child] = hu; q[tail] = first_child;
+                if (ncache) { L->bqv[tail & (HEAP_QN - 1)] = first_child; L->bqh[tail & (HEAP_QN - 1)] = hu; }
+            }
+        } else {
+            for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
+                const int32_t ch = w.cval[c0 + t];
+                h[ch] = hu; q[tail + t] = ch;
+                if (t < ncache) { L->bqv[(tail + t) & (HEAP_QN - 1)] = ch; L->bqh[(tail + t) & (HEAP_QN - 1)] = hu; }
+            }
         }
         lds_hi += ncache;
         tail += nch;
