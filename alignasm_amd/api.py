@@ -47,7 +47,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_parse_mem", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
@@ -79,15 +79,16 @@ class Paf:
         self._h = handle
 
     @staticmethod
-    def read(path):
+    def read(path, device_ranges=False):
+        """device_ranges: leave the cs -> match-range conversion to the GPU (AASM_READ_DEVICE_RANGES)."""
         h = C.c_void_p()
-        _check(LIB.aasm_paf_read(os.fsencode(path), C.byref(h)))
+        _check(LIB.aasm_paf_read_opts(os.fsencode(path), 1 if device_ranges else 0, C.byref(h)))
         return Paf(h)
 
     @staticmethod
-    def parse(text: bytes):
+    def parse(text: bytes, device_ranges=False):
         h = C.c_void_p()
-        _check(LIB.aasm_paf_parse_mem(text, C.c_int64(len(text)), C.byref(h)))
+        _check(LIB.aasm_paf_parse_mem_opts(text, C.c_int64(len(text)), 1 if device_ranges else 0, C.byref(h)))
         return Paf(h)
 
     @staticmethod

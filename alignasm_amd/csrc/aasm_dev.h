@@ -160,6 +160,10 @@ AASM_DEV int64_t wave_incl_min(int64_t x, int64_t neutral) {
     return x;
 }
 
+AASM_DEV int64_t wave_incl_add(int64_t x) {
+    for (int d = 1; d < AASM_WAVE; d <<= 1) x += wave_shfl_up(x, d, (int64_t)0);
+    return x;
+}
 AASM_DEV int64_t wave_sum(int64_t x) {
     for (int d = 1; d < AASM_WAVE; d <<= 1) x += wave_shfl_up(x, d, (int64_t)0);
     return wave_bcast(x, AASM_WAVE - 1);

@@ -39,6 +39,7 @@ namespace aasm {
                (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }
+AASM_DEF_KERNEL_LDS(aasm_k0_cs_ranges, KN_CS_RANGES, 64, CS_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k1_sort, KN_SORT, 256, AASM_SORT_LDS_BYTES, 2)
 AASM_DEF_KERNEL(aasm_k1_sort_fix, KN_SORT_FIX, 64)
 AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)
@@ -217,7 +218,7 @@ struct GpuBackend {
         dim3 g((unsigned)nblocks), b((unsigned)nthreads);
         switch (kn) {
 #define L(KN, name) case KN: hipLaunchKernelGGL(name, g, b, 0, stream, w); break;
-            L(KN_SORT, aasm_k1_sort) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
+            L(KN_CS_RANGES, aasm_k0_cs_ranges) L(KN_SORT, aasm_k1_sort) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
             L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
             L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill)
@@ -293,6 +294,9 @@ struct aasm_result {
     hipStream_t stream;
 };
 
+// record (index in the batch handed to the failing solve) whose cs tag the device rejected
+static thread_local int64_t g_bad_record = -1;
+
 static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_opts &opts, hipStream_t stream, aasm_result **res_out,
                            GpuBackend **be_out) {
     GpuBackend *be = *be_out;
@@ -308,6 +312,10 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     if (e == hipSuccess) e = hipStreamSynchronize(cx.side);
     if (rc == AASM_OK && be->failed()) rc = AASM_E_HIP;
     if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }
+    if (rc == AASM_E_PARSE) {
+        g_bad_record = res->sz.bad_record;
+        set_last_error("malformed cs:Z tag in record " + std::to_string(res->sz.bad_record) + " of the batch");
+    }
     if (rc != AASM_OK) { delete res; return rc; }
     if (timing) {
         for (int i = 0; i < AASM_N_PHASES; i++)
@@ -463,9 +471,17 @@ static int upload_range(const aasm_batch_in *in, int64_t c0, int64_t c1, int dev
     v.aln_fwd = (const uint8_t *)put(in->aln_fwd + r0, R);
     v.map_qul = (const uint8_t *)put(in->map_qul + r0, R);
     v.rec_rng_off = (const int64_t *)put(roff.data(), (R + 1) * 8);
-    v.rng_qry_l = (const int64_t *)put(in->rng_qry_l + g0, G * 8);
-    v.rng_qry_r = (const int64_t *)put(in->rng_qry_r + g0, G * 8);
-    v.rng_ref_l = (const int64_t *)put(in->rng_ref_l + g0, G * 8);
+    if (in->rng_qry_l) {
+        v.rng_qry_l = (const int64_t *)put(in->rng_qry_l + g0, G * 8);
+        v.rng_qry_r = (const int64_t *)put(in->rng_qry_r + g0, G * 8);
+        v.rng_ref_l = (const int64_t *)put(in->rng_ref_l + g0, G * 8);
+    } else if (in->cs_text && in->rec_cs_off) {                     // the device parses the cs tags (aasm_k0_cs_ranges)
+        const int64_t t0 = in->rec_cs_off[r0], t1 = in->rec_cs_off[r1];
+        std::vector<int64_t> toff(R + 1);
+        for (int64_t r = 0; r <= R; r++) toff[r] = in->rec_cs_off[r0 + r] - t0;
+        v.cs_text = (const char *)put(in->cs_text + t0, (size_t)(t1 - t0));
+        v.rec_cs_off = (const int64_t *)put(toff.data(), (R + 1) * 8);
+    } else ok = false;
     if (!ok) {
         for (void *p : up->ptrs) hipFree(p);
         delete up;
@@ -535,8 +551,14 @@ static int validate_batch(const aasm_batch_in *in) {
     }
     for (int64_t c = 0; c < in->n_contigs; c++)
         if (in->ctg_rec_off[c + 1] <= in->ctg_rec_off[c]) { set_last_error("empty contig"); return AASM_E_INVAL; }
+    if (!in->rec_rng_off || (!in->rng_qry_l && !(in->cs_text && in->rec_cs_off))) {
+        set_last_error("the batch carries neither match ranges (rng_*) nor cs tags (cs_text / rec_cs_off)");
+        return AASM_E_INVAL;
+    }
     return AASM_OK;
 }
+
+
 
 static void ctx_release_arena(int device) {
     DevCtx &cx = g_ctx[device];
@@ -570,6 +592,12 @@ static int solve_range_once(const aasm_batch_in *in, int64_t c0, int64_t c1, con
             out->stats.reserved_f[1] = std::chrono::duration<float, std::milli>(t3 - t2).count();   // D2H + pack
             out->stats.reserved_f[2] = std::chrono::duration<float, std::milli>(t2 - t1).count();   // solve wall
         }
+    }
+    if (rc == AASM_E_PARSE && g_bad_record >= 0 && in->cs_text && in->rec_cs_off) {   // say what the host codec says about that tag
+        const int64_t r = in->ctg_rec_off[c0] + g_bad_record;
+        const std::string why = cs_error_message(in->cs_text + in->rec_cs_off[r], in->rec_cs_off[r + 1] - in->rec_cs_off[r], in->aln_fwd[r] != 0,
+                                                 in->qry_str[r], in->qry_end[r], in->ref_str[r], in->ref_end[r]);
+        set_last_error((why.empty() ? std::string("malformed cs:Z tag") : why) + " (record " + std::to_string(r) + ")");
     }
     aasm_result_free(res);
     aasm_upload_free(up);

@@ -103,6 +103,13 @@ static int64_t match_ranges(const char *cs, int64_t cs_len, bool aln_fwd, int64_
     return n;
 }
 
+std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end) {
+    std::vector<CsOp> ops;
+    std::string err;
+    if (match_ranges<std::vector<int64_t>>(cs, cs_len, aln_fwd, qry_str, qry_end, ref_str, ref_end, nullptr, nullptr, nullptr, ops, err) >= 0) err.clear();
+    return err;
+}
+
 struct Edit { std::string cs; int32_t mat_num, aln_len; bool is_cut; };
 
 // paf_data.cpp:125-220
@@ -305,7 +312,7 @@ static int64_t fast_ranges(const char *p, const char *e, bool fwd, int64_t qs, i
     return n;
 }
 
-struct RowIdx { int64_t line, cs; int32_t line_len, cs_len; };
+struct RowIdx { int64_t line, cs; int32_t line_len, cs_len, n_colon; };
 struct ReadChunk {
     int64_t b = 0, e = 0;                      // byte range (whole lines)
     std::vector<RowIdx> rows;
@@ -341,7 +348,8 @@ static void read_pass1(const char *text, ReadChunk &ck) {
             if (!cs || le - p > INT32_MAX) { ck.bad = true; return; }
             int64_t colons = 0;
             for (const char *c = cs + 5; c < cs_end; c++) colons += (*c == ':');
-            ck.rows.push_back(RowIdx{p, (int64_t)(cs - text), (int32_t)(le - p), (int32_t)(cs_end - cs)});
+            if (colons > INT32_MAX) { ck.bad = true; return; }
+            ck.rows.push_back(RowIdx{p, (int64_t)(cs - text), (int32_t)(le - p), (int32_t)(cs_end - cs), (int32_t)colons});
             ck.n_ranges += colons;
             ck.cs_bytes += cs_end - cs;
         }
@@ -381,9 +389,12 @@ static void read_pass2(const char *text, ReadChunk &ck, aasm_paf &paf, int64_t r
             last_chr = rname; last_chr_id = chr_id;
         }
         const char *cs = text + ri.cs;
-        const int64_t nr = fast_ranges(cs + 5, cs + ri.cs_len, fwd, qs, qe, rs, re, QL + ro, QR + ro, RL + ro);
-        if (nr < 0) { ck.bad = true; return; }
-        ro += nr;
+        if (paf.device_ranges) ro += ri.n_colon;                       // the GPU parses (and validates) the tag
+        else {
+            const int64_t nr = fast_ranges(cs + 5, cs + ri.cs_len, fwd, qs, qe, rs, re, QL + ro, QR + ro, RL + ro);
+            if (nr < 0) { ck.bad = true; return; }
+            ro += nr;
+        }
         std::memcpy(paf.cs_pool.data() + co, cs, (size_t)ri.cs_len);
         co += ri.cs_len;
         paf.qry_str[g] = qs; paf.qry_end[g] = qe; paf.ref_str[g] = rs; paf.ref_end[g] = re;
@@ -404,7 +415,8 @@ template <class F> static void run_threads(int n, F fn) {
     for (auto &x : th) x.join();
 }
 
-static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf) {
+static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf, int flags) {
+    paf.device_ranges = (flags & AASM_READ_DEVICE_RANGES) != 0;
     int T = host_threads();
     if (len < (1 << 16)) T = 1;
     std::vector<ReadChunk> ck((size_t)T);
@@ -430,11 +442,11 @@ static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf) {
     paf.aln_fwd.resize(R); paf.map_qul.resize(R); paf.cord_type.resize(R);
     paf.cs_off.resize(R + 1); paf.rec_rng_off.resize(R + 1);
     paf.cs_off[0] = 0; paf.rec_rng_off[0] = 0;
-    paf.rng_qry_l.resize(rng0[T]); paf.rng_qry_r.resize(rng0[T]); paf.rng_ref_l.resize(rng0[T]);
+    if (!paf.device_ranges) { paf.rng_qry_l.resize(rng0[T]); paf.rng_qry_r.resize(rng0[T]); paf.rng_ref_l.resize(rng0[T]); }
     paf.cs_pool.resize(cs0[T]);
     run_threads(T, [&](int t) { read_pass2(text, ck[t], paf, row0[t], rng0[t], cs0[t]); });
     for (int t = 0; t < T; t++) bad |= ck[t].bad;
-    if (bad) { paf = aasm_paf(); return parse_text(text, len, paf); }
+    if (bad) { paf = aasm_paf(); return parse_text(text, len, paf); }            // (host ranges: parse_text builds them)
     // reference names numbered by first appearance in the file (chr_map, :119-123)
     std::unordered_map<std::string_view, int32_t> chr_map;
     std::vector<std::vector<int32_t>> remap((size_t)T);
@@ -565,7 +577,7 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
     flush_group();
     // rebuild the flat arrays: every contig = its main records followed by the appended ones
     aasm_paf n;
-    n.ctg_name = paf.ctg_name; n.chr_name = paf.chr_name; n.has_cs = paf.has_cs;
+    n.ctg_name = paf.ctg_name; n.chr_name = paf.chr_name; n.has_cs = paf.has_cs; n.device_ranges = paf.device_ranges;
     n.ctg_rec_off.assign(1, 0); n.cs_off.assign(1, 0); n.rec_rng_off.assign(1, 0);
     for (int64_t c = 0; c < C; c++) {
         for (int64_t r = paf.ctg_rec_off[c]; r < paf.ctg_rec_off[c + 1]; r++) {
@@ -575,8 +587,9 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             n.cord_type.push_back(paf.cord_type[r]); n.aln_fwd.push_back(paf.aln_fwd[r]); n.map_qul.push_back(paf.map_qul[r]);
             n.cs_pool.insert(n.cs_pool.end(), paf.cs_pool.data() + paf.cs_off[r], paf.cs_pool.data() + paf.cs_off[r + 1]);
             n.cs_off.push_back((int64_t)n.cs_pool.size());
-            for (int64_t t = paf.rec_rng_off[r]; t < paf.rec_rng_off[r + 1]; t++) { n.rng_qry_l.push_back(paf.rng_qry_l[t]); n.rng_qry_r.push_back(paf.rng_qry_r[t]); n.rng_ref_l.push_back(paf.rng_ref_l[t]); }
-            n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
+            if (!paf.device_ranges)
+                for (int64_t t = paf.rec_rng_off[r]; t < paf.rec_rng_off[r + 1]; t++) { n.rng_qry_l.push_back(paf.rng_qry_l[t]); n.rng_qry_r.push_back(paf.rng_qry_r[t]); n.rng_ref_l.push_back(paf.rng_ref_l[t]); }
+            n.rec_rng_off.push_back(n.rec_rng_off.back() + (paf.rec_rng_off[r + 1] - paf.rec_rng_off[r]));
         }
         for (const AltRec &a : added[c]) {
             n.qry_str.push_back(a.qs); n.qry_end.push_back(a.qe); n.ref_str.push_back(a.rs); n.ref_end.push_back(a.re);
@@ -584,9 +597,11 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             n.mat_num.push_back(a.mat); n.aln_len.push_back(a.aln); n.row_index.push_back(a.row);
             n.cord_type.push_back(1); n.aln_fwd.push_back(a.fwd); n.map_qul.push_back(a.mq);   // TYPE_ALT (:302)
             n.cs_pool.insert(n.cs_pool.end(), a.cs.begin(), a.cs.end()); n.cs_off.push_back((int64_t)n.cs_pool.size());
-            n.rng_qry_l.insert(n.rng_qry_l.end(), a.ql.begin(), a.ql.end()); n.rng_qry_r.insert(n.rng_qry_r.end(), a.qr.begin(), a.qr.end());
-            n.rng_ref_l.insert(n.rng_ref_l.end(), a.rl.begin(), a.rl.end());
-            n.rec_rng_off.push_back((int64_t)n.rng_qry_l.size());
+            if (!paf.device_ranges) {
+                n.rng_qry_l.insert(n.rng_qry_l.end(), a.ql.begin(), a.ql.end()); n.rng_qry_r.insert(n.rng_qry_r.end(), a.qr.begin(), a.qr.end());
+                n.rng_ref_l.insert(n.rng_ref_l.end(), a.rl.begin(), a.rl.end());
+            }
+            n.rec_rng_off.push_back(n.rec_rng_off.back() + (int64_t)a.ql.size());
         }
         n.ctg_rec_off.push_back((int64_t)n.qry_str.size());
     }
@@ -724,16 +739,19 @@ extern "C" {
 
 const char *aasm_last_error(void) { return last_error_cstr(); }
 
-int aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **out) {
+int aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **out) { return aasm_paf_parse_mem_opts(text, len, 0, out); }
+int aasm_paf_read(const char *path, aasm_paf **out) { return aasm_paf_read_opts(path, 0, out); }
+
+int aasm_paf_parse_mem_opts(const char *text, int64_t len, int flags, aasm_paf **out) {
     if (!text || !out) return AASM_E_INVAL;
     aasm_paf *paf = new aasm_paf();
-    int rc = parse_text_mt(text, len, *paf);
+    int rc = parse_text_mt(text, len, *paf, flags);
     if (rc != AASM_OK) { set_last_error(paf->error); delete paf; *out = nullptr; return rc; }
     *out = paf;
     return AASM_OK;
 }
 
-int aasm_paf_read(const char *path, aasm_paf **out) {
+int aasm_paf_read_opts(const char *path, int flags, aasm_paf **out) {
     if (!path || !out) return AASM_E_INVAL;
     // the reader threads page the file in themselves: map it instead of copying it
     const int fd = ::open(path, O_RDONLY);
@@ -745,14 +763,14 @@ int aasm_paf_read(const char *path, aasm_paf **out) {
         ssize_t n;
         while ((n = ::read(fd, buf, sizeof buf)) > 0) data.append(buf, (size_t)n);
         ::close(fd);
-        return aasm_paf_parse_mem(data.data(), (int64_t)data.size(), out);
+        return aasm_paf_parse_mem_opts(data.data(), (int64_t)data.size(), flags, out);
     }
-    if (st.st_size == 0) { ::close(fd); return aasm_paf_parse_mem("", 0, out); }
+    if (st.st_size == 0) { ::close(fd); return aasm_paf_parse_mem_opts("", 0, flags, out); }
     void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (m == MAP_FAILED) { set_last_error(std::string("cannot map ") + path); return AASM_E_IO; }
     ::madvise(m, (size_t)st.st_size, MADV_WILLNEED);
-    const int rc = aasm_paf_parse_mem((const char *)m, (int64_t)st.st_size, out);
+    const int rc = aasm_paf_parse_mem_opts((const char *)m, (int64_t)st.st_size, flags, out);
     ::munmap(m, (size_t)st.st_size);
     return rc;
 }
@@ -787,14 +805,15 @@ int aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *v) {
     std::memset(v, 0, sizeof(*v));
     v->n_contigs = paf->n_contigs();
     v->n_records = paf->n_records();
-    v->n_ranges = (int64_t)paf->rng_qry_l.size();
+    v->n_ranges = paf->rec_rng_off.empty() ? 0 : paf->rec_rng_off.back();
     v->ctg_rec_off = paf->ctg_rec_off.data();
     v->qry_str = paf->qry_str.data(); v->qry_end = paf->qry_end.data();
     v->ref_str = paf->ref_str.data(); v->ref_end = paf->ref_end.data();
     v->qry_total = paf->qry_total.data();
     v->ref_chr = paf->ref_chr.data(); v->aln_fwd = paf->aln_fwd.data(); v->map_qul = paf->map_qul.data();
     v->rec_rng_off = paf->rec_rng_off.data();
-    v->rng_qry_l = paf->rng_qry_l.data(); v->rng_qry_r = paf->rng_qry_r.data(); v->rng_ref_l = paf->rng_ref_l.data();
+    if (!paf->device_ranges) { v->rng_qry_l = paf->rng_qry_l.data(); v->rng_qry_r = paf->rng_qry_r.data(); v->rng_ref_l = paf->rng_ref_l.data(); }
+    if (paf->has_cs) { v->cs_text = paf->cs_pool.data(); v->rec_cs_off = paf->cs_off.data(); }
     return AASM_OK;
 }
 

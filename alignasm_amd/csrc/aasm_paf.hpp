@@ -34,6 +34,7 @@ struct aasm_paf {
     std::vector<int64_t> cs_off;               // [R+1] into cs_pool (each entry "cs:Z:...")
     aasm::big_char cs_pool;
     bool has_cs = true;                        // generator may skip cs strings (bench)
+    bool device_ranges = false;                // AASM_READ_DEVICE_RANGES: rng_* stay empty, rec_rng_off holds the counts
     // reference names (chr_map / chr_rev_map, alignasm.cpp:90-93)
     std::vector<std::string> chr_name;
     // match ranges (get_overlap_range, paf_data.cpp:90-123)
@@ -51,5 +52,7 @@ struct CsOp { char type; int64_t length; int32_t text_off, text_len; };
 // returns false + message on malformed tags (the reference throws std::invalid_argument)
 bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err);
 void set_last_error(const std::string &msg);
+// message of the tokenizer / get_overlap_range for one record (used when the device reports a bad cs tag)
+std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end);
 int host_threads();                          // aasm_set_host_threads (0 = all hardware threads), resolved
 }  // namespace aasm

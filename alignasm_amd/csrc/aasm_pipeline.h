@@ -20,7 +20,7 @@
 namespace aasm {
 
 enum Kern {
-    KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
+    KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_SWEEP, KN_FWD_SWEEP,
     KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
@@ -29,6 +29,7 @@ enum Kern {
 // dispatch a kernel body (used verbatim by both backends)
 AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
     switch (kn) {
+        case KN_CS_RANGES: kb_cs_ranges(k, w); break;
         case KN_SORT: kb_sort(k, w); break;
         case KN_SORT_FIX: kb_sort_fix(k, w); break;
         case KN_GATHER_PARTS: kb_gather_parts(k, w); break;
@@ -65,7 +66,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-struct PipelineSizes { int64_t C = 0, R = 0, S = 0, VT = 0, ET = 0, HT = 0; };
+struct PipelineSizes { int64_t C = 0, R = 0, S = 0, VT = 0, ET = 0, HT = 0, bad_record = -1; };
 
 // Runs the pipeline for contigs [0, C) described by `in` (device pointers; ctg_rec_off
 // already offset to the chunk).  Leaves all intermediates in the backend's arena and
@@ -92,6 +93,23 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     AZ(status, int32_t, C, "status");
     AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel");
     AZ(counters, int64_t, CNT_N, "counters");
+
+    // ---- K0 (optional): match ranges from the cs tags, on the device
+    if (!in.rng_qry_l && in.cs_text && in.rec_cs_off) {
+        if (R > INT32_MAX) return AASM_E_INVAL;
+        const int64_t G0 = be.read_i64(in.rec_rng_off + R0), G1 = be.read_i64(in.rec_rng_off + R1);
+        be.phase_begin(AASM_PH_CS);
+        w.cs_text = in.cs_text; w.cs_off = in.rec_cs_off;
+        A(rql_w, int64_t, G1 - G0, "rql_w"); A(rqr_w, int64_t, G1 - G0, "rqr_w"); A(rrl_w, int64_t, G1 - G0, "rrl_w"); A(cs_bad, int32_t, 2, "cs_bad");
+        CHECK_ALLOC();
+        w.rql_w -= G0; w.rqr_w -= G0; w.rrl_w -= G0;                // indexed with the batch's own range offsets
+        be.zero(w.cs_bad, 8);
+        be.launch(KN_CS_RANGES, R, AASM_WAVE, w);
+        be.phase_end(AASM_PH_CS);
+        const int32_t badv = (int32_t)(uint32_t)(uint64_t)be.read_i64((const int64_t *)w.cs_bad);   // 0 = none, else record - INT32_MAX
+        if (badv != 0) { sz.bad_record = R0 + ((int64_t)badv + INT32_MAX); return AASM_E_PARSE; }
+        w.rql = w.rql_w; w.rqr = w.rqr_w; w.rrl = w.rrl_w;
+    } else if (!in.rng_qry_l) return AASM_E_INVAL;
 
     // ---- K1 sort + parts
     be.phase_begin(AASM_PH_SORT);

@@ -19,7 +19,7 @@
 
 static void usage(std::ostream &os) {
     os << "Usage: alignasm [--help] [--version] [--thread THREAD] [--alt PAF_ALT_LOC] [--alt_baseline ALT_BASELINE] "
-          "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] [--timing] PAF_LOC\n\n"
+          "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] [--timing] [--host-ranges] PAF_LOC\n\n"
           "Positional arguments:\n  PAF_LOC              Location of PAF file [required]\n\n"
           "Optional arguments:\n  -h, --help           shows help message and exits\n  -v, --version        prints version information and exits\n"
           "  -t, --thread THREAD  Number of host threads for reading / writing PAF [default: all]\n"
@@ -29,7 +29,8 @@ static void usage(std::ostream &os) {
           "  --max-paths K        paths enumerated per contig (reference constant MAX_PATH_COUNT) [default: 10000]\n"
           "  --gpus N             shard contigs over N GPUs of this node [default: 1]\n"
           "  --device D           first HIP device ordinal [default: 0]\n"
-          "  --timing             print read / solve / write wall time to stderr\n";
+          "  --timing             print read / solve / write wall time to stderr\n"
+          "  --host-ranges        build the cs match ranges in the reader instead of on the GPU\n";
 }
 
 int main(int argc, char **argv) {
@@ -39,7 +40,7 @@ int main(int argc, char **argv) {
     opts.max_paths = 10000;
     int gpus = 1;
     double alt_baseline = 0.5;
-    bool bad = false, use_alt = false, timing = false;
+    bool bad = false, use_alt = false, timing = false, host_ranges = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *what) -> const char * {
@@ -50,6 +51,7 @@ int main(int argc, char **argv) {
         else if (a == "-v" || a == "--version") { std::cout << "0.1.0\n"; return 0; }
         else if (a == "-t" || a == "--thread") aasm_set_host_threads(std::atoi(need("--thread")));
         else if (a == "--timing") timing = true;
+        else if (a == "--host-ranges") host_ranges = true;
         else if (a == "-a" || a == "--alt") alt_loc = need("--alt");
         else if (a == "-b" || a == "--alt_baseline") alt_baseline = std::atof(need("--alt_baseline"));
         else if (a == "--non_skip_linkable") opts.non_skip_linkable = 1;
@@ -81,7 +83,8 @@ int main(int argc, char **argv) {
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t0 = clk::now();
     aasm_paf *paf = nullptr;
-    int rc = aasm_paf_read(std::filesystem::absolute(p).c_str(), &paf);
+    // the reader only indexes the rows; the cs tags are turned into match ranges on the GPU
+    int rc = aasm_paf_read_opts(std::filesystem::absolute(p).c_str(), host_ranges ? 0 : AASM_READ_DEVICE_RANGES, &paf);
     if (rc != AASM_OK) { std::cerr << aasm_last_error() << "\n"; return 1; }    // e.g. "Missing cs:Z tag ..." (:165-168)
     if (use_alt) {
         rc = aasm_paf_merge_alt(paf, std::filesystem::absolute(alt_loc).c_str(), alt_baseline);
@@ -95,6 +98,7 @@ int main(int argc, char **argv) {
     aasm_batch_out out;
     rc = aasm_solve_batch_multi(&view, &opts, gpus, &out);
     const auto t2 = clk::now();
+    if (rc == AASM_E_PARSE) { std::cerr << aasm_last_error() << "\n"; aasm_paf_free(paf); return 1; }       // malformed cs tag, found by the device parser
     if (rc != AASM_OK) { std::cerr << "alignasm: solver failed (" << rc << "): " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 2; }
     if (out.stats.n_internal_errors) std::cerr << "alignasm: " << out.stats.n_internal_errors << " contig(s) hit an internal error state\n";
     std::cout << "Write output PAF file" << std::endl;                           // :487

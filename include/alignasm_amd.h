@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AASM_ABI_VERSION 1
+#define AASM_ABI_VERSION 2
 
 /* error codes */
 #define AASM_OK              0
@@ -70,6 +70,12 @@ typedef struct aasm_batch_in {
     const int64_t *rng_qry_l;     /* [n_ranges]   qry_overlap_range[k].first       */
     const int64_t *rng_qry_r;     /* [n_ranges]   qry_overlap_range[k].second      */
     const int64_t *rng_ref_l;     /* [n_ranges]   ref_overlap_range[k].first       */
+    /* Alternative to the three rng_* arrays (ABI 2): when rng_qry_l is NULL and cs_text is
+     * not, the device derives the match ranges itself from the records' short-form cs tags
+     * (get_overlap_range, paf_data.cpp:90-123, kernel aasm_k0_cs_ranges).  rec_rng_off and
+     * n_ranges must still be given: a record's range count is its number of ':' operations. */
+    const char    *cs_text;       /* cs tags back to back, each starting "cs:Z:"    */
+    const int64_t *rec_cs_off;    /* [n_records+1] offsets into cs_text            */
 } aasm_batch_in;
 
 /* ---- options --------------------------------------------------------------------*/
@@ -128,7 +134,8 @@ enum {
     AASM_PH_GATHER,       /* output compaction                            */
     AASM_PH_HEAP_PREP,    /* SP-tree children CSR + arena sizing          */
     AASM_PH_TOPO,         /* topologically ordered CSR copy for K9        */
-    AASM_PH_MISC
+    AASM_PH_MISC,
+    AASM_PH_CS            /* K0 aasm_k0_cs_ranges alone (only with cs_text input) */
 };
 
 /* Ragged result of a batch: three lists per contig, exactly the three output
@@ -198,6 +205,13 @@ int  aasm_paf_read(const char *path, aasm_paf **paf);              /* alignasm.c
  * 0 = all hardware threads (default).  Returns the previous setting. */
 int  aasm_set_host_threads(int n);
 int  aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **paf);
+/* Reader flags.  AASM_READ_DEVICE_RANGES: do not build the match ranges on the host; rows are
+ * only indexed and their ':' operations counted, aasm_paf_batch() then hands out cs_text /
+ * rec_cs_off with NULL rng_* pointers and the solver parses the cs tags on the GPU (a malformed
+ * tag is then reported by the solve call, AASM_E_PARSE, instead of by the reader).           */
+#define AASM_READ_DEVICE_RANGES 1
+int  aasm_paf_read_opts(const char *path, int flags, aasm_paf **paf);
+int  aasm_paf_parse_mem_opts(const char *text, int64_t len, int flags, aasm_paf **paf);
 /* --alt merge of a second PAF of sub-contig re-alignments (alignasm.cpp:186-332) */
 int  aasm_paf_merge_alt(aasm_paf *paf, const char *alt_path, double alt_baseline);
 int  aasm_paf_merge_alt_mem(aasm_paf *paf, const char *text, int64_t len, double alt_baseline);

@@ -52,6 +52,7 @@ def emul():
     if "e" not in _cache:
         lib = C.CDLL(_ensure(EMUL_SO, os.path.join(ROOT, "tests", "host_emul")))
         lib.emul_debug_fetch.restype = C.c_int64
+        lib.emul_last_bad_record.restype = C.c_int64
         _cache["e"] = lib
     return _cache["e"]
 

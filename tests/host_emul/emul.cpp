@@ -68,6 +68,8 @@ WS g_ws;
 }  // namespace
 
 extern "C" {
+static int64_t g_bad_record = -1;
+int64_t emul_last_bad_record() { return g_bad_record; }   // record whose cs tag K0 rejected (AASM_E_PARSE)
 int emul_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
     delete g_be;
     g_be = new EmuBackend();
@@ -75,6 +77,7 @@ int emul_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_
     if (opts) o = *opts;
     PipelineSizes sz;
     int rc = run_pipeline(*g_be, *in, o, g_ws, sz);
+    g_bad_record = sz.bad_record;
     if (rc != AASM_OK) return rc;
     return fetch_results(*g_be, g_ws, sz, out);
 }

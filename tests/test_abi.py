@@ -23,13 +23,13 @@ def test_library_exports_every_declared_symbol(T):
     for n in names:
         assert hasattr(api.LIB, n), f"{n} declared in include/alignasm_amd.h but not exported"
     assert set(api.EXPORTED) <= set(names)
-    assert api.LIB.aasm_abi_version() == 1
+    assert api.LIB.aasm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from alignasm_amd import _abi
     assert C.sizeof(_abi.OutElem) == 40 and _abi.OUT_ELEM_DTYPE.itemsize == 40
-    assert C.sizeof(_abi.BatchIn) == 3 * 8 + 13 * 8
+    assert C.sizeof(_abi.BatchIn) == 3 * 8 + 13 * 8 + 2 * 8          # ABI 2: + cs_text, rec_cs_off
     assert C.sizeof(_abi.Opts) == 32
     assert C.sizeof(_abi.Stats) == 16 * 8 + 16 * 4 + 4 + 12
     assert C.sizeof(_abi.SynthCfg) == 40

@@ -1,0 +1,111 @@
+"""K0 (aasm_k0_cs_ranges): match ranges derived from the cs tags by the solver itself instead
+of by the host reader.  CPU tier: the kernel body in the 1-lane host emulation against the
+host codec; GPU tier (64-lane windows): tests/test_gpu_parity.py::test_device_cs_ranges."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from alignasm_amd._abi import BatchOut, Opts, unpack_out
+
+
+def _row(cs, fwd=True, qs=100, ql=None, rl=None, name=b"ctg1"):
+    """One PAF row whose coordinates fit the tag (ql / rl = query / reference bases consumed)."""
+    strand = b"+" if fwd else b"-"
+    return b"\t".join([name, b"100000", str(qs).encode(), str(qs + ql).encode(), strand, b"chr1", b"5000000", b"1000", str(1000 + rl).encode(),
+                       b"10", b"10", b"60", b"tp:A:P", b"cs:Z:" + cs]) + b"\n"
+
+
+def _consumed(cs):
+    import re
+    q = r = 0
+    for op in re.findall(rb":[0-9]+|\*[a-z][a-z]|[+-][a-z]+", cs):
+        if op[:1] == b":": q += int(op[1:]); r += int(op[1:])
+        elif op[:1] == b"*": q += 1; r += 1
+        elif op[:1] == b"+": q += len(op) - 1
+        else: r += len(op) - 1
+    return q, r
+
+
+TAGS = [
+    b":10*ac:5+gg:3-t:2",
+    b":1",
+    b"*ag",
+    b"+" + b"acgt" * 40 + b":7",                          # insertion longer than one 64-byte window
+    b":5-" + b"t" * 150 + b":9*ct:123456",               # long deletion, 6-digit length
+    b":" + b"9" * 7 + b"+a",                              # 7-digit length
+    (b":12*ac" * 30) + b":4",                             # many short operations: lengths straddle window ends
+    b":3" + b"+a:1" * 70,
+]
+
+
+def _emul_ranges(T, text, K=4):
+    api = T.api()
+    dev = api.Paf.parse(text, device_ranges=True)
+    view = dev.view()
+    assert not view.rng_qry_l and view.cs_text and view.n_ranges > 0
+    out = BatchOut()
+    rc = T.emul().emul_solve_batch(C.byref(view), C.byref(Opts(K, 0, 0, 0, 1)), C.byref(out))
+    return rc, out, dev
+
+
+def test_device_cs_ranges_equal_host_codec(T):
+    api = T.api()
+    rows = []
+    for k, cs in enumerate(TAGS):
+        q, r = _consumed(cs)
+        for fwd in (True, False):
+            rows.append(_row(cs, fwd, qs=1000 * (len(rows) + 1), ql=q, rl=r))
+    text = b"".join(rows)
+    host = api.Paf.parse(text).batch().arrays
+    rc, out, dev = _emul_ranges(T, text)
+    assert rc == 0
+    T.emul().emul_free_out(C.byref(out))
+    n = int(host["rec_rng_off"][-1])
+    assert np.array_equal(dev.batch().arrays["rec_rng_off"], host["rec_rng_off"])
+    for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
+        assert np.array_equal(T.emul_debug(name, np.int64)[:n], host[key]), name
+
+
+def test_device_cs_solve_equals_host_range_solve(T):
+    api = T.api()
+    text = api.Paf.synth(6, 120, 5, dup_every=4).to_text()
+    hb = api.Paf.parse(text).batch()
+    want = T.oracle_solve(hb, 16)
+    rc, out, dev = _emul_ranges(T, text, 16)
+    assert rc == 0
+    try:
+        got = unpack_out(out)
+    finally:
+        T.emul().emul_free_out(C.byref(out))
+    assert T.diff_outputs(want, got) == []
+    n = int(hb.arrays["rec_rng_off"][-1])
+    assert np.array_equal(T.emul_debug("rql_w", np.int64)[:n], hb.arrays["rng_qry_l"])
+
+
+BAD = [
+    b":10*ac:5+gg:3-t:3",        # consumes one base too many
+    b":10*a:5",                  # substitution with one letter
+    b":10*acg:5",                # ... with three
+    b":0*ac",                    # zero length
+    b":10+:5",                   # empty insertion
+    b":10?:5",                   # not a cs character
+    b"10:5",                     # does not start with an operation
+    b":5:-3",                    # negative length
+    b":1234567890123456789",     # 19 digits
+]
+
+
+@pytest.mark.parametrize("k", range(len(BAD)))
+def test_device_cs_rejects_what_the_host_codec_rejects(T, k):
+    api = T.api()
+    good = b":10*ac:5+gg:3-t:2"
+    q, r = _consumed(good)
+    rows = [_row(good, True, qs=1000 * (i + 1), ql=q, rl=r) for i in range(5)]
+    rows[3] = _row(BAD[k], True, qs=4000, ql=q, rl=r)
+    text = b"".join(rows)
+    with pytest.raises(api.AlignasmError):
+        api.Paf.parse(text)                                # the host reader rejects the file ...
+    rc, out, dev = _emul_ranges(T, text)
+    assert rc == -7                                        # ... and so does the device parser: AASM_E_PARSE
+    assert T.emul().emul_last_bad_record() == 3

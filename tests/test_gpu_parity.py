@@ -88,3 +88,50 @@ def test_sequential_select_fallback_on_gpu(T, case):
     want = T.oracle_solve(hb, K, nsl)
     got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, sequential_select=True)
     assert T.diff_outputs(want, got) == []
+
+
+# ---- K0: match ranges parsed from the cs tags on the device (64-byte windows, one byte per lane)
+def test_device_cs_ranges(T):
+    from test_cs_device import TAGS, _consumed, _row
+    api = T.api()
+    rows = []
+    for cs in TAGS:
+        q, r = _consumed(cs)
+        for fwd in (True, False):
+            rows.append(_row(cs, fwd, qs=1000 * (len(rows) + 1), ql=q, rl=r))
+    text = b"".join(rows) + api.Paf.synth(8, 150, 3, dup_every=5).to_text()
+    host = api.Paf.parse(text).batch().arrays
+    dev = api.Paf.parse(text, device_ranges=True)
+    db = api.DeviceBatch(dev)
+    res = db.solve(max_paths=4, keep_debug=True)
+    n = int(host["rec_rng_off"][-1])
+    for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
+        assert np.array_equal(res.debug(name, np.int64)[:n], host[key]), name
+    res.close(); db.close()
+
+
+def test_device_cs_solve_equals_host_range_solve_and_oracle(T, monkeypatch):
+    api = T.api()
+    text = api.Paf.synth(40, 200, 9, dup_every=4, shuffle=True).to_text()
+    host_paf, dev_paf = api.Paf.parse(text), api.Paf.parse(text, device_ranges=True)
+    want = T.oracle_solve(host_paf.batch(), 16)
+    a = api.solve_batch(host_paf, max_paths=16)
+    b = api.solve_batch(dev_paf, max_paths=16)
+    assert T.diff_outputs(want, a) == [] and T.diff_outputs(want, b) == []
+    monkeypatch.setenv("AASM_TEST_MAX_CONTIGS", "7")               # ranges split on the host: cs text re-based per range
+    c = api.solve_batch(dev_paf, max_paths=16)
+    monkeypatch.delenv("AASM_TEST_MAX_CONTIGS")
+    assert T.diff_outputs(b, c, stats=False) == []
+
+
+def test_device_cs_reports_malformed_tags(T):
+    from test_cs_device import BAD, _consumed, _row
+    api = T.api()
+    good = b":10*ac:5+gg:3-t:2"
+    q, r = _consumed(good)
+    for k, bad in enumerate(BAD):
+        rows = [_row(good, True, qs=1000 * (i + 1), ql=q, rl=r) for i in range(70)]
+        rows[41] = _row(bad, k % 2 == 0, qs=42000, ql=q, rl=r)
+        with pytest.raises(api.AlignasmError) as e:
+            api.solve_batch(api.Paf.parse(b"".join(rows), device_ranges=True), max_paths=4)
+        assert e.value.code == -7 and "(record 41)" in str(e.value), (k, str(e.value))
