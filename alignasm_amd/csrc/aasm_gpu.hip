@@ -39,7 +39,7 @@ namespace aasm {
                (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }
-AASM_DEF_KERNEL_LDS(aasm_k0_cs_ranges, KN_CS_RANGES, 64, CS_LDS_BYTES, 8)
+AASM_DEF_KERNEL(aasm_k0_cs_ranges, KN_CS_RANGES, 256)
 AASM_DEF_KERNEL_LDS(aasm_k1_sort, KN_SORT, 256, AASM_SORT_LDS_BYTES, 2)
 AASM_DEF_KERNEL(aasm_k1_sort_fix, KN_SORT_FIX, 64)
 AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)

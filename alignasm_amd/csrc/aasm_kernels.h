@@ -104,98 +104,85 @@ AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 
 
 // ====================================================================================
 // K0  match ranges from short-form cs tags (get_overlap_range, paf_data.cpp:90-123, over the
-//     tokenizer parse_short_cs, :29-72).  One wave per record.
+//     tokenizer parse_short_cs, :29-72).  One THREAD per record.
 // ====================================================================================
-// The tag is read in windows of 64 bytes, one byte per lane.  The operation characters
-// (':' '*' '+' '-') cannot occur inside an operation's payload, so a ballot of them cuts the
-// window into operations; every lane that holds an operation character owns that operation:
-// it checks the payload's character class against the digit / letter ballots, reads a ':'
-// length from the staged window (an operation that runs past the window end is finished by
-// its lane from global memory), and the query / reference advances become coordinates by a
-// wave prefix sum on top of the running totals.  A '-' strand record is walked in text order
-// from the query END (the reference walks the operations last to first, :75-86), and its
-// ranges are written back to front, so no second pass is needed.  Bit-exact with the host
-// codec (tests); a malformed tag (any of the tokenizer's or the consumption check's errors,
-// :119-122) puts the record's index into cs_bad and the solve fails with AASM_E_PARSE.
-#define CS_LDS_BYTES 128
+// Every lane scans its own tag, eight bytes per load, through the tokenizer's little state
+// machine (operation character -> close the previous operation, open the next; otherwise one
+// more digit / letter of the payload), so all 64 lanes do useful work on every instruction - a
+// wave-cooperative parse of ONE tag (ballots over 64-byte windows) was measured 6x slower: at
+// ~8 bytes per operation most lanes idle.  The ranges of a record go to its own slice of the
+// three range arrays (offsets from the reader's count of ':' operations).  A '-' strand record
+// is walked in text order from the query END (the reference walks the operations last to
+// first, :75-86) and its ranges are written back to front, so no second pass is needed.
+// Bit-exact with the host codec (tests); a malformed tag (any of the tokenizer's errors or the
+// consumption check, :119-122) puts the record's index into cs_bad and the solve fails with
+// AASM_E_PARSE.
 AASM_DEV bool cs_is_op(int c) { return c == ':' || c == '*' || c == '+' || c == '-'; }
-AASM_DEV bool cs_is_digit(int c) { return (unsigned)(c - '0') <= 9u; }
-AASM_DEV bool cs_is_alpha(int c) { return (unsigned)((c | 32) - 'a') < 26u; }
+struct CsScan {
+    int64_t q, rr, val, n, cnt, o0;
+    int32_t plen;
+    int t;                  // open operation (its character), 0 before the first
+    bool fwd, bad;
+};
+AASM_DEV void cs_close_op(CsScan &s, const WS &w) {                  // the open operation is complete
+    if (s.t == ':') {                                                // :42-49, then :101-107
+        if (s.plen < 1 || s.plen > 18 || s.val <= 0 || s.n >= s.cnt) { s.bad = true; return; }
+        if (s.fwd) {
+            const int64_t o = s.o0 + s.n;
+            w.rql_w[o] = s.q; w.rqr_w[o] = s.q + s.val - 1; w.rrl_w[o] = s.rr;
+            s.q += s.val;
+        } else {
+            const int64_t o = s.o0 + s.cnt - 1 - s.n;
+            w.rql_w[o] = s.q - s.val; w.rqr_w[o] = s.q - 1; w.rrl_w[o] = s.rr + s.val - 1;
+            s.q -= s.val;
+        }
+        s.rr += s.val;
+        s.n++;
+    } else if (s.t == '*') {                                         // :50-56, :112-116
+        if (s.plen != 2) { s.bad = true; return; }
+        s.q += s.fwd ? 1 : -1; s.rr += 1;
+    } else {                                                         // :57-64
+        if (s.plen < 1) { s.bad = true; return; }
+        if (s.t == '+') s.q += s.fwd ? s.plen : -s.plen; else s.rr += s.plen;
+    }
+}
 AASM_DEV void kb_cs_ranges(const KCtx &k, const WS &w) {
-    if (k.bid >= w.R) return;
-    const int64_t r = w.R0 + k.bid;
+    const int64_t br = k.bid * k.nthreads + k.tid;
+    if (br >= w.R) return;
+    const int64_t r = w.R0 + br;
     const int64_t p0 = w.cs_off[r], len = w.cs_off[r + 1] - p0;
-    const char *cs = w.cs_text + p0;
-    uint8_t *win = (uint8_t *)k.lds;                                 // the window's bytes, for the ':' lengths
-    const bool fwd = w.in_fwd[r] != 0;
+    const uint8_t *cs = (const uint8_t *)w.cs_text + p0;
     const int64_t qs = w.in_qs[r], qe = w.in_qe[r], rs = w.in_rs[r], re = w.in_re[r];
-    const int64_t o0 = w.in_rng_off[r], cnt = w.in_rng_off[r + 1] - o0;
-    int64_t q = fwd ? qs : qe + 1, rr = fwd ? rs : re;               // fwd: next query / ref base; rev: query end (exclusive) / lowest ref base not yet consumed
-    int64_t n = 0;
-    bool bad = len < 5;
-    if (!bad) {                                                      // "cs:Z:" (:30-33)
-        const char pre[5] = {'c', 's', ':', 'Z', ':'};
-        bool mism = false;
-        for (int t = k.lane; t < 5; t += AASM_WAVE) mism |= cs[t] != pre[t];
-        bad = wave_ballot(mism) != 0;
-    }
-    for (int64_t base = 5; base < len && !bad; base += AASM_WAVE) {
-        const int64_t i = base + k.lane;
-        const bool have = i < len;
-        const int b = have ? (int)(uint8_t)cs[i] : 0;
-        const bool isop = have && cs_is_op(b);
-        const uint64_t M = wave_ballot(isop), D = wave_ballot(have && cs_is_digit(b)), A = wave_ballot(have && cs_is_alpha(b));
-        const uint64_t CM = wave_ballot(isop && b == ':');
-        const int nvalid = (int)((len - base < AASM_WAVE) ? (len - base) : AASM_WAVE);
-        win[k.lane] = (uint8_t)b;
-        wave_lds_sync();
-        bool lbad = have && !isop && !cs_is_digit(b) && !cs_is_alpha(b);   // not a cs character at all
-        if (base == 5 && k.lane == 0 && !isop) lbad = true;          // the tag must start with an operation (:66-68)
-        int64_t dq = 0, dr = 0, val = 0;
-        if (isop) {
-            const uint64_t above = (k.lane >= 63) ? 0 : (M >> (k.lane + 1)) << (k.lane + 1);     // operations after this one, in the window
-            const int nxt = above ? ffs64(above) - 1 : AASM_WAVE;
-            const int pend = nxt < nvalid ? nxt : nvalid;            // payload = window positions (lane, pend)
-            int64_t plen = pend - k.lane - 1;
-            const uint64_t PM = (plen > 0) ? ((plen >= 64 ? ~0ull : ((1ull << plen) - 1)) << (k.lane + 1)) : 0;
-            if (b == ':') {
-                if (PM & ~D) lbad = true;
-                for (int t = k.lane + 1; t < pend && plen <= 18; t++) val = val * 10 + (win[t] - '0');
-            } else if (PM & ~A) lbad = true;
-            if (!above && base + AASM_WAVE < len) {                  // the operation may run past the window: finish it from memory
-                for (int64_t j = base + AASM_WAVE; j < len; j++) {
-                    const int c2 = (int)(uint8_t)cs[j];
-                    if (cs_is_op(c2)) break;
-                    if (b == ':') { if (!cs_is_digit(c2)) lbad = true; else if (plen < 18) val = val * 10 + (c2 - '0'); }
-                    else if (!cs_is_alpha(c2)) lbad = true;
-                    plen++;
-                }
-            }
-            if (b == ':') { if (plen < 1 || plen > 18 || val <= 0) lbad = true; dq = val; dr = val; }      // :42-49
-            else if (b == '*') { if (plen != 2) lbad = true; dq = 1; dr = 1; }                             // :50-56
-            else { if (plen < 1) lbad = true; if (b == '+') dq = plen; else dr = plen; }                  // :57-64
+    CsScan s;
+    s.fwd = w.in_fwd[r] != 0;
+    s.o0 = w.in_rng_off[r]; s.cnt = w.in_rng_off[r + 1] - s.o0;
+    s.q = s.fwd ? qs : qe + 1; s.rr = s.fwd ? rs : re;              // fwd: next query / ref base; rev: query end (exclusive) / lowest ref base not yet consumed
+    s.val = 0; s.n = 0; s.plen = 0; s.t = 0;
+    s.bad = len < 5 || cs[0] != 'c' || cs[1] != 's' || cs[2] != ':' || cs[3] != 'Z' || cs[4] != ':';   // :30-33
+    for (int64_t pos = 5; pos < len && !s.bad; ) {
+        uint64_t wd = 0;                                             // the next <= 8 bytes, first byte lowest
+        int nb = (int)((len - pos < 8) ? (len - pos) : 8);
+        const int mis = (int)((uintptr_t)(cs + pos) & 7);
+        if (mis == 0 && nb == 8) wd = *(const uint64_t *)(cs + pos);
+        else { if (nb > 8 - mis) nb = 8 - mis; for (int t = 0; t < nb; t++) wd |= (uint64_t)cs[pos + t] << (8 * t); }   // up to the next aligned word / the end
+        pos += nb;
+        for (int t = 0; t < nb && !s.bad; t++) {
+            const int c = (int)(wd & 0xff);
+            wd >>= 8;
+            if (cs_is_op(c)) {
+                if (s.t) cs_close_op(s, w);
+                s.t = c; s.plen = 0; s.val = 0;
+            } else if (s.t == ':') {
+                const unsigned dg = (unsigned)(c - '0');
+                if (dg > 9u) s.bad = true;
+                else { if (s.plen < 18) s.val = s.val * 10 + dg; s.plen++; }
+            } else if (s.t && (unsigned)((c | 32) - 'a') < 26u) s.plen++;
+            else s.bad = true;                                       // not a cs character, or payload before any operation (:66-68)
         }
-        const int64_t iq = wave_incl_add(dq), ir = wave_incl_add(dr);
-        const int64_t Q = iq - dq, Rr = ir - dr;                     // advances of the operations before this one, in the window
-        if (isop && b == ':' && !lbad) {
-            const int64_t idx = n + popc64(CM & lanemask_lt(k.lane));
-            if (idx >= cnt) lbad = true;
-            else if (fwd) {
-                const int64_t o = o0 + idx, ql = q + Q;
-                w.rql_w[o] = ql; w.rqr_w[o] = ql + val - 1; w.rrl_w[o] = rr + Rr;              // :101-107
-            } else {
-                const int64_t o = o0 + cnt - 1 - idx, qh = q - Q;
-                w.rql_w[o] = qh - val; w.rqr_w[o] = qh - 1; w.rrl_w[o] = rr + Rr + val - 1;
-            }
-        }
-        const int64_t tq = wave_bcast(iq, AASM_WAVE - 1), tr = wave_bcast(ir, AASM_WAVE - 1);
-        q += fwd ? tq : -tq; rr += tr;
-        n += popc64(CM);
-        bad = wave_ballot(lbad) != 0;
-        wave_lds_sync();
     }
-    if (!bad) bad = (n != cnt) || (fwd ? (q != qe + 1 || rr != re + 1) : (q != qs || rr != rs + 1));   // :119-122
-    if (bad && k.lane == 0) atomic_min_i32(w.cs_bad, (int32_t)(k.bid - INT32_MAX));
+    if (!s.bad && s.t) cs_close_op(s, w);
+    if (!s.bad) s.bad = (s.n != s.cnt) || (s.fwd ? (s.q != qe + 1 || s.rr != re + 1) : (s.q != qs || s.rr != rs + 1));   // :119-122
+    if (s.bad) atomic_min_i32(w.cs_bad, (int32_t)(br - INT32_MAX));
 }
 
 // ====================================================================================

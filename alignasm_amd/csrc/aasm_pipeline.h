@@ -104,7 +104,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         CHECK_ALLOC();
         w.rql_w -= G0; w.rqr_w -= G0; w.rrl_w -= G0;                // indexed with the batch's own range offsets
         be.zero(w.cs_bad, 8);
-        be.launch(KN_CS_RANGES, R, AASM_WAVE, w);
+        be.launch(KN_CS_RANGES, cdiv(R, 256), 256, w);
         be.phase_end(AASM_PH_CS);
         const int32_t badv = (int32_t)(uint32_t)(uint64_t)be.read_i64((const int64_t *)w.cs_bad);   // 0 = none, else record - INT32_MAX
         if (badv != 0) { sz.bad_record = R0 + ((int64_t)badv + INT32_MAX); return AASM_E_PARSE; }

@@ -1,6 +1,6 @@
 """K0 (aasm_k0_cs_ranges): match ranges derived from the cs tags by the solver itself instead
 of by the host reader.  CPU tier: the kernel body in the 1-lane host emulation against the
-host codec; GPU tier (64-lane windows): tests/test_gpu_parity.py::test_device_cs_ranges."""
+host codec; GPU tier: tests/test_gpu_parity.py::test_device_cs_ranges."""
 import ctypes as C
 
 import numpy as np

@@ -90,7 +90,7 @@ def test_sequential_select_fallback_on_gpu(T, case):
     assert T.diff_outputs(want, got) == []
 
 
-# ---- K0: match ranges parsed from the cs tags on the device (64-byte windows, one byte per lane)
+# ---- K0: match ranges parsed from the cs tags on the device (one thread per record)
 def test_device_cs_ranges(T):
     from test_cs_device import TAGS, _consumed, _row
     api = T.api()
