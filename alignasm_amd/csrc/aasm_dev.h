@@ -132,6 +132,20 @@ template <class T> struct LaneArr { T r; AASM_MEM T &at(int) { return r; } };
 #define LA_SET(arr, j, lane, value) do { if ((lane) == (j)) (arr).r = (value); } while (0)
 #endif
 
+// c[j] <- min of c[i] over j < i < n (INT32_MAX where there is none), n <= 64
+AASM_DEV void lane_excl_suffix_min(LaneArr<int32_t> &c, int n, int lane) {
+#if defined(AASM_HOST_EMUL)
+    int32_t run = INT32_MAX;
+    for (int j = n - 1; j >= 0; j--) { const int32_t t = c.a[j]; c.a[j] = run; run = t < run ? t : run; }
+    (void)lane;
+#else
+    int32_t x = lane < n ? c.r : INT32_MAX;
+    for (int d = 1; d < AASM_WAVE; d <<= 1) { const int32_t y = __shfl_down(x, d, 64); if (lane + d < AASM_WAVE && y < x) x = y; }
+    const int32_t e = __shfl_down(x, 1, 64);
+    c.r = (lane + 1 < AASM_WAVE) ? e : INT32_MAX;
+#endif
+}
+
 // mask of the indices j in [0, n), n <= 64, for which pred(j) holds: lane j evaluates pred(j)
 template <class P> AASM_DEV uint64_t wave_index_mask(int n, int lane, P pred) {
 #if defined(AASM_HOST_EMUL)

@@ -1108,9 +1108,9 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 //                 (lane j = j-th node from the root).  80-96 % of the inserts continue from
 //                 exactly that heap, and an insert's descent path is a prefix of its right
 //                 spine, so the descent is ONE lane-parallel compare + ballot and the copied
-//                 nodes of the path are built and stored by all lanes at once.  Only the rank
-//                 chain (pure arithmetic, leftist_heap.hpp:36-38) is sequential, on scalars
-//                 read with v_readlane.  A rank swap at position t sends the new spine into an
+//                 nodes of the path are built and stored by all lanes at once; the rank chain
+//                 (leftist_heap.hpp:36-38) is a min-plus recurrence, solved by one suffix-min
+//                 over the lanes.  A rank swap at position t sends the new spine into an
 //                 old left subtree: the cache then holds positions 0..t plus the node where it
 //                 continues (tail); the walk past the cached prefix (or after a root switch)
 //                 chases pointers and appends what it reads to the cache.
@@ -1183,16 +1183,24 @@ AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, Spine &sp, int32_t &alloc
     }
     KPROF_STAMP(4);                                                                 // descent
     if (alloc + depth + 1 > cap) { ovf = true; return -1; }
-    // ---- rank chain, bottom-up (:34-38): scalar arithmetic on the cached path
-    int32_t r_rank = 1;                                                             // the new leaf has rank 1 (:31)
-    for (int32_t j = depth - 1; j >= 0; j--) {
-        const int32_t l = LA_GET(sp.n, j, .q2.x), l_rank = (LA_GET(sp.n, j, .q1.w) >> 8) & 0xff;
+    // ---- rank chain (:34-38).  Bottom-up the recursion computes, with R = rank of the subtree
+    // below and R_depth = 1 (the new leaf, :31):  swap iff l == null or rank(l) < R;  rank of the
+    // copy R_j = 0 if l == null (the copy then has no right child) else min(rank(l), R) + 1.
+    // With a_j = 0 / rank(l_j) + 1 that is R_j = min(a_j, R_{j+1} + 1), a min-plus recurrence with
+    // the closed form R_j = min_{i >= j}(a_i + i) - j (a_depth = 1): one suffix-min over the lanes.
+    FOR_LANE(j, depth + 1, lane) {
+        if (j == depth) sp.t.at(j) = depth + 1;
+        else { const NodeQ &nj = sp.n.at(j); sp.t.at(j) = ((nj.q2.x < 0) ? 0 : (((nj.q1.w >> 8) & 0xff) + 1)) + j; }
+    }
+    lane_excl_suffix_min(sp.t, depth + 1, lane);                                    // t[j] = R_{j+1} + (j + 1)
+    FOR_LANE(j, depth, lane) {
+        const NodeQ &nj = sp.n.at(j);
+        const int32_t l = nj.q2.x, l_rank = (nj.q1.w >> 8) & 0xff, r_rank = sp.t.at(j) - (j + 1);
         const bool sw = (l < 0) || (l_rank < r_rank);                               // :36-37
         const bool has_right = sw ? (l >= 0) : true;
         const int32_t nr_rank = has_right ? (sw ? l_rank : r_rank) : 0;
         const int32_t nrank = has_right ? nr_rank + 1 : 0;                          // :38
-        LA_SET(sp.t, j, lane, nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16) | ((sw ? 1 : 0) << 24));
-        r_rank = nrank;
+        sp.t.at(j) = nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16) | ((sw ? 1 : 0) << 24);
     }
     // ---- new nodes: leaf = alloc, copy of path position j = alloc + (depth - j)  (allocation order of the recursion)
     const int32_t nalloc = alloc + depth + 1;
