@@ -96,6 +96,7 @@ struct WS {
     Dist *st_cost;
     uint8_t *st_fl;
     I4 *vhdr, *vhdr2;
+    I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
@@ -876,15 +877,46 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
 // `d[to] > d[v] + w` test reproduces the reference's first-wins tie behaviour (hazard B2)
 // without any extra key: targets inside one in-list are distinct, so the 64 lanes relax a
 // whole in-list at once; newly free vertices are appended in list order by ballot+prefix.
+//
+// The sweep is a chain of dependent memory round trips per popped vertex, so the data is laid
+// out to shorten the chain: kb_rev_hdr (thread per vertex) packs {in-list start, in-degree} and
+// the first TWO in-edges with their weights (the mean in-degree is ~2) into 64 bytes that are
+// read together with d[v]; the queue's front window lives in LDS.  That leaves three trips per
+// pop: {header, d[v]} -> {d[u], cnt[u]} -> the stores becoming visible.
+#define REVQ_N 128
+#define AASM_REV_LDS_BYTES (REVQ_N * 4)
+AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
+    const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
+    I4 h[4];
+    for (int t = 0; t < 4; t++) { h[t].x = h[t].y = h[t].z = h[t].w = 0; }
+    h[0].x = (int32_t)(uint32_t)(uint64_t)r0; h[0].y = (int32_t)((uint64_t)r0 >> 32); h[0].z = (int32_t)(r1 - r0);
+    if (r1 > r0) {
+        const int64_t e = e_base + w.r_e[r0], wq = w.e_wq[e];
+        h[0].w = w.r_src[r0];
+        h[1].x = (int32_t)(uint32_t)(uint64_t)wq; h[1].y = (int32_t)((uint64_t)wq >> 32); h[1].z = w.e_wr[e]; h[1].w = w.e_fl[e];
+    }
+    if (r1 > r0 + 1) {
+        const int64_t e = e_base + w.r_e[r0 + 1], wq = w.e_wq[e];
+        h[2].x = w.r_src[r0 + 1]; h[2].y = (int32_t)(uint32_t)(uint64_t)wq; h[2].z = (int32_t)((uint64_t)wq >> 32); h[2].w = w.e_wr[e];
+        h[3].x = w.e_fl[e];
+    }
+    for (int t = 0; t < 4; t++) w.rvh[4 * gv + t] = h[t];
+}
+
 AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
     const int64_t vb = w.voff[c], e_base = w.rowptr[vb];
+    int32_t *ql = (int32_t *)k.lds;                                  // queue positions [head, lds_hi) are also here
     Dist *d = w.sp_d + vb;
     int32_t *best = w.sp_best + vb, *q = w.rev_order + vb, *cnt = w.cnt_tmp + vb;
+    const I4 *rvh = w.rvh + 4 * vb;
     const int32_t dest = (int32_t)(V - 1);
-    int32_t tail = 0;
+    int32_t tail = 0, lds_hi = 0;
     for (int64_t base = 0; base < V; base += AASM_WAVE) {          // init + sources in ascending id (:139-141)
         const int64_t v = base + k.lane;
         const bool act = v < V;
@@ -897,26 +929,36 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
         }
         const bool z = act && od == 0;
         const uint64_t m = wave_ballot(z);
-        if (z) q[tail + popc64(m & lanemask_lt(k.lane))] = (int32_t)v;
+        const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+        if (z) { q[at] = (int32_t)v; if (at < REVQ_N) ql[at] = (int32_t)v; }
         tail += popc64(m);
     }
+    lds_hi = tail < REVQ_N ? tail : REVQ_N;
     wave_fence();
+    wave_lds_sync();
     int32_t head = 0;
     while (head < tail) {
-        const int32_t v = q[head++];
-        const Dist dv = d[v];
+        int32_t v;
+        if (head < lds_hi) v = uni(ql[head & (REVQ_N - 1)]);
+        else v = uni(q[head]);
+        head++;
+        const I4 h0 = uni(rvh[4 * v]), h1 = uni(rvh[4 * v + 1]), h2 = uni(rvh[4 * v + 2]), h3 = uni(rvh[4 * v + 3]);
+        const Dist dv = uni(d[v]);
         const bool reach = !dist_is_max(dv);                         // :166
-        const int64_t r0 = w.rptr[vb + v], r1 = w.rptr[vb + v + 1];
-        for (int64_t base = r0; base < r1; base += AASM_WAVE) {
-            const int64_t p = base + k.lane;
-            const bool act = p < r1;
+        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)h0.y << 32) | (uint32_t)h0.x);
+        const int32_t deg = h0.z;
+        for (int32_t base = 0; base < deg; base += AASM_WAVE) {
+            const int32_t t = base + k.lane;
+            const bool act = t < deg;
             bool z = false;
             int32_t u = 0;
             if (act) {
-                u = w.r_src[p];
+                int64_t wq; int32_t wr; uint8_t fl;
+                if (t == 0) { u = h0.w; wq = (int64_t)(((uint64_t)(uint32_t)h1.y << 32) | (uint32_t)h1.x); wr = h1.z; fl = (uint8_t)h1.w; }
+                else if (t == 1) { u = h2.x; wq = (int64_t)(((uint64_t)(uint32_t)h2.z << 32) | (uint32_t)h2.y); wr = h2.w; fl = (uint8_t)h3.x; }
+                else { const int64_t p = r0 + t; u = w.r_src[p]; const int64_t e = e_base + w.r_e[p]; wq = w.e_wq[e]; wr = w.e_wr[e]; fl = w.e_fl[e]; }
                 if (reach) {
-                    const int64_t e = e_base + w.r_e[p];
-                    const Dist cand = dist_add(dv, edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]));
+                    const Dist cand = dist_add(dv, edge_dist(wq, wr, fl));
                     if (dist_lt<CALC_SUM_MODE>(cand, d[u])) { d[u] = cand; best[u] = v; }   // :168-171
                 }
                 const int32_t left = cnt[u] - 1;
@@ -924,10 +966,14 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
-            if (z) q[tail + popc64(m & lanemask_lt(k.lane))] = u;
-            tail += popc64(m);
+            const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+            if (z) { q[at] = u; if (lds_hi == tail && at - head < REVQ_N) ql[at & (REVQ_N - 1)] = u; }
+            const int32_t nnew = popc64(m);
+            if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
+            tail += nnew;
         }
         wave_fence();
+        wave_lds_sync();
     }
     if (tail != (int32_t)V && k.lane == 0) set_status(w, c, -6);    // cycle: cannot happen (:144-148)
 }

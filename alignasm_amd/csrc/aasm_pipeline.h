@@ -21,7 +21,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_SWEEP, KN_FWD_SWEEP,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP,
     KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
@@ -43,6 +43,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_SORT_ROWS_REV: kb_sort_rows(k, w, w.rptr, w.r_e, w.r_src, w.VT); break;
+        case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep(k, w); break;
         case KN_FWD_SWEEP: kb_fwd_sweep(k, w); break;
         case KN_CHILD_COUNT: kb_child_count(k, w); break;
@@ -188,6 +189,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.scan_i32(w.indeg, VT, w.rptr);
         be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
         be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        A(rvh, I4, 4 * VT, "rvh");
+        CHECK_ALLOC();
+        be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
 
         // ---- K6 / K5 sweeps.  The forward sweep + the topologically ordered CSR copy only feed
