@@ -97,6 +97,7 @@ struct WS {
     uint8_t *st_fl;
     I4 *vhdr, *vhdr2;
     I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
+    I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
@@ -904,6 +905,12 @@ AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread pe
         h[3].x = w.e_fl[e];
     }
     for (int t = 0; t < 4; t++) w.rvh[4 * gv + t] = h[t];
+    // the same for the forward sweep: row start, out-degree and the first two out-edges (head, anomaly weight)
+    const int64_t o0 = w.rowptr[gv], o1 = w.rowptr[gv + 1];
+    I4 f0, f1;
+    f0.x = (int32_t)(uint32_t)(uint64_t)o0; f0.y = (int32_t)((uint64_t)o0 >> 32); f0.z = (int32_t)(o1 - o0); f0.w = (o1 > o0) ? w.e_col[o0] : 0;
+    f1.x = (o1 > o0) ? (w.e_fl[o0] & 3) : 0; f1.y = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0; f1.z = (o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0; f1.w = 0;
+    w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
 }
 
 AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
@@ -987,9 +994,11 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
     const int64_t vb = w.voff[c];
+    int32_t *ql = (int32_t *)k.lds;                                  // queue positions [head, lds_hi) are also here
     int32_t *q = w.fwd_order + vb, *pos = w.fwd_pos + vb, *cnt = w.cnt_tmp2 + vb, *an = w.an + vb;
+    const I4 *fvh = w.fvh + 2 * vb;
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
-    int32_t tail = 0;
+    int32_t tail = 0, lds_hi = 0;
     for (int64_t base = 0; base < V; base += AASM_WAVE) {
         const int64_t v = base + k.lane;
         const bool act = v < V;
@@ -997,24 +1006,34 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
         if (act) { id = w.indeg[vb + v]; cnt[v] = id; an[v] = (v == src) ? 0 : -1; }
         const bool z = act && id == 0;
         const uint64_t m = wave_ballot(z);
-        if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = (int32_t)v; pos[v] = t; }
+        if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = (int32_t)v; pos[v] = t; if (t < REVQ_N) ql[t] = (int32_t)v; }
         tail += popc64(m);
     }
+    lds_hi = tail < REVQ_N ? tail : REVQ_N;
     wave_fence();
+    wave_lds_sync();
     int32_t head = 0;
     while (head < tail) {
-        const int32_t u = q[head++];
-        const int32_t au = an[u];
-        const int64_t r0 = w.rowptr[vb + u], r1 = w.rowptr[vb + u + 1];
-        for (int64_t base = r0; base < r1; base += AASM_WAVE) {
-            const int64_t e = base + k.lane;
-            const bool act = e < r1;
+        int32_t u;
+        if (head < lds_hi) u = uni(ql[head & (REVQ_N - 1)]);
+        else u = uni(q[head]);
+        head++;
+        const I4 f0 = uni(fvh[2 * u]), f1 = uni(fvh[2 * u + 1]);
+        const int32_t au = uni(an[u]);
+        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)f0.y << 32) | (uint32_t)f0.x);
+        const int32_t deg = f0.z;
+        for (int32_t base = 0; base < deg; base += AASM_WAVE) {
+            const int32_t t = base + k.lane;
+            const bool act = t < deg;
             bool z = false;
             int32_t v = 0;
             if (act) {
-                v = w.e_col[e];
+                int32_t wa;
+                if (t == 0) { v = f0.w; wa = f1.x; }
+                else if (t == 1) { v = f1.y; wa = f1.z; }
+                else { v = w.e_col[r0 + t]; wa = w.e_fl[r0 + t] & 3; }
                 if (au >= 0) {
-                    const int32_t nd = au + (w.e_fl[e] & 3);
+                    const int32_t nd = au + wa;
                     if (an[v] < 0 || nd < an[v]) an[v] = nd;
                 }
                 const int32_t left = cnt[v] - 1;
@@ -1022,10 +1041,14 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
-            if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = v; pos[v] = t; }
-            tail += popc64(m);
+            const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+            if (z) { q[at] = v; pos[v] = at; if (lds_hi == tail && at - head < REVQ_N) ql[at & (REVQ_N - 1)] = v; }
+            const int32_t nnew = popc64(m);
+            if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
+            tail += nnew;
         }
         wave_fence();
+        wave_lds_sync();
     }
     if (k.lane == 0) {
         w.anom_dest[c] = an[dest];

@@ -189,7 +189,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.scan_i32(w.indeg, VT, w.rptr);
         be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
         be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
-        A(rvh, I4, 4 * VT, "rvh");
+        A(rvh, I4, 4 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
         CHECK_ALLOC();
         be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
