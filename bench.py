@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--recs", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2000, help="contigs of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=5000, help="contigs of the workload timed on the CPU oracle")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
