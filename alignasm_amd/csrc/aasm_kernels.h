@@ -96,6 +96,7 @@ struct WS {
     Dist *st_cost;
     uint8_t *st_fl;
     I4 *vhdr, *vhdr2;
+    I4 *tnx;                             // next four vertices along best[] (path recovery reads one record per four tree edges)
     I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
 };
@@ -1151,6 +1152,12 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     a.x = (int32_t)(uint32_t)(uint64_t)r0; a.y = (int32_t)((uint64_t)r0 >> 32); a.z = (int32_t)(r1 - r0); a.w = (int32_t)(c1 - c0);
     b.x = (c1 > c0) ? w.cval[c0] : -1; b.y = (int32_t)(uint32_t)(uint64_t)c0; b.z = (int32_t)((uint64_t)c0 >> 32); b.w = 0;
     w.vhdr[gv] = a; w.vhdr2[gv] = b;
+    I4 t;                                                            // best[] is final here (K6 done)
+    t.x = bu;
+    t.y = t.x >= 0 ? w.sp_best[vb + t.x] : -1;
+    t.z = t.y >= 0 ? w.sp_best[vb + t.y] : -1;
+    t.w = t.z >= 0 ? w.sp_best[vb + t.z] : -1;
+    w.tnx[gv] = t;
 }
 
 // arena capacity per contig: an insert into a heap of s nodes allocates at most
@@ -1636,7 +1643,6 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     if (kidx < 0 || kidx >= w.kfound[s.c]) return 0;
     const int32_t *knodes = w.knodes + s.c * (3 * K + 1), *kprev = w.kprev + s.c * (3 * K + 1);
     const HNode *nodes = w.hnodes + w.hoff[s.c];
-    const int32_t *best = w.sp_best + s.vb;
     int32_t ns = 0;
     int32_t cur = w.klast[s.c * K + kidx];
     while (cur != -1) {                                             // sidetrack chain, newest first
@@ -1657,11 +1663,16 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
             sel_push(s, cv, st_v);
             cv = st_v; idx--;
             if (idx >= 0) { st_u = uni(s.pathT[2 * idx]); st_v = uni(s.pathT[2 * idx + 1]); }
-        } else {
-            const int32_t nx = uni(best[cv]);
-            if (nx < 0) { s.err = true; return -1; }
-            sel_push(s, cv, nx);
-            cv = nx;
+        } else {                                                     // up to four tree edges per load
+            const I4 nx4 = uni(w.tnx[s.vb + cv]);
+            const int32_t nxv[4] = {nx4.x, nx4.y, nx4.z, nx4.w};
+            for (int t = 0; t < 4; t++) {
+                const int32_t nx = nxv[t];
+                if (nx < 0) { s.err = true; return -1; }
+                sel_push(s, cv, nx);
+                cv = nx;
+                if (s.err || cv == s.dest || (idx >= 0 && cv == st_u)) break;   // the outer loop decides what comes next
+            }
         }
     }
     if (s.err) return -1;

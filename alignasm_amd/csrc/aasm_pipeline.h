@@ -220,7 +220,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP_PREP);
         AZ(ccnt, int32_t, VT, "ccnt"); AZ(ccur, int32_t, VT, "ccur"); A(cptr, int64_t, VT + 1, "cptr"); A(cval, int32_t, VT, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
-        A(st_cost, Dist, ET, "st_cost"); A(st_fl, uint8_t, ET, "st_fl"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2");
+        A(st_cost, Dist, ET, "st_cost"); A(st_fl, uint8_t, ET, "st_fl"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(tnx, I4, VT, "tnx");
         CHECK_ALLOC();
         be.launch(KN_CHILD_COUNT, cdiv(VT, 256), 256, w);
         be.scan_i32(w.ccnt, VT, w.cptr);
