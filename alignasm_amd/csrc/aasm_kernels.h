@@ -1601,9 +1601,11 @@ struct SelLds {
     uint8_t reach[64];
     int32_t res[2 * 64];           // ISPR result edges (u, v), reverse order
     int32_t pa_win[2 * SEL_WIN];   // read window over pathA
+    int32_t pa_vj[SEL_WIN];        // v_j of each window edge's head
+    uint8_t pa_sg[SEL_WIN];        // ... and whether it is a single-record vertex (v_i == v_j)
     int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
 };
-#define AASM_SEL_LDS_BYTES 7168
+#define AASM_SEL_LDS_BYTES 7488
 static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
@@ -1624,16 +1626,27 @@ AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
     s.last_head = v;
     if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
 }
-AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v) {
+// edge `it` of pathA through a 64-edge LDS window.  A refill also fetches, for every edge of the
+// window at once, whether its head is a single-record vertex and its v_j (what the upgrade asks
+// about every edge), so the edge loop itself has no dependent global loads for them.
+AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v, int32_t &vj, bool &single) {
     SelLds *L = (SelLds *)s.lds;
+    const WS &w = *s.w;
     if (it < s.pa_base || it >= s.pa_base + SEL_WIN) {
         wave_lds_sync();
         s.pa_base = it;
         const int32_t n = (la - it < SEL_WIN) ? (la - it) : SEL_WIN;
         for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) L->pa_win[t] = s.pathA[2 * it + t];
+        for (int32_t t = s.lane; t < n; t += AASM_WAVE) {
+            const int32_t hv = s.pathA[2 * (it + t) + 1];
+            const int32_t a = w.v_i[s.vb + hv], b = w.v_j[s.vb + hv];
+            L->pa_vj[t] = b; L->pa_sg[t] = (a == b) ? 1 : 0;
+        }
         wave_lds_sync();
     }
     u = uni(L->pa_win[2 * (it - s.pa_base)]); v = uni(L->pa_win[2 * (it - s.pa_base) + 1]);
+    vj = uni(L->pa_vj[it - s.pa_base]);
+    single = uni((int32_t)L->pa_sg[it - s.pa_base]) != 0;
 }
 
 // k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
@@ -1803,12 +1816,12 @@ AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last) {
 
 // upgrade_edge_path_with_alt_path (paf_data.cpp:795-921): pathA[la] -> pathB; returns lb
 AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
-    const WS &w = *s.w;
     sel_out_begin(s, s.pathB);
     s.pa_base = -SEL_WIN - 1;
     for (int32_t it = 0; it < la && !s.err; ++it) {
-        int32_t u, v;
-        sel_pa_get(s, it, la, u, v);
+        int32_t u, v, vj;
+        bool v_single;
+        sel_pa_get(s, it, la, u, v, vj, v_single);
         const bool from_src = (u == s.src);
         if (from_src || v != s.dest) {
             int32_t start;
@@ -1816,13 +1829,14 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
             else {
                 if (s.out_n == 0) { s.err = true; break; }
                 start = s.last_head;                                 // continuation_src (:863)
-                if (w.v_i[s.vb + v] != w.v_j[s.vb + v]) { sel_push(s, u, v); continue; }   // :866-873
+                if (!v_single) { sel_push(s, u, v); continue; }      // :866-873
             }
-            const int32_t y = uni(w.v_j[s.vb + v]);
+            const int32_t y = vj;
             if (it + 1 >= la) { s.err = true; break; }
-            int32_t nu, nv;
-            sel_pa_get(s, it + 1, la, nu, nv);
-            const bool nv_single = (nv == s.dest) || (w.v_i[s.vb + nv] == w.v_j[s.vb + nv]);
+            int32_t nu, nv, nvj;
+            bool nvs;
+            sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs);
+            const bool nv_single = (nv == s.dest) || nvs;
             if (nv_single) {                                         // :812-833 / :879-899
                 const int32_t n = sel_ispr(s, start, nv, true, y);
                 if (n < 0) break;
