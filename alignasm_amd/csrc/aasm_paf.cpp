@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string_view>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 #include <climits>
@@ -675,13 +676,14 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
 }
 
 // One output file: contigs are cut into one contiguous share per host thread (balanced by
-// element count), every thread formats its share into its own buffer, and the buffers are
+// estimated output bytes), every thread formats its share into its own buffer, and the buffers are
 // written in contig order.
 template <class EMIT>   // EMIT(contig, buf, ops, err) -> rc : appends every line of one contig
 static int write_file_mt(const aasm_paf &paf, const char *path, const std::vector<int64_t> &weight_prefix, EMIT emit) {
     const int64_t C = paf.n_contigs();
     int T = host_threads();
-    if (weight_prefix[C] < 4096) T = 1;
+    if (weight_prefix[C] < (1 << 20)) T = 1;
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::string> bufs((size_t)T), errs((size_t)T);
     std::vector<int> rcs((size_t)T, AASM_OK);
     std::vector<int64_t> cut((size_t)T + 1, C);
@@ -691,10 +693,19 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
     for (int t = 1; t <= T; t++) { if (cut[t] > C) cut[t] = C; if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1]; }
     run_threads(T, [&](int t) {
         std::vector<CsOp> ops;
+        bufs[t].reserve((size_t)(weight_prefix[cut[t + 1]] - weight_prefix[cut[t]]) + 4096);   // the weights are byte estimates: no regrowth copies
         for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], ops, errs[t]);
     });
     for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { set_last_error(errs[t]); return rcs[t]; }   // first failing contig in file order
-    return write_buffers(path, bufs);
+    const auto t1 = std::chrono::steady_clock::now();
+    const int rc = write_buffers(path, bufs);
+    if (std::getenv("AASM_IO_TIMING")) {
+        size_t total = 0;
+        for (auto &b : bufs) total += b.size();
+        std::fprintf(stderr, "aasm io: %s format %.3f s write %.3f s (%.1f MB, %d threads)\n", path, std::chrono::duration<double>(t1 - t0).count(),
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), total / 1e6, T);
+    }
+    return rc;
 }
 
 // the batch as PAF text (12 columns + tp + cs), rows shared out over the host threads
@@ -823,8 +834,27 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
     const int64_t C = paf->n_contigs();
     int rc;
+    // upper estimate of a contig's output bytes: every element costs its record's cs tag + the 14 other columns
+    auto bytes_prefix = [&](const int64_t *off, const aasm_out_elem *el, int64_t extra_name) {
+        std::vector<int64_t> wp((size_t)C + 1, 0);
+        run_threads(host_threads(), [&](int t) {
+            const int T = host_threads();
+            for (int64_t c = C * t / T; c < C * (t + 1) / T; c++) {
+                int64_t b = 0;
+                const int64_t r0 = paf->ctg_rec_off[c], nrec = paf->ctg_rec_off[c + 1] - r0;
+                for (int64_t k = off[c]; k < off[c + 1]; k++) {
+                    const int64_t ci = el[k].ctg_index;
+                    if (ci >= 0 && ci < nrec) b += paf->cs_off[r0 + ci + 1] - paf->cs_off[r0 + ci];
+                    b += 150 + (int64_t)paf->ctg_name[c].size() + extra_name;
+                }
+                wp[c + 1] = b;
+            }
+        });
+        for (int64_t c = 0; c < C; c++) wp[c + 1] += wp[c];
+        return wp;
+    };
     if (main_path) {                                                    // process_output, :407-443
-        std::vector<int64_t> wp(out->main_off, out->main_off + C + 1);
+        const std::vector<int64_t> wp = bytes_prefix(out->main_off, out->main_elems, 0);
         rc = write_file_mt(*paf, main_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
             for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++) {
                 const int r = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, ops, err);
@@ -835,7 +865,7 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
         if (rc != AASM_OK) return rc;
     }
     if (alt_path) {
-        std::vector<int64_t> wp(out->alt_off, out->alt_off + C + 1);
+        const std::vector<int64_t> wp = bytes_prefix(out->alt_off, out->alt_elems, 0);
         rc = write_file_mt(*paf, alt_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
             for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
                 const int r = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, ops, err);
@@ -846,8 +876,9 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
         if (rc != AASM_OK) return rc;
     }
     if (all_path) {                                                     // process_max_output, :445-485
-        std::vector<int64_t> wp((size_t)C + 1);
-        for (int64_t c = 0; c <= C; c++) wp[c] = out->all_elem_off[out->all_path_off[c]];
+        std::vector<int64_t> eoff((size_t)C + 1);
+        for (int64_t c = 0; c <= C; c++) eoff[c] = out->all_elem_off[out->all_path_off[c]];
+        const std::vector<int64_t> wp = bytes_prefix(eoff.data(), out->all_elems, 12);
         rc = write_file_mt(*paf, all_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
             int32_t cnt = 0;
             for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {

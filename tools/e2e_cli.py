@@ -22,7 +22,7 @@ if a.threads:
     cmd += ["-t", str(a.threads)]
 for rep in range(2):                       # second run: file in the page cache, GPU context warm-up is per process
     t = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, AASM_IO_TIMING="1"))
     print(f"run {rep}: rc={r.returncode} wall {time.time() - t:.2f}s | {' / '.join(r.stderr.strip().splitlines())}", flush=True)
 sizes = {s: os.path.getsize(path[:-4] + s) for s in (".aln.paf", ".aln.alt.paf", ".aln.all.paf")}
 print("outputs MiB:", {k: round(v / 2**20, 1) for k, v in sizes.items()})
