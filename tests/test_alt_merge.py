@@ -111,3 +111,31 @@ def test_empty_alt_is_a_noop(T):
     after = paf.batch().arrays
     for k in before:
         assert np.array_equal(before[k], after[k])
+
+
+def test_alt_merge_with_device_side_ranges(T):
+    """Reader in AASM_READ_DEVICE_RANGES mode + --alt: the merged batch carries cs text and range
+    COUNTS only; the solver (kernel bodies in the host emulation) derives the ranges itself and
+    must land on the same result as the host-range merge."""
+    from alignasm_amd._abi import BatchOut, Opts, unpack_out
+    api = T.api()
+    text = api.Paf.synth(3, 12, 7).to_text()
+    names = []
+    for line in text.decode().splitlines():
+        if not names or names[-1] != line.split("\t")[0]:
+            names.append(line.split("\t")[0])
+    alt = _alt_text(T, names, 99)
+    host = api.Paf.parse(text); host.merge_alt(alt, 0.5)
+    dev = api.Paf.parse(text, device_ranges=True); dev.merge_alt(alt, 0.5)
+    hv, dv = host.view(), dev.view()
+    assert dv.n_records == hv.n_records > 36 and dv.n_ranges == hv.n_ranges and not dv.rng_qry_l and dv.cs_text
+    want = T.oracle_solve(host.batch(), 64)
+    out = BatchOut()
+    assert T.emul().emul_solve_batch(C.byref(dv), C.byref(Opts(64, 0, 0, 0, 1)), C.byref(out)) == 0
+    try:
+        got = unpack_out(out)
+    finally:
+        T.emul().emul_free_out(C.byref(out))
+    assert T.diff_outputs(want, got) == []
+    n = int(hv.n_ranges)
+    assert np.array_equal(T.emul_debug("rql_w", np.int64)[:n], host.batch().arrays["rng_qry_l"])
