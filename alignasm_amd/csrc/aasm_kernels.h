@@ -1247,13 +1247,16 @@ AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, Spine &sp, int32_t &alloc
         depth = sp.len;
         int32_t a = sp.tail;
         while (a >= 0) {
-            const NodeQ n = uni(heap_read(nodes, L, a, alloc));
-            if (!nodeq_key_lt(n, key, ksum)) { a_rank = n.q1.w & 0xff; break; }
+            // the node is the same in every lane; the 64-bit key compare stays on the vector unit (one
+            // v_cmp per 64-bit test, where the scalar unit needs a sequence each) and only its outcome,
+            // the rank and the right pointer become scalars
+            const NodeQ n = heap_read(nodes, L, a, alloc);
+            if (!uni(nodeq_key_lt(n, key, ksum))) { a_rank = uni(n.q1.w) & 0xff; break; }
             if (depth >= AASM_WAVE_MAX - 2) { ovf = true; return -1; }
             LA_SET(sp.n, depth, lane, n);
             LA_SET(sp.idx, depth, lane, a);
             depth++;
-            a = n.q2.y;                                                             // ->right
+            a = uni(n.q2.y);                                                        // ->right
         }
         a_stop = a;
     }
@@ -1369,7 +1372,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
             while (vm && !ovf) {                                     // inserts in list order
                 const int t = ffs64(vm) - 1;
                 vm &= vm - 1;
-                const Dist cc = uni(L->cbuf[t]);
+                const Dist cc = L->cbuf[t];                          // same in every lane; only ever compared / stored by vector code
                 hu = heap_insert(nodes, L, sp, alloc, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
             }
             wave_lds_sync();                                         // before the next chunk overwrites cbuf
