@@ -109,3 +109,61 @@ def test_device_cs_rejects_what_the_host_codec_rejects(T, k):
     rc, out, dev = _emul_ranges(T, text)
     assert rc == -7                                        # ... and so does the device parser: AASM_E_PARSE
     assert T.emul().emul_last_bad_record() == 3
+
+
+def _random_tag(rng):
+    ops = []
+    for _ in range(int(rng.integers(1, 40))):
+        k = int(rng.integers(0, 10))
+        if k < 5: ops.append(b":%d" % int(rng.choice([1, 2, 9, 10, 99, 100, 12345, 7])))
+        elif k < 7: ops.append(b"*" + bytes(rng.choice(list(b"acgtn"), 2).tolist()))
+        elif k < 9: ops.append(b"+" + bytes(rng.choice(list(b"acgt"), int(rng.choice([1, 2, 5, 70, 200]))).tolist()))
+        else: ops.append(b"-" + bytes(rng.choice(list(b"acgt"), int(rng.choice([1, 3, 64, 129]))).tolist()))
+    return b"".join(ops)
+
+
+def test_device_cs_fuzz_valid_and_mutated_tags(T):
+    """Random valid tags: device ranges == host ranges.  Randomly damaged tags: the device parser
+    rejects exactly the files the host codec rejects, and names the first bad record."""
+    api = T.api()
+    rng = np.random.default_rng(7)
+    tags = [_random_tag(rng) for _ in range(120)]
+    rows = []
+    for i, cs in enumerate(tags):
+        q, r = _consumed(cs)
+        rows.append(_row(cs, bool(i % 3), qs=100000 * (i + 1) % 90000, ql=q, rl=r, name=b"ctg%d" % (i // 10)))
+    text = b"".join(rows)
+    host = api.Paf.parse(text).batch().arrays
+    rc, out, dev = _emul_ranges(T, text)
+    assert rc == 0
+    T.emul().emul_free_out(C.byref(out))
+    n = int(host["rec_rng_off"][-1])
+    for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
+        assert np.array_equal(T.emul_debug(name, np.int64)[:n], host[key]), name
+    n_bad = 0
+    for trial in range(60):
+        victim = int(rng.integers(0, len(tags)))
+        cs = bytearray(tags[victim])
+        pos = int(rng.integers(0, len(cs)))
+        how = int(rng.integers(0, 4))
+        if how == 0: cs[pos] = rng.choice(list(b":*+-acgt0123456789?Z "))
+        elif how == 1: del cs[pos]
+        elif how == 2: cs.insert(pos, int(rng.choice(list(b":*+-a5"))))
+        else: cs = cs[:pos]
+        q, r = _consumed(tags[victim])
+        broken = list(rows)
+        broken[victim] = _row(bytes(cs), bool(victim % 3), qs=100000 * (victim + 1) % 90000, ql=q, rl=r, name=b"ctg%d" % (victim // 10))
+        t2 = b"".join(broken)
+        try:
+            api.Paf.parse(t2)
+            host_ok = True
+        except api.AlignasmError:
+            host_ok = False
+        rc, out, dev = _emul_ranges(T, t2)
+        if rc == 0:
+            T.emul().emul_free_out(C.byref(out))
+        assert (rc == 0) == host_ok, (trial, victim, bytes(cs)[:60], rc, host_ok)
+        if not host_ok:
+            n_bad += 1
+            assert rc == -7 and T.emul().emul_last_bad_record() == victim
+    assert n_bad > 20
