@@ -1761,6 +1761,28 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     const int64_t e_start = uni(w.tp_ptr[s.vb + pa]);
     const int32_t T = (int32_t)(uni(w.tp_ptr[s.vb + pb]) - e_start);
     if (T > ISPR_MAX_E) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+    if (W == 2) {
+        // 62 % of the calls: one vertex x between start and target.  If a -> x and x -> target exist, the
+        // last hop from x is allowed and there is no edge a -> target, then a -> x -> target is the only
+        // path in the window and the DP has nothing to decide: one look at the two rows instead of
+        // staging + DP + backtrack.
+        const int32_t x_off = (int32_t)(uni(w.tp_ptr[s.vb + pa + 1]) - e_start);
+        const int32_t x = uni(w.fwd_order[s.vb + pa + 1]);
+        const bool x_ok = !wl_flag || uni(w.tp_vj[s.vb + pa + 1]) == wl;
+        bool direct = false, ax = false, xb = false;
+        for (int32_t idx = s.lane; idx < T; idx += AASM_WAVE) {
+            const int32_t rel = w.te_tgt[e_start + idx] - pa;
+            if (idx < x_off) { direct |= rel == 2; ax |= rel == 1; } else xb |= rel == 2;
+        }
+        if (x_ok && !wave_ballot(direct) && wave_ballot(ax) && wave_ballot(xb)) {
+            s.n_ispr_v += 2; s.n_ispr_e += T;
+            wave_lds_sync();
+            if (s.lane == 0) { L->res[0] = x; L->res[1] = bd; L->res[2] = a; L->res[3] = x; }
+            s.res_lds = true;
+            wave_lds_sync();
+            return 2;
+        }
+    }
     for (int32_t t = s.lane; t < W; t += AASM_WAVE) {
         L->excl[t] = (int32_t)(w.tp_ptr[s.vb + pa + t] - e_start);
         L->u[t] = w.fwd_order[s.vb + pa + t];
