@@ -1605,7 +1605,8 @@ struct SelLds {
     int32_t res[2 * 64];           // ISPR result edges (u, v), reverse order
     int32_t pa_win[2 * SEL_WIN];   // read window over pathA
     int32_t pa_vj[SEL_WIN];        // v_j of each window edge's head
-    uint8_t pa_sg[SEL_WIN];        // ... and whether it is a single-record vertex (v_i == v_j)
+    uint8_t pa_sg[SEL_WIN];        // ... and whether it is a single-record vertex (v_i == v_j): bit 0; bit 1: the ISPR over this edge
+                                   //     and the next one is decided without running it (see sel_pa_get)
     int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
 };
 #define AASM_SEL_LDS_BYTES 7488
@@ -1631,8 +1632,13 @@ AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
 }
 // edge `it` of pathA through a 64-edge LDS window.  A refill also fetches, for every edge of the
 // window at once, whether its head is a single-record vertex and its v_j (what the upgrade asks
-// about every edge), so the edge loop itself has no dependent global loads for them.
-AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v, int32_t &vj, bool &single) {
+// about every edge), so the edge loop itself has no dependent global loads for them - and it
+// settles the common ISPR calls in advance: for the edge (u, v) followed by (v, nv), if nv sits
+// exactly two topological positions after u (so v is the only vertex between them) and the graph
+// has no edge u -> nv, then u -> v -> nv is the only path of the window from u to nv, whatever the
+// whitelist (v carries it), and internal_shortest_path_recover(u, nv) returns these two edges.
+// The edge loop uses that whenever its continuation vertex is u (99 % of the time).
+AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v, int32_t &vj, bool &single, bool &settled) {
     SelLds *L = (SelLds *)s.lds;
     const WS &w = *s.w;
     if (it < s.pa_base || it >= s.pa_base + SEL_WIN) {
@@ -1641,15 +1647,25 @@ AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t 
         const int32_t n = (la - it < SEL_WIN) ? (la - it) : SEL_WIN;
         for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) L->pa_win[t] = s.pathA[2 * it + t];
         for (int32_t t = s.lane; t < n; t += AASM_WAVE) {
-            const int32_t hv = s.pathA[2 * (it + t) + 1];
+            const int32_t tu = s.pathA[2 * (it + t)], hv = s.pathA[2 * (it + t) + 1];
             const int32_t a = w.v_i[s.vb + hv], b = w.v_j[s.vb + hv];
-            L->pa_vj[t] = b; L->pa_sg[t] = (a == b) ? 1 : 0;
+            int32_t fl = (a == b) ? 1 : 0;
+            if (it + t + 1 < la) {
+                const int32_t nvv = s.pathA[2 * (it + t + 1) + 1];
+                if (w.fwd_pos[s.vb + nvv] - w.fwd_pos[s.vb + tu] == 2) {
+                    bool has = false;
+                    for (int64_t e = w.rowptr[s.vb + tu]; e < w.rowptr[s.vb + tu + 1]; e++) has |= w.e_col[e] == nvv;
+                    if (!has) fl |= 2;
+                }
+            }
+            L->pa_vj[t] = b; L->pa_sg[t] = (uint8_t)fl;
         }
         wave_lds_sync();
     }
     u = uni(L->pa_win[2 * (it - s.pa_base)]); v = uni(L->pa_win[2 * (it - s.pa_base) + 1]);
     vj = uni(L->pa_vj[it - s.pa_base]);
-    single = uni((int32_t)L->pa_sg[it - s.pa_base]) != 0;
+    const int32_t fl = uni((int32_t)L->pa_sg[it - s.pa_base]);
+    single = (fl & 1) != 0; settled = (fl & 2) != 0;
 }
 
 // k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
@@ -1845,8 +1861,8 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
     s.pa_base = -SEL_WIN - 1;
     for (int32_t it = 0; it < la && !s.err; ++it) {
         int32_t u, v, vj;
-        bool v_single;
-        sel_pa_get(s, it, la, u, v, vj, v_single);
+        bool v_single, settled;
+        sel_pa_get(s, it, la, u, v, vj, v_single, settled);
         const bool from_src = (u == s.src);
         if (from_src || v != s.dest) {
             int32_t start;
@@ -1859,19 +1875,26 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
             const int32_t y = vj;
             if (it + 1 >= la) { s.err = true; break; }
             int32_t nu, nv, nvj;
-            bool nvs;
-            sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs);
+            bool nvs, nsettled;
+            sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs, nsettled);
             const bool nv_single = (nv == s.dest) || nvs;
+            const bool known = settled && start == u;                // the call would return (u, v), (v, nv): see sel_pa_get
             if (nv_single) {                                         // :812-833 / :879-899
-                const int32_t n = sel_ispr(s, start, nv, true, y);
-                if (n < 0) break;
-                if (n == 0) sel_push(s, u, v);
-                else sel_append_alt(s, n, true);
+                if (known) sel_push(s, u, v);                        // the result without its last edge
+                else {
+                    const int32_t n = sel_ispr(s, start, nv, true, y);
+                    if (n < 0) break;
+                    if (n == 0) sel_push(s, u, v);
+                    else sel_append_alt(s, n, true);
+                }
             } else {                                                 // :834-843 / :900-909
-                const int32_t n = sel_ispr(s, start, nv, false, -1);
-                if (n < 0) break;
-                if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
-                else sel_append_alt(s, n, false);
+                if (known) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                else {
+                    const int32_t n = sel_ispr(s, start, nv, false, -1);
+                    if (n < 0) break;
+                    if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                    else sel_append_alt(s, n, false);
+                }
                 ++it;
             }
         } else {                                                     // v == dest (:845-858)
