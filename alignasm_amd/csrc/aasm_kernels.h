@@ -1652,10 +1652,23 @@ AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t 
             int32_t fl = (a == b) ? 1 : 0;
             if (it + t + 1 < la) {
                 const int32_t nvv = s.pathA[2 * (it + t + 1) + 1];
-                if (w.fwd_pos[s.vb + nvv] - w.fwd_pos[s.vb + tu] == 2) {
+                const int32_t pu = w.fwd_pos[s.vb + tu], dpos = w.fwd_pos[s.vb + nvv] - pu;
+                if (dpos == 2) {
                     bool has = false;
                     for (int64_t e = w.rowptr[s.vb + tu]; e < w.rowptr[s.vb + tu + 1]; e++) has |= w.e_col[e] == nvv;
                     if (!has) fl |= 2;
+                } else if (dpos == 3) {
+                    // one more vertex y in the window: u -> v -> nv stays the only path if there is no edge
+                    // u -> nv, no u -> y -> nv, and no three-hop path through y (u -> y -> v or v -> y -> nv)
+                    const int32_t pv = w.fwd_pos[s.vb + hv];
+                    const bool y_first = pv == pu + 2;
+                    const int32_t y = w.fwd_order[s.vb + (y_first ? pu + 1 : pu + 2)];
+                    bool u_nv = false, u_y = false, y_nv = false, y_v = false, v_y = false;
+                    for (int64_t e = w.rowptr[s.vb + tu]; e < w.rowptr[s.vb + tu + 1]; e++) { const int32_t c2 = w.e_col[e]; u_nv |= c2 == nvv; u_y |= c2 == y; }
+                    for (int64_t e = w.rowptr[s.vb + y]; e < w.rowptr[s.vb + y + 1]; e++) { const int32_t c2 = w.e_col[e]; y_nv |= c2 == nvv; y_v |= c2 == hv; }
+                    if (!y_first) for (int64_t e = w.rowptr[s.vb + hv]; e < w.rowptr[s.vb + hv + 1]; e++) v_y |= w.e_col[e] == y;
+                    const bool other = u_nv || (u_y && y_nv) || (y_first ? (u_y && y_v) : (v_y && y_nv));
+                    if (!other) fl |= 2;
                 }
             }
             L->pa_vj[t] = b; L->pa_sg[t] = (uint8_t)fl;
