@@ -1876,6 +1876,31 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
         int32_t u, v, vj;
         bool v_single, settled;
         sel_pa_get(s, it, la, u, v, vj, v_single, settled);
+        // A run of edges whose single-record heads are all settled (the other heads are pushed as they are
+        // anyway) comes out of the steps below exactly as it went in - whether a step takes one edge
+        // (:812-833) or two (:834-843) - as long as the continuation vertex is the edge tail, which it
+        // stays inside such a run.  The part of the run inside the window is copied in one piece.
+        if (it > 0 && s.last_head == u && settled) {
+            SelLds *L = (SelLds *)s.lds;
+            const int32_t off = it - s.pa_base, n_win = (la - s.pa_base < SEL_WIN) ? (la - s.pa_base) : SEL_WIN;
+            int32_t mine = n_win;                                    // first edge at or after `it` that the steps have to look at
+            for (int32_t t = off + s.lane; t < n_win; t += AASM_WAVE) {   // (one edge per lane: the window is 64 edges)
+                const int32_t fl = L->pa_sg[t];
+                if ((((fl & 1) && !(fl & 2)) || L->pa_win[2 * t + 1] == s.dest) && t < mine) mine = t;
+            }
+            const uint64_t sm = wave_ballot(mine < n_win);
+            const int32_t first = sm ? wave_bcast(mine, ffs64(sm) - 1) : n_win;      // lanes hold ascending edges: the lowest lane has the smallest
+            const int32_t run = first - off;
+            if (run >= 4) {
+                if (s.out_n + run > s.cap) { s.err = true; break; }
+                sel_out_flush(s);
+                for (int32_t t = s.lane; t < 2 * run; t += AASM_WAVE) s.out_dst[2 * s.out_n + t] = L->pa_win[2 * off + t];
+                s.out_n += run; s.out_flushed = s.out_n;
+                s.last_head = uni(L->pa_win[2 * (off + run - 1) + 1]);
+                it += run - 1;
+                continue;
+            }
+        }
         const bool from_src = (u == s.src);
         if (from_src || v != s.dest) {
             int32_t start;
