@@ -1891,7 +1891,7 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
             const uint64_t sm = wave_ballot(mine < n_win);
             const int32_t first = sm ? wave_bcast(mine, ffs64(sm) - 1) : n_win;      // lanes hold ascending edges: the lowest lane has the smallest
             const int32_t run = first - off;
-            if (run >= 4) {
+            if (run >= 2) {
                 if (s.out_n + run > s.cap) { s.err = true; break; }
                 sel_out_flush(s);
                 for (int32_t t = s.lane; t < 2 * run; t += AASM_WAVE) s.out_dst[2 * s.out_n + t] = L->pa_win[2 * off + t];
