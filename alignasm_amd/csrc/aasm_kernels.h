@@ -885,8 +885,8 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
 // the first TWO in-edges with their weights (the mean in-degree is ~2) into 64 bytes that are
 // read together with d[v]; the queue's front window lives in LDS.  That leaves three trips per
 // pop: {header, d[v]} -> {d[u], cnt[u]} -> the stores becoming visible.
-#define REVQ_N 128
-#define AASM_REV_LDS_BYTES (REVQ_N * 4)
+#define REVQ_N 64
+#define AASM_REV_LDS_BYTES (REVQ_N * 100)
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
@@ -914,12 +914,19 @@ AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread pe
     w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
 }
 
+// LDS queue window of the reverse sweep: besides the vertex, an entry carries the vertex's
+// in-list header and its final distance.  Both are known when the vertex is appended (the header
+// is static and was fetched together with the relax loads, the distance is the value the
+// appending lane has just computed or read), so a pop finds everything in LDS and the only
+// memory round trip left per pop is {d[u], cnt[u], header[u]} of its in-neighbours.
+struct RevQ { int32_t v[REVQ_N]; I4 h[REVQ_N][4]; Dist d[REVQ_N]; };
+static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
     const int64_t vb = w.voff[c], e_base = w.rowptr[vb];
-    int32_t *ql = (int32_t *)k.lds;                                  // queue positions [head, lds_hi) are also here
+    RevQ *Q = (RevQ *)k.lds;                                         // queue positions [head, lds_hi)
     Dist *d = w.sp_d + vb;
     int32_t *best = w.sp_best + vb, *q = w.rev_order + vb, *cnt = w.cnt_tmp + vb;
     const I4 *rvh = w.rvh + 4 * vb;
@@ -929,16 +936,21 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
         const int64_t v = base + k.lane;
         const bool act = v < V;
         int32_t od = 0;
+        Dist dv0 = dist_max();
         if (act) {
             od = (int32_t)(w.rowptr[vb + v + 1] - w.rowptr[vb + v]);
             cnt[v] = od;
-            d[v] = (v == dest) ? dist_zero() : dist_max();
+            if (v == dest) dv0 = dist_zero();
+            d[v] = dv0;
             best[v] = -1;
         }
         const bool z = act && od == 0;
         const uint64_t m = wave_ballot(z);
         const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
-        if (z) { q[at] = (int32_t)v; if (at < REVQ_N) ql[at] = (int32_t)v; }
+        if (z) {
+            q[at] = (int32_t)v;
+            if (at < REVQ_N) { Q->v[at] = (int32_t)v; for (int t = 0; t < 4; t++) Q->h[at][t] = rvh[4 * v + t]; Q->d[at] = dv0; }
+        }
         tail += popc64(m);
     }
     lds_hi = tail < REVQ_N ? tail : REVQ_N;
@@ -947,11 +959,16 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     int32_t head = 0;
     while (head < tail) {
         int32_t v;
-        if (head < lds_hi) v = uni(ql[head & (REVQ_N - 1)]);
-        else v = uni(q[head]);
+        I4 h0, h1, h2, h3;
+        Dist dv;
+        if (head < lds_hi) {
+            const int32_t sl = head & (REVQ_N - 1);
+            v = uni(Q->v[sl]); h0 = uni(Q->h[sl][0]); h1 = uni(Q->h[sl][1]); h2 = uni(Q->h[sl][2]); h3 = uni(Q->h[sl][3]); dv = uni(Q->d[sl]);
+        } else {
+            v = uni(q[head]);
+            h0 = uni(rvh[4 * v]); h1 = uni(rvh[4 * v + 1]); h2 = uni(rvh[4 * v + 2]); h3 = uni(rvh[4 * v + 3]); dv = uni(d[v]);
+        }
         head++;
-        const I4 h0 = uni(rvh[4 * v]), h1 = uni(rvh[4 * v + 1]), h2 = uni(rvh[4 * v + 2]), h3 = uni(rvh[4 * v + 3]);
-        const Dist dv = uni(d[v]);
         const bool reach = !dist_is_max(dv);                         // :166
         const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)h0.y << 32) | (uint32_t)h0.x);
         const int32_t deg = h0.z;
@@ -960,22 +977,33 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
             const bool act = t < deg;
             bool z = false;
             int32_t u = 0;
+            I4 uh0, uh1, uh2, uh3;
+            Dist du = dist_max();
+            uh0.x = uh0.y = uh0.z = uh0.w = 0; uh1 = uh0; uh2 = uh0; uh3 = uh0;
             if (act) {
                 int64_t wq; int32_t wr; uint8_t fl;
                 if (t == 0) { u = h0.w; wq = (int64_t)(((uint64_t)(uint32_t)h1.y << 32) | (uint32_t)h1.x); wr = h1.z; fl = (uint8_t)h1.w; }
                 else if (t == 1) { u = h2.x; wq = (int64_t)(((uint64_t)(uint32_t)h2.z << 32) | (uint32_t)h2.y); wr = h2.w; fl = (uint8_t)h3.x; }
                 else { const int64_t p = r0 + t; u = w.r_src[p]; const int64_t e = e_base + w.r_e[p]; wq = w.e_wq[e]; wr = w.e_wr[e]; fl = w.e_fl[e]; }
+                du = d[u];
+                const int32_t left = cnt[u] - 1;
+                uh0 = rvh[4 * u]; uh1 = rvh[4 * u + 1]; uh2 = rvh[4 * u + 2]; uh3 = rvh[4 * u + 3];     // in case u becomes free now
                 if (reach) {
                     const Dist cand = dist_add(dv, edge_dist(wq, wr, fl));
-                    if (dist_lt<CALC_SUM_MODE>(cand, d[u])) { d[u] = cand; best[u] = v; }   // :168-171
+                    if (dist_lt<CALC_SUM_MODE>(cand, du)) { du = cand; d[u] = cand; best[u] = v; }   // :168-171
                 }
-                const int32_t left = cnt[u] - 1;
                 cnt[u] = left;
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
             const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
-            if (z) { q[at] = u; if (lds_hi == tail && at - head < REVQ_N) ql[at & (REVQ_N - 1)] = u; }
+            if (z) {
+                q[at] = u;
+                if (lds_hi == tail && at - head < REVQ_N) {
+                    const int32_t sl = at & (REVQ_N - 1);
+                    Q->v[sl] = u; Q->h[sl][0] = uh0; Q->h[sl][1] = uh1; Q->h[sl][2] = uh2; Q->h[sl][3] = uh3; Q->d[sl] = du;
+                }
+            }
             const int32_t nnew = popc64(m);
             if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
             tail += nnew;
