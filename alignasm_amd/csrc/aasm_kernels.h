@@ -1018,12 +1018,13 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
 // runs Dial's bucketed BFS on the 0/1/2 anomaly weights (k_weighted_bfs.hpp:16-37) and
 // keeps only anom_dis[dest] (paf_data.cpp:715,1615); on a DAG the same scalar is the
 // min-plus DP along the topological order, folded into this sweep.
+struct FwdQ { int32_t v[REVQ_N], an[REVQ_N]; I4 f[REVQ_N][2]; };       // same idea as RevQ: out-list header + final anomaly distance
 AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
     const int64_t vb = w.voff[c];
-    int32_t *ql = (int32_t *)k.lds;                                  // queue positions [head, lds_hi) are also here
+    FwdQ *Q = (FwdQ *)k.lds;                                         // queue positions [head, lds_hi)
     int32_t *q = w.fwd_order + vb, *pos = w.fwd_pos + vb, *cnt = w.cnt_tmp2 + vb, *an = w.an + vb;
     const I4 *fvh = w.fvh + 2 * vb;
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
@@ -1031,11 +1032,15 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     for (int64_t base = 0; base < V; base += AASM_WAVE) {
         const int64_t v = base + k.lane;
         const bool act = v < V;
-        int32_t id = 1;
-        if (act) { id = w.indeg[vb + v]; cnt[v] = id; an[v] = (v == src) ? 0 : -1; }
+        int32_t id = 1, a0 = -1;
+        if (act) { id = w.indeg[vb + v]; cnt[v] = id; a0 = (v == src) ? 0 : -1; an[v] = a0; }
         const bool z = act && id == 0;
         const uint64_t m = wave_ballot(z);
-        if (z) { const int32_t t = tail + popc64(m & lanemask_lt(k.lane)); q[t] = (int32_t)v; pos[v] = t; if (t < REVQ_N) ql[t] = (int32_t)v; }
+        if (z) {
+            const int32_t t = tail + popc64(m & lanemask_lt(k.lane));
+            q[t] = (int32_t)v; pos[v] = t;
+            if (t < REVQ_N) { Q->v[t] = (int32_t)v; Q->an[t] = a0; Q->f[t][0] = fvh[2 * v]; Q->f[t][1] = fvh[2 * v + 1]; }
+        }
         tail += popc64(m);
     }
     lds_hi = tail < REVQ_N ? tail : REVQ_N;
@@ -1043,35 +1048,45 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     wave_lds_sync();
     int32_t head = 0;
     while (head < tail) {
-        int32_t u;
-        if (head < lds_hi) u = uni(ql[head & (REVQ_N - 1)]);
-        else u = uni(q[head]);
+        int32_t u, au;
+        I4 f0, f1;
+        if (head < lds_hi) {
+            const int32_t sl = head & (REVQ_N - 1);
+            u = uni(Q->v[sl]); au = uni(Q->an[sl]); f0 = uni(Q->f[sl][0]); f1 = uni(Q->f[sl][1]);
+        } else {
+            u = uni(q[head]); au = uni(an[u]); f0 = uni(fvh[2 * u]); f1 = uni(fvh[2 * u + 1]);
+        }
         head++;
-        const I4 f0 = uni(fvh[2 * u]), f1 = uni(fvh[2 * u + 1]);
-        const int32_t au = uni(an[u]);
         const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)f0.y << 32) | (uint32_t)f0.x);
         const int32_t deg = f0.z;
         for (int32_t base = 0; base < deg; base += AASM_WAVE) {
             const int32_t t = base + k.lane;
             const bool act = t < deg;
             bool z = false;
-            int32_t v = 0;
+            int32_t v = 0, av = -1;
+            I4 vf0, vf1;
+            vf0.x = vf0.y = vf0.z = vf0.w = 0; vf1 = vf0;
             if (act) {
                 int32_t wa;
                 if (t == 0) { v = f0.w; wa = f1.x; }
                 else if (t == 1) { v = f1.y; wa = f1.z; }
                 else { v = w.e_col[r0 + t]; wa = w.e_fl[r0 + t] & 3; }
+                av = an[v];
+                const int32_t left = cnt[v] - 1;
+                vf0 = fvh[2 * v]; vf1 = fvh[2 * v + 1];                // in case v becomes free now
                 if (au >= 0) {
                     const int32_t nd = au + wa;
-                    if (an[v] < 0 || nd < an[v]) an[v] = nd;
+                    if (av < 0 || nd < av) { av = nd; an[v] = nd; }
                 }
-                const int32_t left = cnt[v] - 1;
                 cnt[v] = left;
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
             const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
-            if (z) { q[at] = v; pos[v] = at; if (lds_hi == tail && at - head < REVQ_N) ql[at & (REVQ_N - 1)] = v; }
+            if (z) {
+                q[at] = v; pos[v] = at;
+                if (lds_hi == tail && at - head < REVQ_N) { const int32_t sl = at & (REVQ_N - 1); Q->v[sl] = v; Q->an[sl] = av; Q->f[sl][0] = vf0; Q->f[sl][1] = vf1; }
+            }
             const int32_t nnew = popc64(m);
             if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
             tail += nnew;
