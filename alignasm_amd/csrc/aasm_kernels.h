@@ -1167,7 +1167,7 @@ AASM_DEV void kb_child_fill(const KCtx &k, const WS &w) {           // thread pe
 // every out-edge the sidetrack cost c = w + d[v] - d[u] and whether it goes into the heap -
 // not when d[v] is max() (:204-205), and not the FIRST edge of the list that is u's tree edge
 // (:207-210).  Plus the header the heap wave reads per vertex, packed into two 16-byte words:
-// {row start (2), row length, #children} {first child, child-list start (2), -}.  This takes
+// {row start (2), row length, #children} {first child, child-list start (2), #inserts}.  This takes
 // d[], best[], the row pointers and, for the common single child, the child list out of the
 // wave's chain of dependent loads, and lets it prefetch the next vertex's header.
 AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
@@ -1179,6 +1179,7 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     const int32_t bu = w.sp_best[gv];
     const int64_t r0 = w.rowptr[gv], r1 = w.rowptr[gv + 1];
     bool seen_p = false;
+    int32_t n_ins = 0;
     for (int64_t e = r0; e < r1; e++) {
         const int32_t v = w.e_col[e];
         const Dist dv = d[v];
@@ -1186,14 +1187,14 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
         if (!dist_is_max(dv)) {
             const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
             if (!seen_p && v == bu && dist_eq(cc, dist_zero())) seen_p = true;
-            else { fl = 1; w.st_cost[e] = cc; }
+            else { fl = 1; w.st_cost[e] = cc; n_ins++; }
         }
         w.st_fl[e] = fl;
     }
     const int64_t c0 = w.cptr[gv], c1 = w.cptr[gv + 1];
     I4 a, b;
     a.x = (int32_t)(uint32_t)(uint64_t)r0; a.y = (int32_t)((uint64_t)r0 >> 32); a.z = (int32_t)(r1 - r0); a.w = (int32_t)(c1 - c0);
-    b.x = (c1 > c0) ? w.cval[c0] : -1; b.y = (int32_t)(uint32_t)(uint64_t)c0; b.z = (int32_t)((uint64_t)c0 >> 32); b.w = 0;
+    b.x = (c1 > c0) ? w.cval[c0] : -1; b.y = (int32_t)(uint32_t)(uint64_t)c0; b.z = (int32_t)((uint64_t)c0 >> 32); b.w = n_ins;
     w.vhdr[gv] = a; w.vhdr2[gv] = b;
     I4 t;                                                            // best[] is final here (K6 done)
     t.x = bu;
@@ -1401,7 +1402,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
             if (nx >= 0) { pf_u = nx; pf_a = vh[nx]; pf_b = vh2[nx]; }
         }
         KPROF_STAMP(0);                                              // vertex header
-        for (int64_t base = r0; base < r1 && !ovf; base += AASM_WAVE) {
+        for (int64_t base = r0; hb.w > 0 && base < r1 && !ovf; base += AASM_WAVE) {     // (a vertex without sidetracks does not touch its row)
             const int64_t e = base + k.lane;
             bool valid = false;
             if (e < r1 && w.st_fl[e]) {
