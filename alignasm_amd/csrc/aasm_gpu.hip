@@ -55,7 +55,7 @@ AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
 AASM_DEF_KERNEL(aasm_k6_sort_rows_rev, KN_SORT_ROWS_REV, 64)
 AASM_DEF_KERNEL(aasm_k6_rev_hdr, KN_REV_HDR, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_sweep, KN_REV_SWEEP, 64, AASM_REV_LDS_BYTES, 8)
-AASM_DEF_KERNEL_LDS(aasm_k5_fwd_sweep, KN_FWD_SWEEP, 64, AASM_REV_LDS_BYTES, 8)
+AASM_DEF_KERNEL_LDS(aasm_k5_fwd_sweep, KN_FWD_SWEEP, 64, AASM_FWD_LDS_BYTES, 8)
 AASM_DEF_KERNEL(aasm_k7_child_count, KN_CHILD_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k7_child_fill, KN_CHILD_FILL, 256)
 AASM_DEF_KERNEL(aasm_k7_sort_rows_child, KN_SORT_ROWS_CHILD, 64)

@@ -885,7 +885,7 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
 // the first TWO in-edges with their weights (the mean in-degree is ~2) into 64 bytes that are
 // read together with d[v]; the queue's front window lives in LDS.  That leaves three trips per
 // pop: {header, d[v]} -> {d[u], cnt[u]} -> the stores becoming visible.
-#define REVQ_N 64
+#define REVQ_N 32
 #define AASM_REV_LDS_BYTES (REVQ_N * 100)
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
@@ -1018,7 +1018,9 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
 // runs Dial's bucketed BFS on the 0/1/2 anomaly weights (k_weighted_bfs.hpp:16-37) and
 // keeps only anom_dis[dest] (paf_data.cpp:715,1615); on a DAG the same scalar is the
 // min-plus DP along the topological order, folded into this sweep.
+#define AASM_FWD_LDS_BYTES (REVQ_N * 40)
 struct FwdQ { int32_t v[REVQ_N], an[REVQ_N]; I4 f[REVQ_N][2]; };       // same idea as RevQ: out-list header + final anomaly distance
+static_assert(sizeof(FwdQ) <= AASM_FWD_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
