@@ -37,7 +37,8 @@ WORKLOADS = {
     # name: (contigs, recs, dense, K, seed, description)
     "c2": (50, 1000, False, 1, 11, "C2 single-chromosome synthetic PAF: 50 contigs x 1000 records, sparse, K=1, seed 11"),
     "c3": (5000, 1000, False, 4, 21, "C3 human WGS-scale synthetic PAF: 5000 contigs x 1000 records (5M records), sparse, K=4, seed 21"),
-    "c5": (10000, 1000, True, 16, 31, "C5 cancer-karyotype synthetic PAF: 10000 contigs x 1000 records, dense, K=16, seed 31"),
+    # C5 is defined on 8 GPUs (10000 contigs, contig-sharded): the per-GPU share, kept fixed for any --gpus (weak scaling)
+    "c5": (1250, 1000, True, 16, 31, "C5 cancer-karyotype synthetic PAF: 10000 contigs x 1000 records on 8 GPUs = 1250 contigs per GPU, dense, K=16, seed 31"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
