@@ -1684,6 +1684,7 @@ AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
 // has no edge u -> nv, then u -> v -> nv is the only path of the window from u to nv, whatever the
 // whitelist (v carries it), and internal_shortest_path_recover(u, nv) returns these two edges.
 // The edge loop uses that whenever its continuation vertex is u (99 % of the time).
+#define SETTLE_ROW_MAX 48
 AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v, int32_t &vj, bool &single, bool &settled) {
     SelLds *L = (SelLds *)s.lds;
     const WS &w = *s.w;
@@ -1699,9 +1700,11 @@ AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t 
             if (it + t + 1 < la) {
                 const int32_t nvv = s.pathA[2 * (it + t + 1) + 1];
                 const int32_t pu = w.fwd_pos[s.vb + tu], dpos = w.fwd_pos[s.vb + nvv] - pu;
-                if (dpos == 2) {
+                const int64_t ur0 = w.rowptr[s.vb + tu], ur1 = w.rowptr[s.vb + tu + 1];
+                if (ur1 - ur0 > SETTLE_ROW_MAX) {}                       // a long row: not worth one lane's scan, the step runs the DP
+                else if (dpos == 2) {
                     bool has = false;
-                    for (int64_t e = w.rowptr[s.vb + tu]; e < w.rowptr[s.vb + tu + 1]; e++) has |= w.e_col[e] == nvv;
+                    for (int64_t e = ur0; e < ur1; e++) has |= w.e_col[e] == nvv;
                     if (!has) fl |= 2;
                 } else if (dpos == 3) {
                     // one more vertex y in the window: u -> v -> nv stays the only path if there is no edge
@@ -1710,10 +1713,14 @@ AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t 
                     const bool y_first = pv == pu + 2;
                     const int32_t y = w.fwd_order[s.vb + (y_first ? pu + 1 : pu + 2)];
                     bool u_nv = false, u_y = false, y_nv = false, y_v = false, v_y = false;
-                    for (int64_t e = w.rowptr[s.vb + tu]; e < w.rowptr[s.vb + tu + 1]; e++) { const int32_t c2 = w.e_col[e]; u_nv |= c2 == nvv; u_y |= c2 == y; }
-                    for (int64_t e = w.rowptr[s.vb + y]; e < w.rowptr[s.vb + y + 1]; e++) { const int32_t c2 = w.e_col[e]; y_nv |= c2 == nvv; y_v |= c2 == hv; }
-                    if (!y_first) for (int64_t e = w.rowptr[s.vb + hv]; e < w.rowptr[s.vb + hv + 1]; e++) v_y |= w.e_col[e] == y;
-                    const bool other = u_nv || (u_y && y_nv) || (y_first ? (u_y && y_v) : (v_y && y_nv));
+                    const int64_t yr0 = w.rowptr[s.vb + y], yr1 = w.rowptr[s.vb + y + 1], vr0 = w.rowptr[s.vb + hv], vr1 = w.rowptr[s.vb + hv + 1];
+                    for (int64_t e = ur0; e < ur1; e++) { const int32_t c2 = w.e_col[e]; u_nv |= c2 == nvv; u_y |= c2 == y; }
+                    const bool short_rows = yr1 - yr0 <= SETTLE_ROW_MAX && (y_first || vr1 - vr0 <= SETTLE_ROW_MAX);
+                    if (short_rows) {
+                        for (int64_t e = yr0; e < yr1; e++) { const int32_t c2 = w.e_col[e]; y_nv |= c2 == nvv; y_v |= c2 == hv; }
+                        if (!y_first) for (int64_t e = vr0; e < vr1; e++) v_y |= w.e_col[e] == y;
+                    }
+                    const bool other = u_nv || !short_rows || (u_y && y_nv) || (y_first ? (u_y && y_v) : (v_y && y_nv));
                     if (!other) fl |= 2;
                 }
             }
