@@ -140,7 +140,7 @@ AASM_DEV void lane_excl_suffix_min(LaneArr<int32_t> &c, int n, int lane) {
     (void)lane;
 #else
     int32_t x = lane < n ? c.r : INT32_MAX;
-    for (int d = 1; d < AASM_WAVE; d <<= 1) { const int32_t y = __shfl_down(x, d, 64); if (lane + d < AASM_WAVE && y < x) x = y; }
+    for (int d = 1; d < n; d <<= 1) { const int32_t y = __shfl_down(x, d, 64); if (lane + d < AASM_WAVE && y < x) x = y; }   // log2(n) steps: lanes >= n hold INT32_MAX
     const int32_t e = __shfl_down(x, 1, 64);
     c.r = (lane + 1 < AASM_WAVE) ? e : INT32_MAX;
 #endif
