@@ -1048,6 +1048,20 @@ void oracle_std_sort_perm(const int64_t *qs, const int64_t *qe, int64_t n, int32
     for (int64_t i = 0; i < n; i++) perm[i] = v[i].ctg_index;
 }
 
+// K1 / K2 predicates and the PafOutputData constructor exposed for truth tables against the
+// real header (oracle/ref_harness.cpp: ref_read_lt, ref_qry_contains, ref_qry_partial_overlap,
+// ref_output_from_read).
+static Rec mk_rec(int64_t qs, int64_t qe, int32_t idx) { Rec r{}; r.qry_str = qs; r.qry_end = qe; r.ctg_index = idx; return r; }
+int oracle_read_lt(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) { return (mk_rec(a_qs, a_qe, 0) < mk_rec(b_qs, b_qe, 1)) ? 1 : 0; }
+int oracle_qry_contains(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) { return mk_rec(a_qs, a_qe, 0).qry_contains(mk_rec(b_qs, b_qe, 1)) ? 1 : 0; }
+int oracle_qry_partial_overlap(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) { return qry_partial_overlap(mk_rec(a_qs, a_qe, 0), mk_rec(b_qs, b_qe, 1)) ? 1 : 0; }
+void oracle_output_from_read(const int64_t *in, int64_t *out) {
+    Rec r = mk_rec(in[1], in[2], (int32_t)in[0]);
+    r.ref_str = in[3]; r.ref_end = in[4];
+    const Out o = out_from(r);
+    out[0] = o.ctg_index; out[1] = o.qs; out[2] = o.qe; out[3] = o.rs; out[4] = o.re; out[5] = o.is_alt ? 1 : 0;
+}
+
 // PafDistance predicates exposed for truth-table tests against the real header.
 int oracle_dist_lt(const int64_t *a, const int64_t *b, int mode) {
     return d_lt(Dist{a[0], a[1], a[2], a[3], a[4]}, Dist{b[0], b[1], b[2], b[3], b[4]}, (Mode)mode) ? 1 : 0;

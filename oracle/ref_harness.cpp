@@ -9,6 +9,9 @@
 //   heap_insert/LeftistHeap ... /root/reference/src/leftist_heap.hpp:17-41
 //   k_weighted_bfs ............ /root/reference/src/k_weighted_bfs.hpp:15-37
 //   Graph<>, add_edge ......... /root/reference/src/graph_operations.hpp:9-17
+//   PafReadData::operator<, qry_contains, qry_partial_overlap, PafOutputData(PafReadData)
+//   ........................... /root/reference/src/paf_data.hpp:69-86,95-104 (K1 sort order via
+//                               std::sort over std::vector<PafReadData>, K2 overlap predicates)
 //
 // What cannot be built: src/paf_data.cpp (solve_ctg_read, cs codec) and
 // src/alignasm.cpp include third-party headers absent from this image
@@ -208,6 +211,51 @@ int64_t ref_generic_arena_inversions(void) {
     int64_t inv = 0; const Solver::heap_t *prev = nullptr;
     for (auto &nd : g_solver->alloc) { if (prev && &nd < prev) inv++; prev = &nd; }
     return inv;
+}
+
+// ---- K1 / K2 pieces that are header-only in the reference (paf_data.hpp:69-86,101-104) ----
+// The sort is driven exactly as paf_data.cpp:232,241 drive it: a copy of the contig's
+// std::vector<PafReadData> (the full 200-byte struct with its strings and range vectors, so
+// libstdc++ moves the same objects) sorted by std::sort with the REAL PafReadData::operator<.
+// perm[i] = ctg_index of the record that ends up at sorted position i.
+static PafReadData mk_read(int64_t qs, int64_t qe, int32_t idx) {
+    PafReadData r{};
+    r.paf_index = idx; r.ctg_index = idx; r.ctg_sorted_index = -1;
+    r.qry_str = qs; r.qry_end = qe; r.ref_str = 0; r.ref_end = 0;
+    r.ref_chr = 0; r.map_qul = 0; r.aln_fwd = true;
+    r.mat_num = 0; r.aln_len = 0; r.ref_total_length = 0; r.qry_total_length = 0;
+    r.original_cord = {TYPE_MAIN, idx};
+    return r;
+}
+int64_t ref_sort_perm(const int64_t *qs, const int64_t *qe, int64_t n, int32_t *perm) {
+    std::vector<PafReadData> original;
+    original.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) original.push_back(mk_read(qs[i], qe[i], (int32_t)i));
+    auto sorted = original;                                          // paf_data.cpp:232
+    std::sort(sorted.begin(), sorted.end());                         // paf_data.cpp:241
+    for (int64_t i = 0; i < n; i++) perm[i] = sorted[i].ctg_index;
+    return n;
+}
+int ref_read_lt(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) {
+    return (mk_read(a_qs, a_qe, 0) < mk_read(b_qs, b_qe, 1)) ? 1 : 0;         // paf_data.hpp:69-73
+}
+int ref_qry_contains(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) {
+    return mk_read(a_qs, a_qe, 0).qry_contains(mk_read(b_qs, b_qe, 1)) ? 1 : 0;  // :74-77
+}
+int ref_qry_partial_overlap(int64_t a_qs, int64_t a_qe, int64_t b_qs, int64_t b_qe) {
+    return qry_partial_overlap(mk_read(a_qs, a_qe, 0), mk_read(b_qs, b_qe, 1)) ? 1 : 0;   // :78-86
+}
+// PafOutputData(const PafReadData&) (:101-104) and the default constructor (:95-97).
+// in: {ctg_index, qry_str, qry_end, ref_str, ref_end}; out: {ctg_index, e_qs, e_qe, e_rs, e_re, is_alt}
+void ref_output_from_read(const int64_t *in, int64_t *out) {
+    PafReadData r = mk_read(in[1], in[2], (int32_t)in[0]);
+    r.ref_str = in[3]; r.ref_end = in[4];
+    PafOutputData o(r);
+    out[0] = o.ctg_index; out[1] = o.edited_qry_str; out[2] = o.edited_qry_end; out[3] = o.edited_ref_str; out[4] = o.edited_ref_end;
+    out[5] = o.is_alt_path ? 1 : 0;
+    PafOutputData z;
+    out[6] = z.ctg_index; out[7] = z.edited_qry_str; out[8] = z.edited_qry_end; out[9] = z.edited_ref_str; out[10] = z.edited_ref_end;
+    out[11] = z.is_alt_path ? 1 : 0;
 }
 
 } // extern "C"

@@ -72,8 +72,22 @@ def ref_algos():
             out[f"g{g}_{key}"] = r[key]
         out[f"g{g}_path_len"] = np.array([len(p) for p in r["paths"]], np.int64)
         out[f"g{g}_paths"] = np.concatenate(r["paths"]) if r["paths"] else np.zeros(0, np.int64)
+    # K1 / K2 header-only code (paf_data.hpp:69-86): std::sort over real PafReadData objects and the
+    # overlap predicates, from the real header (ref_harness.cpp: ref_sort_perm, ref_qry_*)
+    from test_oracle_vs_ref import _ref_perm, _sort_cases
+    cases = [c for c in _sort_cases() if len(c[0]) <= 1025]
+    out["n_sorts"] = np.array([len(cases)])
+    for i, (qs, qe) in enumerate(cases):
+        out[f"s{i}_qs"], out[f"s{i}_qe"], out[f"s{i}_perm"] = qs, qe, _ref_perm(R, qs, qe)
+    iv = [(a, b) for a in range(6) for b in range(a, 6)]
+    tab = []
+    for (a0, a1) in iv:
+        for (b0, b1) in iv:
+            args = [C.c_int64(x) for x in (a0, a1, b0, b1)]
+            tab.append([a0, a1, b0, b1, R.ref_read_lt(*args), R.ref_qry_contains(*args), R.ref_qry_partial_overlap(*args)])
+    out["read_pred"] = np.array(tab, np.int64)
     np.savez_compressed(os.path.join(HERE, "ref_algos.npz"), **out)
-    print("ref_algos.npz:", len(graphs), "graphs")
+    print("ref_algos.npz:", len(graphs), "graphs,", len(cases), "sorts,", len(tab), "predicate rows")
 
 
 def solve():
