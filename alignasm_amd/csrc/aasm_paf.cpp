@@ -4,7 +4,7 @@
 // (SURVEY.md 8(f) row f1), needed so `alignasm <input.paf>` and the three output files
 // stay drop-in:
 //   reader ................ src/alignasm.cpp:76-183
-//   parse_short_cs ........ src/paf_data.cpp:29-72
+//   cs tokenizer .......... src/paf_data.cpp:29-72
 //   get_overlap_range ..... src/paf_data.cpp:90-123
 //   get_edited_paf_data ... src/paf_data.cpp:125-220
 //   writers ............... src/alignasm.cpp:398-490 (field list: SURVEY.md Appendix D)
@@ -34,141 +34,161 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 const char *last_error_cstr() { return g_last_error.c_str(); }
 
-static inline bool cs_is_alpha(char c) { return std::isalpha(static_cast<unsigned char>(c)) != 0; }
+// ---- short-form cs:Z codec ----------------------------------------------------------------
+// One scanner for everything the reference does with a cs tag (tokenizer paf_data.cpp:29-72,
+// get_overlap_range :90-123, get_edited_paf_data :125-220).  cs_scan walks the text ONCE, first
+// operation to last, and hands every operation {type, payload length, text span} to a visitor;
+// no operation list is built.  A '-' strand record is walked in the same text order with the
+// query cursor running DOWN from qry_end + 1 (the reference walks its operation list backwards
+// with the cursor running up): an operation then covers [cursor - len, cursor - 1], match ranges
+// come out last to first, and the operations a re-cut keeps come out already in output order
+// (the reference reverses its kept list, :180-182).
+// Error texts are the reference's (drop-in); the order of detection is too: a tokenizer error
+// anywhere in the tag wins over what the walk finds (the reference tokenizes the whole tag first).
+enum CsErr { CS_OK = 0, CS_E_TAG, CS_E_LENGTH, CS_E_SUBST, CS_E_INDEL, CS_E_OP, CS_E_CONSUME, CS_E_INS_CLIP, CS_E_EDIT };
+static const char *cs_err_text(CsErr e) {
+    switch (e) {
+        case CS_E_TAG: return "PAF record does not contain a short-form cs:Z tag";          // :31
+        case CS_E_LENGTH: return "Invalid :length operation in cs tag";                      // :46
+        case CS_E_SUBST: return "Invalid substitution operation in cs tag";                  // :52
+        case CS_E_INDEL: return "Empty indel operation in cs tag";                           // :63
+        case CS_E_OP: return "Unsupported operation in short-form cs tag";                   // :66
+        case CS_E_CONSUME: return "cs tag consumption does not match PAF coordinates";       // :121
+        case CS_E_INS_CLIP: return "Alignment was clipped inside a cs insertion";            // :160
+        case CS_E_EDIT: return "Edited cs tag does not match edited PAF coordinates";        // :217
+        default: return "";
+    }
+}
+static inline bool alpha_ascii(char c) { return (unsigned)(((unsigned char)c | 32) - 'a') < 26u; }   // isalpha, "C" locale
 
-// paf_data.cpp:29-72.  `cs` points at "cs:Z:...".
-bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err) {
-    ops.clear();
-    if (len < 5 || std::memcmp(cs, "cs:Z:", 5) != 0) {
-        err = "PAF record does not contain a short-form cs:Z tag";
-        return false;
-    }
-    int64_t pos = 5;
-    while (pos < len) {
-        const int64_t op_start = pos;
-        const char type = cs[pos++];
-        int64_t length = 0;
-        if (type == ':') {
-            int64_t p = pos;
-            // std::from_chars(int64): optional '-', digits
-            bool neg = false;
-            if (p < len && cs[p] == '-') { neg = true; p++; }
-            int64_t dstart = p;
-            while (p < len && cs[p] >= '0' && cs[p] <= '9') { length = length * 10 + (cs[p] - '0'); p++; }
-            if (p == dstart || neg || length <= 0) { err = "Invalid :length operation in cs tag"; return false; }
-            pos = p;
-        } else if (type == '*') {
-            if (pos + 2 > len || !cs_is_alpha(cs[pos]) || !cs_is_alpha(cs[pos + 1])) {
-                err = "Invalid substitution operation in cs tag";
-                return false;
+// visit(type, n, text, text_len): n = run length of ':' / payload letters of '+' '-' / 1 for '*'
+template <class V> static CsErr cs_scan(const char *cs, int64_t len, V &&visit) {
+    if (len < 5 || std::memcmp(cs, "cs:Z:", 5) != 0) return CS_E_TAG;
+    const char *p = cs + 5, *const e = cs + len;
+    while (p < e) {
+        const char *const op = p;
+        const char t = *p++;
+        int64_t n;
+        if (t == ':') {                                       // what std::from_chars<int64_t> accepts: [-]digits, in range
+            const bool neg = p < e && *p == '-';
+            if (neg) p++;
+            const char *const d0 = p;
+            uint64_t v = 0;
+            bool ovf = false;
+            for (; p < e && (unsigned)(*p - '0') <= 9u; p++) {
+                const uint64_t d = (uint64_t)(*p - '0');
+                if (v > ((uint64_t)INT64_MAX - d) / 10) ovf = true; else v = v * 10 + d;
             }
-            pos += 2;
-            length = 1;
-        } else if (type == '+' || type == '-') {
-            const int64_t seq_start = pos;
-            while (pos < len && cs_is_alpha(cs[pos])) ++pos;
-            length = pos - seq_start;
-            if (length == 0) { err = "Empty indel operation in cs tag"; return false; }
-        } else {
-            err = "Unsupported operation in short-form cs tag";
-            return false;
-        }
-        ops.push_back(CsOp{type, length, (int32_t)op_start, (int32_t)(pos - op_start)});
+            if (p == d0 || neg || ovf || v == 0) return CS_E_LENGTH;
+            n = (int64_t)v;
+        } else if (t == '*') {
+            if (p + 2 > e || !alpha_ascii(p[0]) || !alpha_ascii(p[1])) return CS_E_SUBST;
+            p += 2;
+            n = 1;
+        } else if (t == '+' || t == '-') {
+            const char *const s0 = p;
+            while (p < e && alpha_ascii(*p)) p++;
+            n = p - s0;
+            if (n == 0) return CS_E_INDEL;
+        } else return CS_E_OP;
+        visit(t, n, op, (int64_t)(p - op));
     }
-    return true;
+    return CS_OK;
 }
 
-// paf_data.cpp:90-123.  Appends ranges; returns count or -1.
+// Query / reference cursor of one walk.  fwd: q = next query base, r = next reference base (both
+// ascending).  '-' strand, text order: q = exclusive upper end of the query bases not yet covered
+// (descending), r = lowest reference base not yet consumed (ascending: the text of a '-' strand
+// record runs along the reference).  at() is what the reference's qry_index holds when it meets
+// the same operation.
+struct CsCursor {
+    bool fwd; int64_t q, r;
+    CsCursor(bool f, int64_t qs, int64_t qe, int64_t rs, int64_t re) : fwd(f), q(f ? qs : qe + 1), r(f ? rs : re) {}
+    int64_t lo(int64_t n) const { return fwd ? q : q - n; }                 // first query base an n-base operation covers
+    void take_q(int64_t n) { q += fwd ? n : -n; }
+    bool done(int64_t qs, int64_t qe, int64_t rs, int64_t re) const {       // :119-122
+        return fwd ? (q == qe + 1 && r == re + 1) : (q == qs && r == rs + 1);
+    }
+};
+
+// why a tag was rejected (the fast paths below only say "no"): the reference's message
+static CsErr cs_diagnose(const char *cs, int64_t len, bool fwd, int64_t qs, int64_t qe, int64_t rs, int64_t re) {
+    CsCursor c(fwd, qs, qe, rs, re);
+    const CsErr e = cs_scan(cs, len, [&](char t, int64_t n, const char *, int64_t) {
+        if (t == ':' || t == '*') { c.take_q(n); c.r += n; } else if (t == '+') c.take_q(n); else c.r += n;
+    });
+    if (e != CS_OK) return e;
+    return c.done(qs, qe, rs, re) ? CS_OK : CS_E_CONSUME;
+}
+std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end) {
+    return cs_err_text(cs_diagnose(cs, cs_len, aln_fwd, qry_str, qry_end, ref_str, ref_end));
+}
+
+static int64_t fast_ranges(const char *p, const char *e, bool fwd, int64_t qs, int64_t qe, int64_t rs, int64_t re, int64_t *ql, int64_t *qr, int64_t *rl);
+
+// get_overlap_range into growing vectors (serial reader, --alt rows, aasm_cs_match_ranges); returns the count or -1 + message
 template <class VEC>
 static int64_t match_ranges(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end,
-                            int64_t ref_str, int64_t ref_end, VEC *ql, VEC *qr, VEC *rl, std::vector<CsOp> &ops, std::string &err) {
-    if (!parse_short_cs(cs, cs_len, ops, err)) return -1;
-    const int64_t ref_step = aln_fwd ? 1 : -1;
-    int64_t ref_index = ref_str, qry_index = qry_str, n = 0;
-    const int64_t nops = (int64_t)ops.size();
-    for (int64_t t = 0; t < nops; t++) {
-        const CsOp &op = aln_fwd ? ops[t] : ops[nops - 1 - t];     // query orientation, :75-86
-        if (op.type == ':') {
-            if (ql) { ql->push_back(qry_index); qr->push_back(qry_index + op.length - 1); rl->push_back(ref_index); }
-            n++;
-            ref_index += op.length * ref_step;
-            qry_index += op.length;
-        } else if (op.type == '+') qry_index += op.length;
-        else if (op.type == '-') ref_index += op.length * ref_step;
-        else { ref_index += ref_step; qry_index += 1; }
+                            int64_t ref_str, int64_t ref_end, VEC *ql, VEC *qr, VEC *rl, std::string &err) {
+    int64_t colons = 0, n = -1;
+    for (int64_t i = 5; i < cs_len; i++) colons += cs[i] == ':';             // upper bound of the range count
+    if (cs_len >= 5 && std::memcmp(cs, "cs:Z:", 5) == 0) {
+        const size_t base = ql ? ql->size() : 0;
+        std::vector<int64_t> tmp;
+        int64_t *a, *b, *c;
+        if (ql) { ql->resize(base + colons); qr->resize(base + colons); rl->resize(base + colons); a = ql->data() + base; b = qr->data() + base; c = rl->data() + base; }
+        else { tmp.resize(3 * (size_t)colons + 3); a = tmp.data(); b = a + colons + 1; c = b + colons + 1; }
+        n = fast_ranges(cs + 5, cs + cs_len, aln_fwd, qry_str, qry_end, ref_str, ref_end, a, b, c);
+        if (ql) { const size_t keep = base + (size_t)(n > 0 ? n : 0); ql->resize(keep); qr->resize(keep); rl->resize(keep); }
     }
-    if (qry_index != qry_end + 1 || ref_index != ref_end + ref_step) {
-        err = "cs tag consumption does not match PAF coordinates";
-        return -1;
-    }
+    if (n < 0) { err = cs_err_text(cs_diagnose(cs, cs_len, aln_fwd, qry_str, qry_end, ref_str, ref_end)); return -1; }
     return n;
-}
-
-std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end) {
-    std::vector<CsOp> ops;
-    std::string err;
-    if (match_ranges<std::vector<int64_t>>(cs, cs_len, aln_fwd, qry_str, qry_end, ref_str, ref_end, nullptr, nullptr, nullptr, ops, err) >= 0) err.clear();
-    return err;
 }
 
 struct Edit { std::string cs; int32_t mat_num, aln_len; bool is_cut; };
 
-// paf_data.cpp:125-220
+// get_edited_paf_data (paf_data.cpp:125-220) in one pass over the tag: every operation is clipped
+// against the edited query interval [eq_s, eq_e] as it is met and what survives is rendered at once.
 static bool edit_cs(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end,
                     int32_t mat_num, int32_t aln_len, int64_t eq_s, int64_t eq_e, int64_t er_s, int64_t er_e,
-                    Edit &out, std::vector<CsOp> &ops, std::string &err) {
-    const bool is_cut = eq_s != qry_str || eq_e != qry_end;
-    if (!is_cut) {
-        out.cs.assign(cs, cs_len);
+                    Edit &out, std::string &err) {
+    if (eq_s == qry_str && eq_e == qry_end) {                                  // not cut: the record's own tag (:131-136)
+        out.cs.assign(cs, (size_t)cs_len);
         out.mat_num = mat_num; out.aln_len = aln_len; out.is_cut = false;
         return true;
     }
-    if (!parse_short_cs(cs, cs_len, ops, err)) return false;
-    struct Kept { char type; int64_t length; int32_t off, len; };
-    std::vector<Kept> kept;
-    int64_t qry_index = qry_str;
-    const int64_t nops = (int64_t)ops.size();
-    for (int64_t t = 0; t < nops; t++) {
-        const CsOp &op = aln_fwd ? ops[t] : ops[nops - 1 - t];
-        if (op.type == ':') {
-            const int64_t op_end = qry_index + op.length - 1;
-            const int64_t rs = std::max(qry_index, eq_s), re = std::min(op_end, eq_e);
-            if (rs <= re) kept.push_back(Kept{':', re - rs + 1, 0, 0});
-            qry_index += op.length;
-        } else if (op.type == '+') {
-            const int64_t op_end = qry_index + op.length - 1;
-            const bool overlaps = qry_index <= eq_e && eq_s <= op_end;
-            if (overlaps) {
-                if (qry_index < eq_s || eq_e < op_end) { err = "Alignment was clipped inside a cs insertion"; return false; }
-                kept.push_back(Kept{'+', op.length, op.text_off, op.text_len});
-            }
-            qry_index += op.length;
-        } else if (op.type == '*') {
-            if (eq_s <= qry_index && qry_index <= eq_e) kept.push_back(Kept{'*', 1, op.text_off, op.text_len});
-            qry_index += 1;
-        } else {
-            if (eq_s < qry_index && qry_index <= eq_e) kept.push_back(Kept{'-', op.length, op.text_off, op.text_len});
+    out.cs.assign("cs:Z:"); out.mat_num = 0; out.aln_len = 0; out.is_cut = true;
+    CsCursor c(aln_fwd, qry_str, qry_end, 0, 0);
+    int64_t q_bases = 0, r_bases = 0;
+    bool ins_clipped = false;
+    char num[24];
+    const CsErr te = cs_scan(cs, cs_len, [&](char t, int64_t n, const char *text, int64_t text_len) {
+        if (t == '-') {                                                        // sits between query bases at() - 1 and at(): kept when both stay (:171-177)
+            if (eq_s < c.q && c.q <= eq_e) { out.cs.append(text, (size_t)text_len); r_bases += n; out.aln_len += (int32_t)n; }
+            return;
         }
-    }
-    if (!aln_fwd) std::reverse(kept.begin(), kept.end());
-    out.cs = "cs:Z:"; out.mat_num = 0; out.aln_len = 0; out.is_cut = true;
-    int64_t query_bases = 0, reference_bases = 0;
-    char buf[32];
-    for (const auto &k : kept) {
-        if (k.type == ':') {
-            int n = std::snprintf(buf, sizeof buf, ":%lld", (long long)k.length);
-            out.cs.append(buf, n);
-            out.mat_num += (int32_t)k.length; out.aln_len += (int32_t)k.length;
-            query_bases += k.length; reference_bases += k.length;
-        } else {
-            out.cs.append(cs + k.off, k.len);
-            if (k.type == '+') { query_bases += k.length; out.aln_len += (int32_t)k.length; }
-            else if (k.type == '-') { reference_bases += k.length; out.aln_len += (int32_t)k.length; }
-            else { query_bases += 1; reference_bases += 1; out.aln_len += 1; }
+        const int64_t lo = c.lo(n), hi = lo + n - 1;                           // the query bases this operation covers
+        const int64_t a = std::max(lo, eq_s), b = std::min(hi, eq_e);
+        c.take_q(n);
+        if (a > b) return;                                                     // entirely clipped away
+        if (t == ':') {                                                        // :144-152: the surviving part of the run
+            const int64_t keep = b - a + 1;
+            char *e = num + sizeof num, *p = e;
+            for (uint64_t u = (uint64_t)keep; ; u /= 10) { *--p = (char)('0' + u % 10); if (u < 10) break; }
+            *--p = ':';
+            out.cs.append(p, (size_t)(e - p));
+            out.mat_num += (int32_t)keep; out.aln_len += (int32_t)keep; q_bases += keep; r_bases += keep;
+        } else if (t == '+') {                                                 // :153-164: all of it or an error
+            if (a != lo || b != hi) { ins_clipped = true; return; }
+            out.cs.append(text, (size_t)text_len); q_bases += n; out.aln_len += (int32_t)n;
+        } else {                                                               // '*', :165-170
+            out.cs.append(text, (size_t)text_len); q_bases += 1; r_bases += 1; out.aln_len += 1;
         }
-    }
-    const int64_t exp_q = eq_e - eq_s + 1, exp_r = std::llabs(er_e - er_s) + 1;
-    if (query_bases != exp_q || reference_bases != exp_r) { err = "Edited cs tag does not match edited PAF coordinates"; return false; }
+    });
+    CsErr e = te;
+    if (e == CS_OK && ins_clipped) e = CS_E_INS_CLIP;
+    if (e == CS_OK && (q_bases != eq_e - eq_s + 1 || r_bases != std::llabs(er_e - er_s) + 1)) e = CS_E_EDIT;   // :209-218
+    if (e != CS_OK) { err = cs_err_text(e); return false; }
     return true;
 }
 
@@ -185,7 +205,6 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
     std::unordered_map<std::string, int32_t> chr_map;
     std::string ctg_chr;
     std::vector<std::string_view> f;
-    std::vector<CsOp> ops;
     int32_t row_global_index = 0;
     paf.ctg_rec_off.assign(1, 0);
     paf.cs_off.assign(1, 0);
@@ -228,7 +247,7 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
                 if (f[i].size() >= 5 && f[i].substr(0, 5) == "cs:Z:") { cs = f[i]; break; }
             if (cs.empty()) { paf.error = "Missing cs:Z tag in PAF record for query '" + qry_chr + "'"; return AASM_E_PARSE; }
             std::string err;
-            int64_t nr = match_ranges(cs.data(), (int64_t)cs.size(), fwd, qs, qe, rs, re, &paf.rng_qry_l, &paf.rng_qry_r, &paf.rng_ref_l, ops, err);
+            int64_t nr = match_ranges(cs.data(), (int64_t)cs.size(), fwd, qs, qe, rs, re, &paf.rng_qry_l, &paf.rng_qry_r, &paf.rng_ref_l, err);
             if (nr < 0) { paf.error = err + " (row " + std::to_string(row_global_index) + ")"; return AASM_E_PARSE; }
             paf.rec_rng_off.push_back((int64_t)paf.rng_qry_l.size());
             paf.qry_str.push_back(qs); paf.qry_end.push_back(qe); paf.ref_str.push_back(rs); paf.ref_end.push_back(re);
@@ -262,7 +281,6 @@ int host_threads() {
     return n;
 }
 
-static inline bool alpha_ascii(char c) { return (unsigned)(((unsigned char)c | 32) - 'a') < 26u; }   // isalpha, "C" locale
 static inline bool fast_i64(const char *s, const char *e, int64_t &v) {       // [-]digits, <= 18 of them
     bool neg = false;
     if (s < e && *s == '-') { neg = true; s++; }
@@ -290,8 +308,12 @@ static int64_t fast_ranges(const char *p, const char *e, bool fwd, int64_t qs, i
         if (t == ':') {
             int64_t len = 0;
             const char *d0 = p;
-            while (p < e && (unsigned)(*p - '0') <= 9u) { len = len * 10 + (*p - '0'); p++; }
-            if (p == d0 || p - d0 > 18 || len <= 0) return -1;
+            while (p < e && (unsigned)(*p - '0') <= 9u) {                // int64 range, as std::from_chars (:43-47)
+                const int64_t d = *p - '0';
+                if (len > (INT64_MAX - d) / 10) return -1;
+                len = len * 10 + d; p++;
+            }
+            if (p == d0 || len <= 0) return -1;
             if (fwd) { ql[n] = q; qr[n] = q + len - 1; rl[n] = r; q += len; r += len; }
             else { ql[n] = q - len; qr[n] = q - 1; rl[n] = r + len - 1; q -= len; r += len; }
             n++;
@@ -492,7 +514,6 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
     for (int64_t c = 0; c < C; c++) paf_map[paf.ctg_name[c]] = (int32_t)c;          // last index wins (:136)
     std::vector<std::vector<AltRec>> added(C);
     std::vector<std::string_view> f;
-    std::vector<CsOp> ops;
     // per-contig qry_total of the LAST record (the reference copies it from .back(), :267-272)
     auto last_qtot = [&](int32_t c) -> int64_t {
         if (!added[c].empty()) return added[c].back().qtot;
@@ -559,7 +580,7 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             r.cs.assign(cs.data(), cs.size());
             r.mat = (int32_t)mat; r.aln = (int32_t)aln; r.row = row;
             std::string err;
-            if (match_ranges(cs.data(), (int64_t)cs.size(), r.fwd != 0, r.qs, r.qe, r.rs, r.re, &r.ql, &r.qr, &r.rl, ops, err) < 0) {
+            if (match_ranges(cs.data(), (int64_t)cs.size(), r.fwd != 0, r.qs, r.qe, r.rs, r.re, &r.ql, &r.qr, &r.rl, err) < 0) {
                 paf.error = err + " (alt row " + std::to_string(row) + ")";
                 return AASM_E_PARSE;
             }
@@ -621,7 +642,7 @@ static inline void put_i64(std::string &s, int64_t v) {
 }
 
 static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &name, const aasm_out_elem &o,
-                     std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+                     std::string &buf, std::string &err) {
     const int64_t r = paf.ctg_rec_off[contig] + o.ctg_index;
     if (o.ctg_index < 0 || r >= paf.ctg_rec_off[contig + 1]) { err = "output element refers to a record outside its contig"; return AASM_E_INVAL; }
     const bool fwd = paf.aln_fwd[r] != 0;
@@ -631,7 +652,7 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     const bool uncut = o.edited_qry_str == paf.qry_str[r] && o.edited_qry_end == paf.qry_end[r];   // not cut: the record's own cs / mat_num / aln_len (paf_data.cpp:131-136)
     if (uncut) { ed.mat_num = paf.mat_num[r]; ed.aln_len = paf.aln_len[r]; ed.is_cut = false; }
     else if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
-                      o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, ops, err))
+                      o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, err))
         return AASM_E_PARSE;
     buf += name; buf += '\t';
     put_i64(buf, paf.qry_total[r]); buf += '\t';
@@ -678,7 +699,7 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
 // One output file: contigs are cut into one contiguous share per host thread (balanced by
 // estimated output bytes), every thread formats its share into its own buffer, and the buffers are
 // written in contig order.
-template <class EMIT>   // EMIT(contig, buf, ops, err) -> rc : appends every line of one contig
+template <class EMIT>   // EMIT(contig, buf, err) -> rc : appends every line of one contig
 static int write_file_mt(const aasm_paf &paf, const char *path, const std::vector<int64_t> &weight_prefix, EMIT emit) {
     const int64_t C = paf.n_contigs();
     int T = host_threads();
@@ -692,9 +713,8 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
         cut[t] = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), weight_prefix[C] * t / T) - weight_prefix.begin();
     for (int t = 1; t <= T; t++) { if (cut[t] > C) cut[t] = C; if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1]; }
     run_threads(T, [&](int t) {
-        std::vector<CsOp> ops;
-        bufs[t].reserve((size_t)(weight_prefix[cut[t + 1]] - weight_prefix[cut[t]]) + 4096);   // the weights are byte estimates: no regrowth copies
-        for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], ops, errs[t]);
+            bufs[t].reserve((size_t)(weight_prefix[cut[t + 1]] - weight_prefix[cut[t]]) + 4096);   // the weights are byte estimates: no regrowth copies
+        for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], errs[t]);
     });
     for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { set_last_error(errs[t]); return rcs[t]; }   // first failing contig in file order
     const auto t1 = std::chrono::steady_clock::now();
@@ -855,9 +875,9 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
     };
     if (main_path) {                                                    // process_output, :407-443
         const std::vector<int64_t> wp = bytes_prefix(out->main_off, out->main_elems, 0);
-        rc = write_file_mt(*paf, main_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+        rc = write_file_mt(*paf, main_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
             for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++) {
-                const int r = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, ops, err);
+                const int r = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, err);
                 if (r != AASM_OK) return r;
             }
             return (int)AASM_OK;
@@ -866,9 +886,9 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
     }
     if (alt_path) {
         const std::vector<int64_t> wp = bytes_prefix(out->alt_off, out->alt_elems, 0);
-        rc = write_file_mt(*paf, alt_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+        rc = write_file_mt(*paf, alt_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
             for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
-                const int r = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, ops, err);
+                const int r = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, err);
                 if (r != AASM_OK) return r;
             }
             return (int)AASM_OK;
@@ -879,13 +899,13 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
         std::vector<int64_t> eoff((size_t)C + 1);
         for (int64_t c = 0; c <= C; c++) eoff[c] = out->all_elem_off[out->all_path_off[c]];
         const std::vector<int64_t> wp = bytes_prefix(eoff.data(), out->all_elems, 12);
-        rc = write_file_mt(*paf, all_path, wp, [&](int64_t c, std::string &buf, std::vector<CsOp> &ops, std::string &err) {
+        rc = write_file_mt(*paf, all_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
             int32_t cnt = 0;
             for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
                 ++cnt;
                 const std::string name = paf->ctg_name[c] + "." + std::to_string(cnt);
                 for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++) {
-                    const int r = emit_line(*paf, c, name, out->all_elems[k], buf, ops, err);
+                    const int r = emit_line(*paf, c, name, out->all_elems[k], buf, err);
                     if (r != AASM_OK) return r;
                 }
             }
@@ -899,9 +919,8 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
 int64_t aasm_cs_match_ranges(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str,
                              int64_t ref_end, int64_t *qry_l, int64_t *qry_r, int64_t *ref_l, int64_t cap) {
     std::vector<int64_t> a, b, c;
-    std::vector<CsOp> ops;
     std::string err;
-    int64_t n = match_ranges(cs, cs_len, aln_fwd != 0, qry_str, qry_end, ref_str, ref_end, &a, &b, &c, ops, err);
+    int64_t n = match_ranges(cs, cs_len, aln_fwd != 0, qry_str, qry_end, ref_str, ref_end, &a, &b, &c, err);
     if (n < 0) { set_last_error(err); return AASM_E_PARSE; }
     for (int64_t i = 0; i < n && i < cap; i++) {
         if (qry_l) qry_l[i] = a[i];
@@ -915,11 +934,10 @@ int64_t aasm_cs_edit(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_st
                      int64_t e_qry_end, int64_t e_ref_str, int64_t e_ref_end, char *out_cs, int64_t cap, int32_t *mat_num,
                      int32_t *aln_len, int32_t *is_cut) {
     Edit ed;
-    std::vector<CsOp> ops;
     std::string err;
     // mat_num / aln_len of the uncut record are passed IN through the out pointers
     int32_t m0 = mat_num ? *mat_num : 0, a0 = aln_len ? *aln_len : 0;
-    if (!edit_cs(cs, cs_len, aln_fwd != 0, qry_str, qry_end, m0, a0, e_qry_str, e_qry_end, e_ref_str, e_ref_end, ed, ops, err)) {
+    if (!edit_cs(cs, cs_len, aln_fwd != 0, qry_str, qry_end, m0, a0, e_qry_str, e_qry_end, e_ref_str, e_ref_end, ed, err)) {
         set_last_error(err);
         return AASM_E_PARSE;
     }

@@ -48,9 +48,6 @@ struct aasm_paf {
 
 namespace aasm {
 // cs codec (own implementation of the behaviour of paf_data.cpp:19-220)
-struct CsOp { char type; int64_t length; int32_t text_off, text_len; };
-// returns false + message on malformed tags (the reference throws std::invalid_argument)
-bool parse_short_cs(const char *cs, int64_t len, std::vector<CsOp> &ops, std::string &err);
 void set_last_error(const std::string &msg);
 // message of the tokenizer / get_overlap_range for one record (used when the device reports a bad cs tag)
 std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end);

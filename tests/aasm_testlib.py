@@ -75,6 +75,34 @@ def api():
     return a
 
 
+def io_oracle():
+    """oracle/paf_io_oracle.py: plain-Python restatement of the reference's reader, cs codec,
+    --alt merge and writers (test infrastructure; independent of the product's aasm_paf.cpp)."""
+    if "io" not in _cache:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("paf_io_oracle", os.path.join(ROOT, "oracle", "paf_io_oracle.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _cache["io"] = mod
+    return _cache["io"]
+
+
+def io_oracle_batch(st) -> HostBatch:
+    """The records an oracle-side reader state holds, as a HostBatch for oracle_solve / the product."""
+    return HostBatch(io_oracle().to_arrays(st))
+
+
+def io_oracle_files(text, alt_text=None, alt_baseline=0.5, K=10000, nsl=False, solver=None):
+    """The whole reference pipeline on the oracle side: reader -> [--alt merge] -> solve -> writers.
+    Returns (main, alt, all) bytes.  solver(hb, K, nsl) defaults to the CPU oracle."""
+    io = io_oracle()
+    st = io.read_paf(text)
+    if alt_text:
+        io.merge_alt(st, alt_text, alt_baseline)
+    sol = (solver or oracle_solve)(io_oracle_batch(st), K, nsl)
+    return io.render_outputs(st, sol)
+
+
 def synth(n_contigs, recs, seed, dense=False, dup_every=0, shuffle=False, heavy_tail=False) -> HostBatch:
     paf = api().Paf.synth(n_contigs, recs, seed, dense=dense, heavy_tail=heavy_tail, dup_every=dup_every, shuffle=shuffle, no_cs=True)
     hb = paf.batch()

@@ -1,6 +1,7 @@
 """K0 (aasm_k0_cs_ranges): match ranges derived from the cs tags by the solver itself instead
 of by the host reader.  CPU tier: the kernel body in the 1-lane host emulation against the
-host codec; GPU tier: tests/test_gpu_parity.py::test_device_cs_ranges."""
+oracle-side codec (oracle/paf_io_oracle.py: get_overlap_range, paf_data.cpp:90-123 -- NOT the
+product's own host codec); GPU tier: tests/test_gpu_parity.py::test_device_cs_ranges."""
 import ctypes as C
 
 import numpy as np
@@ -39,6 +40,20 @@ TAGS = [
 ]
 
 
+def _oracle_arrays(T, text):
+    io = T.io_oracle()
+    return {k: np.asarray(v, np.int64) for k, v in io.to_arrays(io.read_paf(text)).items()}
+
+
+def _oracle_accepts(T, text):
+    io = T.io_oracle()
+    try:
+        io.read_paf(text)
+        return True
+    except (io.CsError, ValueError):
+        return False
+
+
 def _emul_ranges(T, text, K=4):
     api = T.api()
     dev = api.Paf.parse(text, device_ranges=True)
@@ -49,7 +64,7 @@ def _emul_ranges(T, text, K=4):
     return rc, out, dev
 
 
-def test_device_cs_ranges_equal_host_codec(T):
+def test_device_cs_ranges_equal_oracle_codec(T):
     api = T.api()
     rows = []
     for k, cs in enumerate(TAGS):
@@ -57,7 +72,7 @@ def test_device_cs_ranges_equal_host_codec(T):
         for fwd in (True, False):
             rows.append(_row(cs, fwd, qs=1000 * (len(rows) + 1), ql=q, rl=r))
     text = b"".join(rows)
-    host = api.Paf.parse(text).batch().arrays
+    host = _oracle_arrays(T, text)
     rc, out, dev = _emul_ranges(T, text)
     assert rc == 0
     T.emul().emul_free_out(C.byref(out))
@@ -97,15 +112,16 @@ BAD = [
 
 
 @pytest.mark.parametrize("k", range(len(BAD)))
-def test_device_cs_rejects_what_the_host_codec_rejects(T, k):
+def test_device_cs_rejects_what_the_oracle_codec_rejects(T, k):
     api = T.api()
     good = b":10*ac:5+gg:3-t:2"
     q, r = _consumed(good)
     rows = [_row(good, True, qs=1000 * (i + 1), ql=q, rl=r) for i in range(5)]
     rows[3] = _row(BAD[k], True, qs=4000, ql=q, rl=r)
     text = b"".join(rows)
+    assert not _oracle_accepts(T, text)                    # the reference's codec throws on this file ...
     with pytest.raises(api.AlignasmError):
-        api.Paf.parse(text)                                # the host reader rejects the file ...
+        api.Paf.parse(text)                                # ... the product's host reader rejects it ...
     rc, out, dev = _emul_ranges(T, text)
     assert rc == -7                                        # ... and so does the device parser: AASM_E_PARSE
     assert T.emul().emul_last_bad_record() == 3
@@ -123,8 +139,9 @@ def _random_tag(rng):
 
 
 def test_device_cs_fuzz_valid_and_mutated_tags(T):
-    """Random valid tags: device ranges == host ranges.  Randomly damaged tags: the device parser
-    rejects exactly the files the host codec rejects, and names the first bad record."""
+    """Random valid tags: device ranges == oracle-side ranges.  Randomly damaged tags: the device parser
+    and the product's host reader reject exactly the files the oracle-side codec rejects, and the device
+    names the first bad record."""
     api = T.api()
     rng = np.random.default_rng(7)
     tags = [_random_tag(rng) for _ in range(120)]
@@ -133,7 +150,7 @@ def test_device_cs_fuzz_valid_and_mutated_tags(T):
         q, r = _consumed(cs)
         rows.append(_row(cs, bool(i % 3), qs=100000 * (i + 1) % 90000, ql=q, rl=r, name=b"ctg%d" % (i // 10)))
     text = b"".join(rows)
-    host = api.Paf.parse(text).batch().arrays
+    host = _oracle_arrays(T, text)
     rc, out, dev = _emul_ranges(T, text)
     assert rc == 0
     T.emul().emul_free_out(C.byref(out))
@@ -154,11 +171,12 @@ def test_device_cs_fuzz_valid_and_mutated_tags(T):
         broken = list(rows)
         broken[victim] = _row(bytes(cs), bool(victim % 3), qs=100000 * (victim + 1) % 90000, ql=q, rl=r, name=b"ctg%d" % (victim // 10))
         t2 = b"".join(broken)
+        host_ok = _oracle_accepts(T, t2)
         try:
             api.Paf.parse(t2)
-            host_ok = True
+            assert host_ok
         except api.AlignasmError:
-            host_ok = False
+            assert not host_ok
         rc, out, dev = _emul_ranges(T, t2)
         if rc == 0:
             T.emul().emul_free_out(C.byref(out))

@@ -1,6 +1,7 @@
-"""GPU tier at BASELINE.json's full single-GPU size (C3: 5 000 contigs x 1 000 records,
-K = 4): size-independent properties of the result + exact comparison with the oracle on a
-sample of contigs (the oracle needs seconds per hundred contigs, not per five thousand)."""
+"""GPU tier at BASELINE.json's full sizes -- C3 (5 000 contigs x 1 000 records, sparse, K = 4) and
+the per-GPU share of C5 (10 000 dense contigs on 8 GPUs = 1 250 x 1 000, K = 16): size-independent
+properties of the result + exact comparison with the oracle on a sample of contigs (the oracle needs
+seconds per hundred sparse contigs and ~0.1 s per dense one, not per thousands)."""
 import numpy as np
 import pytest
 
@@ -19,17 +20,16 @@ def c3(T):
     res.close(); db.close(); paf.close()
 
 
-def test_c3_chain_properties(T, c3):
-    paf, db, out, st = c3
+def _chain_properties(paf, out, st, NC):
     assert (out["status"] == 0).all() and st["n_internal_errors"] == 0 and st["n_unconnectable"] == 0
     view = paf.view()
     from alignasm_amd._abi import _np_from
-    rec_off = _np_from(view.ctg_rec_off, 5001, np.int64)
+    rec_off = _np_from(view.ctg_rec_off, NC + 1, np.int64)
     qs_in = _np_from(view.qry_str, int(view.n_records), np.int64)
     qe_in = _np_from(view.qry_end, int(view.n_records), np.int64)
     m, off = out["main"], out["main_off"]
     assert (np.diff(off) >= 1).all()
-    ctg = np.repeat(np.arange(5000), np.diff(off))
+    ctg = np.repeat(np.arange(NC), np.diff(off))
     rec = rec_off[ctg] + m["ctg_index"]
     # every element stays inside its record and keeps at least one base
     assert (m["ctg_index"] >= 0).all() and (rec < rec_off[ctg + 1]).all()
@@ -41,9 +41,14 @@ def test_c3_chain_properties(T, c3):
     assert set(np.unique(m["is_alt"])) <= {0, 1}
     # alt list: either empty or a valid chain too
     a, aoff = out["alt"], out["alt_off"]
-    actg = np.repeat(np.arange(5000), np.diff(aoff))
+    actg = np.repeat(np.arange(NC), np.diff(aoff))
     asame = actg[1:] == actg[:-1]
     assert (a["qe"][:-1][asame] < a["qs"][1:][asame]).all()
+
+
+def test_c3_chain_properties(T, c3):
+    paf, db, out, st = c3
+    _chain_properties(paf, out, st, 5000)
 
 
 def test_c3_idempotent_and_deterministic(T, c3):
@@ -67,6 +72,57 @@ def test_c3_sample_matches_oracle(T, c3):
         assert np.array_equal(want["main"], got_main), c0
         assert np.array_equal(want["alt"], got_alt), c0
         assert np.array_equal(want["main_off"], mo[c0:c0 + 9] - mo[c0]), c0
+
+
+# ---- C5: the per-GPU share of BASELINE configs[4] (10 000 dense contigs x 1 000 records, K = 16, 8 GPUs)
+@pytest.fixture(scope="module")
+def c5(T):
+    api = T.api()
+    paf = api.Paf.synth(1250, 1000, 31, dense=True, no_cs=True)
+    db = api.DeviceBatch(paf)
+    res = db.solve(max_paths=16, timing=True)
+    out = res.fetch()
+    st = res.stats()
+    yield paf, db, out, st
+    res.close(); db.close(); paf.close()
+
+
+def test_c5_share_chain_properties(T, c5):
+    paf, db, out, st = c5
+    _chain_properties(paf, out, st, 1250)
+    assert st["n_edges"] > 40 * st["n_vertices"] / 3          # the high-multiplicity graph it is meant to be (E/V ~ 20)
+
+
+def test_c5_share_idempotent(T, c5):
+    paf, db, out, st = c5
+    res2 = db.solve(max_paths=16)
+    out2 = res2.fetch(); res2.close()
+    assert T.diff_outputs(out, out2, stats=False) == []
+
+
+def test_c5_share_sample_matches_oracle(T, c5):
+    paf, db, out, st = c5
+    from alignasm_amd._abi import HostBatch
+    rng = np.random.default_rng(5)
+    for c0 in sorted(int(x) for x in rng.choice(1246, size=5, replace=False)):      # 5 windows of 4 dense contigs
+        hb = HostBatch.from_view_range(paf.view(), c0, c0 + 4)
+        want = T.oracle_solve(hb, 16)
+        mo, ao, po = out["main_off"], out["alt_off"], out["all_path_off"]
+        assert np.array_equal(want["main"], out["main"][mo[c0]:mo[c0 + 4]]), c0
+        assert np.array_equal(want["alt"], out["alt"][ao[c0]:ao[c0 + 4]]), c0
+        assert np.array_equal(want["main_off"], mo[c0:c0 + 5] - mo[c0]), c0
+        assert np.array_equal(want["all_path_off"], po[c0:c0 + 5] - po[c0]), c0
+
+
+def test_two_devices_match_oracle(T):
+    """aasm_solve_batch_multi over two GPUs (skipped on a one-GPU box): contig-sharded, no collective."""
+    api = T.api()
+    if api.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    hb = T.synth(64, 150, 9, heavy_tail=True, dup_every=5)
+    want = T.oracle_solve(hb, 16)
+    got = api.solve_batch(hb, max_paths=16, n_devices=2)
+    assert T.diff_outputs(want, got, stats=False) == []
 
 
 def test_multi_device_entry_equals_single(T):

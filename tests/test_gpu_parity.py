@@ -6,7 +6,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     (10, 100, 1, 10000, False, 0, False, False, False),      # BASELINE config C1: 10 x 100, K as shipped
-    (6, 1000, 11, 1, False, 0, False, False, False),         # C2 shape (single chromosome, K=1), reduced contig count
+    (50, 1000, 11, 1, False, 0, False, False, False),        # BASELINE config C2 at full size: 50 x 1000 (single chromosome), K=1
     (6, 1000, 21, 4, False, 0, False, False, False),         # C3 shape
     (4, 600, 31, 16, True, 0, False, False, False),          # C5 shape (dense, K=16)
     (2, 300, 31, 10000, True, 0, False, False, False),
@@ -100,7 +100,8 @@ def test_device_cs_ranges(T):
         for fwd in (True, False):
             rows.append(_row(cs, fwd, qs=1000 * (len(rows) + 1), ql=q, rl=r))
     text = b"".join(rows) + api.Paf.synth(8, 150, 3, dup_every=5).to_text()
-    host = api.Paf.parse(text).batch().arrays
+    io = T.io_oracle()                                           # oracle-side get_overlap_range (paf_data.cpp:90-123), not the product's host codec
+    host = {k: np.asarray(v, np.int64) for k, v in io.to_arrays(io.read_paf(text)).items()}
     dev = api.Paf.parse(text, device_ranges=True)
     db = api.DeviceBatch(dev)
     res = db.solve(max_paths=4, keep_debug=True)
@@ -126,12 +127,14 @@ def test_device_cs_solve_equals_host_range_solve_and_oracle(T, monkeypatch):
 
 def test_device_cs_reports_malformed_tags(T):
     from test_cs_device import BAD, _consumed, _row
-    api = T.api()
+    api, io = T.api(), T.io_oracle()
     good = b":10*ac:5+gg:3-t:2"
     q, r = _consumed(good)
     for k, bad in enumerate(BAD):
         rows = [_row(good, True, qs=1000 * (i + 1), ql=q, rl=r) for i in range(70)]
         rows[41] = _row(bad, k % 2 == 0, qs=42000, ql=q, rl=r)
+        with pytest.raises(io.CsError) as want:                   # what the reference's codec throws for this file
+            io.read_paf(b"".join(rows))
         with pytest.raises(api.AlignasmError) as e:
             api.solve_batch(api.Paf.parse(b"".join(rows), device_ranges=True), max_paths=4)
-        assert e.value.code == -7 and "(record 41)" in str(e.value), (k, str(e.value))
+        assert e.value.code == -7 and "(record 41)" in str(e.value) and str(want.value) in str(e.value), (k, str(e.value), str(want.value))
