@@ -1,4 +1,4 @@
-"""ctypes mirror of include/alignasm_amd.h (ABI version 2).
+"""ctypes mirror of include/alignasm_amd.h (ABI version 3).
 
 Plumbing only: no computation lives in Python.  The structs are shared by the product
 binding (alignasm_amd.api) and by the test-side loaders of the oracle libraries.
@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 AASM_N_PHASES = 16
-PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "heap_prep", "topo", "misc", "cs"]
+PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "heap_prep", "topo", "misc", "cs", "final"]
 
 AASM_OK = 0
 AASM_E_INVAL, AASM_E_NODEVICE, AASM_E_HIP, AASM_E_NOMEM = -1, -2, -3, -4

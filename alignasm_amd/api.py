@@ -35,6 +35,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.aasm_last_error.restype = C.c_char_p
     lib.aasm_debug_fetch.restype = C.c_int64
+    lib.aasm_debug_counter.restype = C.c_int64
     lib.aasm_paf_n_contigs.restype = C.c_int64
     lib.aasm_cs_match_ranges.restype = C.c_int64
     lib.aasm_cs_edit.restype = C.c_int64
@@ -47,7 +48,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_debug_fetch", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
@@ -66,9 +67,17 @@ def device_count():
     return int(LIB.aasm_device_count())
 
 
-def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False):
+def debug_counter(name):
+    """Process-wide diagnostic counter: "range_splits", "device_mallocs", "stream_syncs"."""
+    return int(LIB.aasm_debug_counter(name.encode()))
+
+
+def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False,
+              test_max_contigs=0, test_inject_launch_failure=False):
     o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
     o.reserved[0] = 1 if sequential_select else 0      # bit 0: force the one-wave-per-contig selection kernel
+    o.reserved[1] = int(test_max_contigs)              # test hook: longer contig ranges "do not fit" (range split)
+    o.reserved[2] = 1 if test_inject_launch_failure else 0
     return o
 
 
@@ -153,14 +162,16 @@ def free_out(out: BatchOut):
     LIB.aasm_free_out(C.byref(out))
 
 
-def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False):
+def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False,
+                test_max_contigs=0, test_inject_launch_failure=False):
     """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
     view = batch.view if isinstance(batch, HostBatch) else batch.view()
+    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure)
     if n_devices > 1:
         out = BatchOut()
-        _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select)), int(n_devices), C.byref(out)))
+        _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(opts), int(n_devices), C.byref(out)))
     else:
-        out = solve_batch_raw(view, make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select))
+        out = solve_batch_raw(view, opts)
     try:
         return unpack_out(out)
     finally:

@@ -11,6 +11,7 @@
 // returns AASM_E_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -71,6 +72,34 @@ AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k9_topo_fill, KN_TOPO_FILL, 64)
 AASM_DEF_KERNEL(aasm_k9_gather_out, KN_GATHER_OUT, 64)
+
+// ---- T1 truth tables on the device (test entry aasm_debug_predicates) ------------------
+// One thread per pair (a, b) of 5-int64 PafDistance tuples {qry, ref, anom, qul_nonzero, qul_total}.
+// out bit 0: dist_lt<CALC_SUM>(a, b)   bit 1: dist_lt<QRY_SCORE>(a, b)   bit 2: dist_eq(a, b)
+//     bit 3: nodeq_key_lt (heap node holding key a, against key b; K7's descent test)
+//     bit 4: pqkey_less (a, b as priority-queue entries with equal node / insertion index; K8)
+__global__ void __launch_bounds__(256) aasm_t1_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Dist x, y;
+    x.qry = a[5 * i]; x.ref = a[5 * i + 1]; x.anom = (int32_t)a[5 * i + 2]; x.qnz = (int32_t)a[5 * i + 3]; x.qtot = (int32_t)a[5 * i + 4]; x.pad = 0;
+    y.qry = b[5 * i]; y.ref = b[5 * i + 1]; y.anom = (int32_t)b[5 * i + 2]; y.qnz = (int32_t)b[5 * i + 3]; y.qtot = (int32_t)b[5 * i + 4]; y.pad = 0;
+    NodeQ nd;
+    nd.q0.x = (int32_t)(uint32_t)(uint64_t)x.qry; nd.q0.y = (int32_t)((uint64_t)x.qry >> 32);
+    nd.q0.z = (int32_t)(uint32_t)(uint64_t)x.ref; nd.q0.w = (int32_t)((uint64_t)x.ref >> 32);
+    nd.q1.x = x.anom; nd.q1.y = x.qnz; nd.q1.z = x.qtot; nd.q1.w = 1;
+    nd.q2.x = nd.q2.y = -1; nd.q2.z = nd.q2.w = 0;
+    PQEnt ea, eb;
+    ea.d = x; ea.node = 7; ea.cur = 3; ea.pad0 = ea.pad1 = 0;
+    eb.d = y; eb.node = 7; eb.cur = 3; eb.pad0 = eb.pad1 = 0;
+    uint8_t r = 0;
+    r |= dist_lt<CALC_SUM_MODE>(x, y) ? 1 : 0;
+    r |= dist_lt<QRY_SCORE_MODE>(x, y) ? 2 : 0;
+    r |= dist_eq(x, y) ? 4 : 0;
+    r |= nodeq_key_lt(nd, y, y.qry + y.ref) ? 8 : 0;
+    r |= pqkey_less(pqkey_of(ea, 0), pqkey_of(eb, 0)) ? 16 : 0;
+    out[i] = r;
+}
 
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
 #define SCAN_TPB 256
@@ -145,11 +174,14 @@ struct DevCtx {
     uint64_t generation = 0;
     std::mutex mu;
     hipEvent_t ev_b[AASM_N_PHASES], ev_e[AASM_N_PHASES], ev_t0, ev_t1;
+    int n_events_made = 0;              // ev_fork, ev_join, then timing_event(0 ..)
+    hipEvent_t *timing_event(int i) { return i < AASM_N_PHASES ? &ev_b[i] : i < 2 * AASM_N_PHASES ? &ev_e[i - AASM_N_PHASES] : i == 2 * AASM_N_PHASES ? &ev_t0 : &ev_t1; }
     bool events = false;
     size_t peak_bytes = 0;
 };
 static DevCtx g_ctx[16];
 static std::mutex g_init_mu;
+static std::atomic<int64_t> g_n_range_splits{0}, g_n_device_mallocs{0}, g_n_stream_syncs{0};
 
 static std::string hip_err(const char *what, hipError_t e) {
     return std::string(what) + ": " + hipGetErrorString(e);
@@ -165,12 +197,29 @@ static int ctx_init(int device) {
     if (e != hipSuccess || n <= 0) { set_last_error("no HIP device available (this library has no CPU fallback)"); return AASM_E_NODEVICE; }
     if (device >= n) { set_last_error("device ordinal beyond hipGetDeviceCount"); return AASM_E_NODEVICE; }
     if ((e = hipSetDevice(device)) != hipSuccess) { set_last_error(hip_err("hipSetDevice", e)); return AASM_E_NODEVICE; }
-    if ((e = hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking)) != hipSuccess) { set_last_error(hip_err("hipStreamCreate", e)); return AASM_E_NODEVICE; }
-    if ((e = hipStreamCreateWithFlags(&cx.side, hipStreamNonBlocking)) != hipSuccess) { set_last_error(hip_err("hipStreamCreate", e)); return AASM_E_NODEVICE; }
-    hipEventCreateWithFlags(&cx.ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&cx.ev_join, hipEventDisableTiming);
-    if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t))) != hipSuccess) { set_last_error(hip_err("hipHostMalloc", e)); return AASM_E_NODEVICE; }
-    for (int i = 0; i < AASM_N_PHASES; i++) { hipEventCreate(&cx.ev_b[i]); hipEventCreate(&cx.ev_e[i]); }
-    hipEventCreate(&cx.ev_t0); hipEventCreate(&cx.ev_t1);
+    // everything or nothing: a failure leaves no half-made context behind (the next call starts over)
+    auto fail = [&](const char *what, hipError_t err) {
+        set_last_error(hip_err(what, err));
+        if (cx.pinned) { hipHostFree(cx.pinned); cx.pinned = nullptr; }
+        if (cx.n_events_made > 0) { hipEventDestroy(cx.ev_fork); }
+        if (cx.n_events_made > 1) { hipEventDestroy(cx.ev_join); }
+        for (int i = 2; i < cx.n_events_made; i++) hipEventDestroy(*cx.timing_event(i - 2));
+        cx.n_events_made = 0;
+        if (cx.side) { hipStreamDestroy(cx.side); cx.side = nullptr; }
+        if (cx.stream) { hipStreamDestroy(cx.stream); cx.stream = nullptr; }
+        return AASM_E_NODEVICE;
+    };
+    if ((e = hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&cx.side, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&cx.ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    cx.n_events_made = 1;
+    if ((e = hipEventCreateWithFlags(&cx.ev_join, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    cx.n_events_made = 2;
+    for (int i = 0; i < 2 * AASM_N_PHASES + 2; i++) {
+        if ((e = hipEventCreate(cx.timing_event(i))) != hipSuccess) return fail("hipEventCreate", e);
+        cx.n_events_made++;
+    }
+    if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t))) != hipSuccess) return fail("hipHostMalloc", e);
     cx.events = true;
     cx.device = device;
     cx.ready = true;
@@ -182,7 +231,7 @@ struct GpuBackend {
     hipStream_t stream, main_stream;
     bool on_side = false, forked = false;
     bool timing;
-    bool fail = false;
+    bool fail = false, out_of_memory = false;
     bool phase_used[AASM_N_PHASES] = {false};
     size_t cur_block = 0, bytes = 0;
     std::map<std::string, std::pair<void *, size_t>> named;
@@ -195,10 +244,21 @@ struct GpuBackend {
         n = (n + 255) & ~(size_t)255;
         while (cur_block < cx.blocks.size() && cx.blocks[cur_block].used + n > cx.blocks[cur_block].cap) cur_block++;
         if (cur_block >= cx.blocks.size()) {
-            size_t cap = n > ((size_t)512 << 20) ? n : ((size_t)512 << 20);
+            // a new block doubles the arena (first block: 1 GB), so a cold start takes a handful of hipMalloc
+            // calls whatever the batch needs; when the doubled size does not fit, only what is asked for
+            size_t have = 0;
+            for (auto &b : cx.blocks) have += b.cap;
+            size_t cap = have > ((size_t)1 << 30) ? have : ((size_t)1 << 30);
+            if (cap < n) cap = n;
             char *p = nullptr;
             hipError_t e = hipMalloc((void **)&p, cap);
-            if (e != hipSuccess) { hip_fail("hipMalloc", e); return nullptr; }
+            g_n_device_mallocs++;
+            if (e == hipErrorOutOfMemory && cap > n) { (void)hipGetLastError(); cap = n; e = hipMalloc((void **)&p, cap); g_n_device_mallocs++; }
+            if (e != hipSuccess) {
+                if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); out_of_memory = true; if (!fail) set_last_error("out of device memory (workspace arena)"); fail = true; }
+                else hip_fail("hipMalloc", e);
+                return nullptr;
+            }
             cx.blocks.push_back(ArenaBlock{p, cap, 0});
             cur_block = cx.blocks.size() - 1;
         }
@@ -211,6 +271,7 @@ struct GpuBackend {
         return p;
     }
     bool failed() const { return fail; }
+    bool oom() const { return out_of_memory; }
     void zero(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
     void fill_byte(void *p, int v, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, v, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
     void fill_ff(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
@@ -259,6 +320,7 @@ struct GpuBackend {
         if (fail) return 0;
         hipError_t e = hipMemcpyAsync(cx.pinned, p, 8, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        g_n_stream_syncs++;
         if (e != hipSuccess) { hip_fail("scalar read-back", e); return 0; }
         return cx.pinned[0];
     }
@@ -277,8 +339,8 @@ struct GpuBackend {
     void fork() { if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
     void use_side(bool on) { on_side = on; stream = on ? cx.side : main_stream; }
     void join() { if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
-    void phase_begin(int ph) { if (timing && !fail) { hipEventRecord(cx.ev_b[ph], stream); phase_used[ph] = true; } }
-    void phase_end(int ph) { if (timing && !fail) hipEventRecord(cx.ev_e[ph], stream); }
+    void phase_begin(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_b[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); phase_used[ph] = true; } }
+    void phase_end(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_e[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); } }
 };
 
 }  // namespace aasm
@@ -311,7 +373,7 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     be->join();
     hipError_t e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipStreamSynchronize(cx.side);
-    if (rc == AASM_OK && be->failed()) rc = AASM_E_HIP;
+    if (rc == AASM_OK && be->failed()) rc = be->oom() ? AASM_E_NOMEM : AASM_E_HIP;
     if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }
     if (rc == AASM_E_PARSE) {
         g_bad_record = res->sz.bad_record;
@@ -320,8 +382,9 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     if (rc != AASM_OK) { delete res; return rc; }
     if (timing) {
         for (int i = 0; i < AASM_N_PHASES; i++)
-            if (be->phase_used[i]) { float ms = 0; hipEventElapsedTime(&ms, cx.ev_b[i], cx.ev_e[i]); res->stats.phase_ms[i] = ms; }
-        float ms = 0; hipEventElapsedTime(&ms, cx.ev_t0, cx.ev_t1); res->stats.total_ms = ms;
+            if (be->phase_used[i]) { float ms = 0; if (hipEventElapsedTime(&ms, cx.ev_b[i], cx.ev_e[i]) == hipSuccess) res->stats.phase_ms[i] = ms; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, cx.ev_t0, cx.ev_t1) == hipSuccess) res->stats.total_ms = ms;
     }
     {   // counters are tiny: read them now so stats are available without a full fetch
         int64_t cnt[CNT_N];
@@ -418,6 +481,39 @@ void aasm_free_out(aasm_batch_out *out) {
     std::memset(out, 0, sizeof(*out));
 }
 
+// Test entry (row T1): evaluates the device's PafDistance predicates on n pairs of host tuples.
+int aasm_debug_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t *out, int device) {
+    if (!a || !b || !out || n <= 0) return AASM_E_INVAL;
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    hipSetDevice(device);
+    int64_t *da = nullptr, *db = nullptr;
+    uint8_t *dout = nullptr;
+    hipError_t e = hipMalloc((void **)&da, (size_t)n * 40);
+    if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)n * 40);
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(da, a, (size_t)n * 40, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b, (size_t)n * 40, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(aasm_t1_predicates, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, g_ctx[device].stream, da, db, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(da); hipFree(db); hipFree(dout);
+    if (e != hipSuccess) { set_last_error(hip_err("aasm_debug_predicates", e)); return AASM_E_HIP; }
+    return AASM_OK;
+}
+
+int64_t aasm_debug_counter(const char *name) {
+    if (!name) return -1;
+    const std::string n(name);
+    if (n == "range_splits") return g_n_range_splits.load();
+    if (n == "device_mallocs") return g_n_device_mallocs.load();
+    if (n == "stream_syncs") return g_n_stream_syncs.load();
+    return -1;
+}
+
 int64_t aasm_debug_fetch(aasm_result *res, const char *name, void *dst, int64_t dst_bytes) {
     if (!res || !name) return AASM_E_INVAL;
     DevCtx &cx = g_ctx[res->device];
@@ -445,13 +541,15 @@ static int upload_range(const aasm_batch_in *in, int64_t c0, int64_t c1, int dev
     hipSetDevice(device);
     aasm_upload *up = new aasm_upload();
     up->device = device;
-    bool ok = true;
+    bool ok = true, oom = false;
+    std::string why = "the batch carries neither match ranges nor cs tags";
     auto put = [&](const void *src, size_t bytes) -> void * {
         void *p = nullptr;
         if (!ok) return nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) { ok = false; oom = (e == hipErrorOutOfMemory); (void)hipGetLastError(); why = hip_err("hipMalloc(upload)", e); return nullptr; }
         up->ptrs.push_back(p);
-        if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        if (bytes && (e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice)) != hipSuccess) { ok = false; why = hip_err("hipMemcpy H2D", e); }
         return p;
     };
     // rebase the offsets of the contig range [c0, c1) to start at 0
@@ -486,8 +584,8 @@ static int upload_range(const aasm_batch_in *in, int64_t c0, int64_t c1, int dev
     if (!ok) {
         for (void *p : up->ptrs) hipFree(p);
         delete up;
-        set_last_error("device upload failed (out of memory?)");
-        return AASM_E_NOMEM;
+        set_last_error("device upload failed: " + why);
+        return oom ? AASM_E_NOMEM : AASM_E_HIP;
     }
     *dev_view = up->view;
     *up_out = up;
@@ -545,6 +643,7 @@ static void concat_parts(std::vector<aasm_batch_out> &parts, const std::vector<i
     }
 }
 
+static inline bool host_coord_ok(int64_t x) { return x >= 0 && x < AASM_COORD_LIMIT; }
 static int validate_batch(const aasm_batch_in *in) {
     if (!in || in->n_contigs <= 0 || !in->ctg_rec_off || in->ctg_rec_off[0] != 0 || in->ctg_rec_off[in->n_contigs] != in->n_records) {
         set_last_error("inconsistent contig offsets");
@@ -556,6 +655,18 @@ static int validate_batch(const aasm_batch_in *in) {
         set_last_error("the batch carries neither match ranges (rng_*) nor cs tags (cs_text / rec_cs_off)");
         return AASM_E_INVAL;
     }
+    // ranges the device's narrowed fields are exact for (aasm_kernels.h AASM_COORD_LIMIT; the device repeats the
+    // coordinate check per contig for batches that are handed over already resident)
+    for (int64_t c = 0; c < in->n_contigs; c++)
+        if (in->ctg_rec_off[c + 1] - in->ctg_rec_off[c] > (int64_t)INT32_MAX - 64) {
+            set_last_error("contig " + std::to_string(c) + " has more than 2^31 records");
+            return AASM_E_OVERFLOW;
+        }
+    for (int64_t r = 0; r < in->n_records; r++)
+        if (!(host_coord_ok(in->qry_str[r]) && host_coord_ok(in->qry_end[r]) && host_coord_ok(in->ref_str[r]) && host_coord_ok(in->ref_end[r]) && host_coord_ok(in->qry_total[r]))) {
+            set_last_error("record " + std::to_string(r) + ": coordinate outside [0, 2^40) (qry_str / qry_end / ref_str / ref_end / qry_total)");
+            return AASM_E_OVERFLOW;
+        }
     return AASM_OK;
 }
 
@@ -572,9 +683,9 @@ static void ctx_release_arena(int device) {
 }
 
 static int solve_range_once(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
-    if (const char *lim = std::getenv("AASM_TEST_MAX_CONTIGS")) {      // test hook: pretend larger ranges do not fit
-        const long long n = std::atoll(lim);
-        if (n > 0 && c1 - c0 > n) { set_last_error("range exceeds AASM_TEST_MAX_CONTIGS"); return AASM_E_NOMEM; }
+    if (o.reserved[1] > 0 && c1 - c0 > o.reserved[1]) {               // test hook (opts.reserved[1]): pretend larger ranges do not fit
+        set_last_error("range exceeds the test limit opts.reserved[1]");
+        return AASM_E_NOMEM;
     }
     aasm_upload *up = nullptr;
     aasm_batch_in dv;
@@ -620,7 +731,8 @@ static void add_stats(aasm_stats &a, const aasm_stats &b, bool sum_time) {
 // independent) after the arena of the failed attempt has been given back.
 static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts &o, aasm_batch_out *out) {
     int rc = solve_range_once(in, c0, c1, o, out);
-    if (rc != AASM_E_NOMEM || c1 - c0 < 2) return rc;
+    if (rc != AASM_E_NOMEM || c1 - c0 < 2) return rc;                    // only a true allocation failure is worth splitting for
+    g_n_range_splits++;
     ctx_release_arena(o.device);
     const int64_t mid = c0 + (c1 - c0) / 2;
     std::vector<aasm_batch_out> parts(2);

@@ -104,6 +104,12 @@ struct WS {
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
+// Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
+// int32, e_wr is int32): coordinates in [0, 2^40), so that a path sum over < 2^20 edges of
+// 2 * coordinate stays far inside int64 and every per-edge reference weight fits int32 after the
+// 1e6 cap (paf_data.cpp:487-490).  A contig outside it gets status AASM_E_OVERFLOW (-5).
+#define AASM_COORD_LIMIT ((int64_t)1 << 40)
+AASM_DEV bool coord_ok(int64_t x) { return x >= 0 && x < AASM_COORD_LIMIT; }
 
 // ====================================================================================
 // K0  match ranges from short-form cs tags (get_overlap_range, paf_data.cpp:90-123, over the
@@ -424,6 +430,7 @@ AASM_DEV void kb_gather_parts(const KCtx &k, const WS &w) {
             w.s_ctg[b + i] = (int32_t)c;
             w.s_rb[b + i] = w.in_rng_off[o];
             w.s_rn[b + i] = (int32_t)(w.in_rng_off[o + 1] - w.in_rng_off[o]);
+            if (!(coord_ok(qs_i) && coord_ok(qe_i) && coord_ok(w.in_rs[o]) && coord_ok(w.in_re[o]) && coord_ok(w.in_qt[o]))) w.status[c] = -5;   // AASM_E_OVERFLOW (benign race: same value)
         }
         const int64_t incl = wave_incl_max(qe_i, NEG);
         int64_t excl = wave_shfl_up(incl, 1, NEG);
@@ -544,6 +551,11 @@ AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread pe
     const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c];
     if (N <= 1) { w.ctgV[c] = 0; return; }                          // N == 1 shortcut (:235-239)
     const int64_t P = w.ov_rank[w.ov_off[b + N]] - w.ov_rank[w.ov_off[b]];
+    if (N + P + 2 > (int64_t)INT32_MAX - 64 || w.status[c] != 0) {  // vertex ids are int32; a contig flagged by the input guard is not solved
+        if (w.status[c] == 0) w.status[c] = -5;                     // AASM_E_OVERFLOW
+        w.ctgV[c] = 0;
+        return;
+    }
     w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
 }
 
@@ -564,7 +576,7 @@ AASM_DEV void kb_vfill_slot(const KCtx &k, const WS &w) {           // thread pe
     const int64_t s = k.bid * k.nthreads + k.tid;
     if (s >= w.S) return;
     int32_t vid = -1;
-    if (w.ov_ok[s]) {
+    if (w.ov_ok[s] && w.ctgV[w.s_ctg[w.ov_rec[s]]] != 0) {           // (a contig rejected by the input guards has no vertices)
         const int64_t g = w.ov_rec[s], c = w.s_ctg[g];
         const int64_t b = w.rec_off[c] - w.R0, N = w.rec_off[c + 1] - w.rec_off[c], vb = w.voff[c];
         vid = (int32_t)(N + (w.ov_rank[s] - w.ov_rank[w.ov_off[b]]));      // lexicographic (i, j) (:371-372)
@@ -1220,7 +1232,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     int lg = 0;
     for (int64_t t = I + 1; t > 1; t >>= 1) lg++;
     int64_t cap = I * (lg + 2) + 8;
-    if (cap > 0x7fffff00) cap = 0x7fffff00;
+    if (cap > 0x7fffff00) cap = 0x7fffff00;                          // arena indices are int32: a contig that really needs more ends with status AASM_E_OVERFLOW (kb_heap)
     w.hcap_cnt[c] = (int32_t)cap;
 }
 

@@ -89,7 +89,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
 #define A(field, type, n, name) w.field = (type *)be.alloc(name, sizeof(type) * (size_t)((n) > 0 ? (n) : 1))
 #define AZ(field, type, n, name) do { A(field, type, n, name); be.zero(w.field, sizeof(type) * (size_t)((n) > 0 ? (n) : 1)); } while (0)
-#define CHECK_ALLOC() do { if (be.failed()) return AASM_E_NOMEM; } while (0)
+// out of device memory -> AASM_E_NOMEM (the caller may split the contig range); any other HIP failure (launch,
+// memset, scan, read-back) -> AASM_E_HIP with the original error text, never retried
+#define CHECK_ALLOC() do { if (be.oom()) return AASM_E_NOMEM; if (be.failed()) return AASM_E_HIP; } while (0)
 
     AZ(status, int32_t, C, "status");
     AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel");
@@ -119,6 +121,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     A(s_qt, int64_t, R, "s_qt"); A(s_rb, int64_t, R, "s_rb"); A(s_rn, int32_t, R, "s_rn"); A(s_chr, int32_t, R, "s_chr");
     A(s_orig, int32_t, R, "s_orig"); A(s_ctg, int32_t, R, "s_ctg"); A(s_pid, int32_t, R, "s_pid"); A(s_fl, uint8_t, R, "s_fl");
     CHECK_ALLOC();
+    if (opts.reserved[2] & 1) be.launch(KN_SORT, C, 4096, w);       // test hook: an invalid launch configuration (block size > 1024)
     be.launch(KN_SORT, C, 256, w);
     be.launch(KN_SORT_FIX, cdiv(C, 64), 64, w);
     be.launch(KN_GATHER_PARTS, C, AASM_WAVE, w);
@@ -289,7 +292,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.launch(KN_SEL_CONVERT, NCONV, AASM_WAVE, w);
             be.phase_end(AASM_PH_SELECT);
         }
-        be.phase_begin(AASM_PH_GATHER);
+        be.phase_begin(AASM_PH_FINAL);
         be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
         const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
         if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow: exact-size re-run of the pick only
@@ -302,7 +305,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
             be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
         }
-        be.phase_end(AASM_PH_GATHER);
+        be.phase_end(AASM_PH_FINAL);
     } else {
         A(pathA, int32_t, 2 * (R + 2 * C), "pathA"); A(pathB, int32_t, 2 * (R + 2 * C), "pathB"); A(pathT, int32_t, 2 * (R + 2 * C), "pathT");
         A(pre2, int32_t, VT, "pre2"); AZ(stamp, int32_t, VT, "stamp"); A(dist2, Dist, VT, "dist2");

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AASM_ABI_VERSION 2
+#define AASM_ABI_VERSION 3
 
 /* error codes */
 #define AASM_OK              0
@@ -44,7 +44,8 @@ extern "C" {
 #define AASM_E_NODEVICE     -2   /* no HIP device / HIP runtime error at init      */
 #define AASM_E_HIP          -3   /* HIP runtime error during a solve               */
 #define AASM_E_NOMEM        -4   /* device or host allocation failed               */
-#define AASM_E_OVERFLOW     -5   /* an internal pool overflowed even after retry   */
+#define AASM_E_OVERFLOW     -5   /* input outside the supported range (coordinates >= 2^40, a contig of >= 2^31
+                                    records / vertices / heap nodes) or an internal pool overflow        */
 #define AASM_E_INTERNAL     -6   /* "must not happen" state of the reference hit   */
 #define AASM_E_PARSE        -7   /* PAF / cs tag parse error (host codec)          */
 #define AASM_E_IO           -8
@@ -85,7 +86,11 @@ typedef struct aasm_opts {
     int32_t device;            /* HIP device ordinal                                  */
     int32_t collect_timing;    /* 1: bracket every kernel with HIP events            */
     int32_t keep_debug;        /* 1: keep device intermediates for aasm_debug_fetch   */
-    int32_t reserved[3];       /* [0] bit 0: force the sequential selection kernel (tests)  */
+    int32_t reserved[3];       /* test hooks, 0 in production:
+                                * [0] bit 0: force the sequential selection kernel
+                                * [1] > 0:   pretend that contig ranges longer than this do not fit in device
+                                *            memory (exercises the range split of aasm_solve_batch)
+                                * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP)  */
 } aasm_opts;
 
 /* ---- output ---------------------------------------------------------------------
@@ -135,7 +140,8 @@ enum {
     AASM_PH_HEAP_PREP,    /* SP-tree children CSR + arena sizing          */
     AASM_PH_TOPO,         /* topologically ordered CSR copy for K9        */
     AASM_PH_MISC,
-    AASM_PH_CS            /* K0 aasm_k0_cs_ranges alone (only with cs_text input) */
+    AASM_PH_CS,           /* K0 aasm_k0_cs_ranges alone (only with cs_text input) */
+    AASM_PH_FINAL         /* K9 per-contig final pick (aasm_k9_sel_final)          */
 };
 
 /* Ragged result of a batch: three lists per contig, exactly the three output
@@ -193,6 +199,14 @@ void aasm_upload_free(aasm_upload *up);
  * opts.keep_debug=1 (names listed in DESIGN.md; e.g. "perm", "csr_col", "sp_d").
  * Call with dst==NULL to get the byte size.                                           */
 int64_t aasm_debug_fetch(aasm_result *res, const char *name, void *dst, int64_t dst_bytes);
+/* Process-wide diagnostic counters (tests / tuning): "range_splits" (contig ranges halved after an
+ * out-of-memory), "device_mallocs" (hipMalloc calls of the arenas), "stream_syncs" (host waits on a
+ * pipeline stream).  Unknown name: -1.                                                         */
+int64_t aasm_debug_counter(const char *name);
+/* Test entry for row T1: the device's PafDistance predicates (paf_data.hpp:142-168) on n pairs of
+ * {qry, ref, anom, qul_nonzero, qul_total} tuples.  out[i] bit 0: a < b in CALC_SUM mode, bit 1: a < b in
+ * QRY_SCORE mode, bit 2: a == b, bit 3: K7's node-key test, bit 4: K8's queue order (equal node / index). */
+int  aasm_debug_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t *out, int device);
 
 /* ---- host-side codec + file contract (reference: src/paf_data.cpp:19-220,
  *      src/alignasm.cpp:76-183,398-490).  Implemented in host C++.                  */

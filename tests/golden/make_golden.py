@@ -87,6 +87,22 @@ def ref_algos():
             args = [C.c_int64(x) for x in (a0, a1, b0, b1)]
             tab.append([a0, a1, b0, b1, R.ref_read_lt(*args), R.ref_qry_contains(*args), R.ref_qry_partial_overlap(*args)])
     out["read_pred"] = np.array(tab, np.int64)
+    # T1: PafDistance predicates of the real header on truth-table tuples (incl. max(), negative qul_total);
+    # the -m gpu tier evaluates the DEVICE's dist_lt / dist_eq / nodeq_key_lt / pqkey_less on the same pairs
+    import itertools
+    vals = [-2, -1, 0, 1, 3]
+    cands = [np.array(v, np.int64) for v in itertools.product(vals, [-1, 0, 2], [-1, 0, 1], [-2, -1, 0, 1, 2], [-1, 0, 1, 2])]
+    cands += [np.array([-1, -1, -1, -1, 0], np.int64), np.array([-1, -1, -1, 1, -1], np.int64), np.array([-1, -1, -1, -2, 2], np.int64)]
+    cands += [np.array([int(x) for x in rng.integers(0, 1 << 36, 2)] + [int(x) for x in rng.integers(0, 50, 3)], np.int64) for _ in range(300)]
+    cands += [np.array([5_000_000_000, 7, 1, 2, 3], np.int64), np.array([7, 5_000_000_000, 1, 2, 3], np.int64), np.array([5_000_000_007, 0, 1, 4, 6], np.int64)]
+    idx = np.random.default_rng(2).integers(0, len(cands), size=(20000, 2))
+    ta, tb = np.stack([cands[i] for i in idx[:, 0]]), np.stack([cands[j] for j in idx[:, 1]])
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    res = np.zeros(len(ta), np.uint8)
+    for i in range(len(ta)):
+        a, b = np.ascontiguousarray(ta[i]), np.ascontiguousarray(tb[i])
+        res[i] = R.ref_dist_lt(P(a), P(b), 0) | (R.ref_dist_lt(P(a), P(b), 1) << 1) | (R.ref_dist_eq(P(a), P(b)) << 2)
+    out["t1_a"], out["t1_b"], out["t1_res"] = ta, tb, res
     np.savez_compressed(os.path.join(HERE, "ref_algos.npz"), **out)
     print("ref_algos.npz:", len(graphs), "graphs,", len(cases), "sorts,", len(tab), "predicate rows")
 

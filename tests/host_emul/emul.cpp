@@ -29,11 +29,12 @@ struct EmuBackend {
         return p;
     }
     bool failed() const { return fail; }
+    bool oom() const { return fail; }
     void zero(void *p, size_t n) { memset(p, 0, n); }
     void fill_ff(void *p, size_t n) { memset(p, 0xFF, n); }
     void fill_byte(void *p, int v, size_t n) { memset(p, v, n); }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
-        (void)nthreads;
+        if (nthreads > 1024) return;                // (the injected bad launch of the GPU tests: nothing to emulate)
         for (int64_t b = 0; b < nblocks; b++) {
             // one logical thread per block slot: bodies index with bid*nthreads+tid
             for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {

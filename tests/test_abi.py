@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(T):
     for n in names:
         assert hasattr(api.LIB, n), f"{n} declared in include/alignasm_amd.h but not exported"
     assert set(api.EXPORTED) <= set(names)
-    assert api.LIB.aasm_abi_version() == 2
+    assert api.LIB.aasm_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -65,19 +65,47 @@ def test_repeat_solve_is_deterministic(T):
     assert T.diff_outputs(outs[0], outs[1]) == [] and T.diff_outputs(outs[0], outs[2]) == []
 
 
-def test_out_of_memory_ranges_are_split_and_concatenated(T, monkeypatch):
+def test_out_of_memory_ranges_are_split_and_concatenated(T):
     """A contig range that does not fit is halved recursively (contigs are independent); the
-    concatenated result must equal the unsplit one.  AASM_TEST_MAX_CONTIGS simulates the
-    hipMalloc failure."""
+    concatenated result must equal the unsplit one.  opts.reserved[1] simulates the
+    out-of-memory hipMalloc."""
     api = T.api()
     hb = T.synth(23, 70, 41, heavy_tail=True, dup_every=6)
     whole = api.solve_batch(hb, max_paths=32)
-    monkeypatch.setenv("AASM_TEST_MAX_CONTIGS", "4")
-    split = api.solve_batch(hb, max_paths=32)
-    monkeypatch.delenv("AASM_TEST_MAX_CONTIGS")
+    n0 = api.debug_counter("range_splits")
+    split = api.solve_batch(hb, max_paths=32, test_max_contigs=4)
+    assert api.debug_counter("range_splits") - n0 >= 5
     assert T.diff_outputs(whole, split, stats=False) == []
     for k in ("n_vertices", "n_edges", "n_heap_nodes", "n_paths_found", "n_pairs"):
         assert whole["stats"][k] == split["stats"][k], k
+
+
+def test_hip_failure_is_reported_not_retried_as_out_of_memory(T):
+    """A HIP error that is not an allocation failure (here: an injected invalid launch) must come back
+    as AASM_E_HIP with the runtime's own message, and must not trigger the out-of-memory range split."""
+    api = T.api()
+    hb = T.synth(16, 60, 3)
+    n0 = api.debug_counter("range_splits")
+    with pytest.raises(api.AlignasmError) as e:
+        api.solve_batch(hb, max_paths=8, test_inject_launch_failure=True)
+    assert e.value.code == -3 and "kernel launch" in str(e.value) and "memory" not in str(e.value).lower(), str(e.value)
+    assert api.debug_counter("range_splits") == n0
+    want = T.oracle_solve(hb, 8)                                   # and the device context is still usable afterwards
+    assert T.diff_outputs(want, api.solve_batch(hb, max_paths=8)) == []
+
+
+def test_cold_arena_takes_few_device_allocations(T):
+    """The workspace arena grows by doubling: a cold solve of a batch that needs GBs takes a handful of
+    hipMalloc calls, a warm one none."""
+    api = T.api()
+    hb = T.synth(300, 400, 13)
+    db = api.DeviceBatch(hb)
+    db.solve(max_paths=4).close()
+    n1 = api.debug_counter("device_mallocs")
+    assert n1 <= 12
+    db.solve(max_paths=4).close()
+    assert api.debug_counter("device_mallocs") == n1
+    db.close()
 
 
 @pytest.mark.parametrize("case", [CASES[0], CASES[5], CASES[8], CASES[13]], ids=_id)
@@ -111,7 +139,7 @@ def test_device_cs_ranges(T):
     res.close(); db.close()
 
 
-def test_device_cs_solve_equals_host_range_solve_and_oracle(T, monkeypatch):
+def test_device_cs_solve_equals_host_range_solve_and_oracle(T):
     api = T.api()
     text = api.Paf.synth(40, 200, 9, dup_every=4, shuffle=True).to_text()
     host_paf, dev_paf = api.Paf.parse(text), api.Paf.parse(text, device_ranges=True)
@@ -119,9 +147,7 @@ def test_device_cs_solve_equals_host_range_solve_and_oracle(T, monkeypatch):
     a = api.solve_batch(host_paf, max_paths=16)
     b = api.solve_batch(dev_paf, max_paths=16)
     assert T.diff_outputs(want, a) == [] and T.diff_outputs(want, b) == []
-    monkeypatch.setenv("AASM_TEST_MAX_CONTIGS", "7")               # ranges split on the host: cs text re-based per range
-    c = api.solve_batch(dev_paf, max_paths=16)
-    monkeypatch.delenv("AASM_TEST_MAX_CONTIGS")
+    c = api.solve_batch(dev_paf, max_paths=16, test_max_contigs=7)   # ranges split on the host: cs text re-based per range
     assert T.diff_outputs(b, c, stats=False) == []
 
 
@@ -138,3 +164,46 @@ def test_device_cs_reports_malformed_tags(T):
         with pytest.raises(api.AlignasmError) as e:
             api.solve_batch(api.Paf.parse(b"".join(rows), device_ranges=True), max_paths=4)
         assert e.value.code == -7 and "(record 41)" in str(e.value) and str(want.value) in str(e.value), (k, str(e.value), str(want.value))
+
+
+# ---- row T1: the device's PafDistance predicates against the REAL header's results (ref_algos.npz)
+def test_device_pafdistance_predicates_match_reference_truth_tables(T):
+    import ctypes as C
+    import os
+    api = T.api()
+    z = np.load(os.path.join(T.GOLDEN, "ref_algos.npz"))
+    a, b, want = np.ascontiguousarray(z["t1_a"]), np.ascontiguousarray(z["t1_b"]), z["t1_res"]
+    got = np.zeros(len(a), np.uint8)
+    rc = api.LIB.aasm_debug_predicates(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_int64(len(a)), got.ctypes.data_as(C.c_void_p), 0)
+    assert rc == 0, api.LIB.aasm_last_error()
+    assert np.array_equal(got & 7, want)                      # dist_lt<CALC_SUM>, dist_lt<QRY_SCORE>, dist_eq: paf_data.hpp:142-168
+    assert np.array_equal((got >> 3) & 1, want & 1)           # K7's node-key test is operator< in CALC_SUM mode, max() included
+    real = ((a >= 0).all(1) & (b >= 0).all(1))                # K8's queue order is defined on distances of real walks (components >= 0)
+    assert real.sum() > 2000
+    assert np.array_equal((got[real] >> 4) & 1, want[real] & 1)
+
+
+def test_input_guards_report_overflow(T):
+    """Coordinates outside [0, 2^40) / oversized contigs are refused with AASM_E_OVERFLOW and a message
+    instead of being squeezed into the device's int32 fields; on a batch that is already resident the
+    device flags the contig (ctg_status -5) and solves the others."""
+    api = T.api()
+    hb = T.synth(6, 50, 3)
+    bad = {k: v.copy() for k, v in hb.arrays.items()}
+    r = int(bad["ctg_rec_off"][2]) + 5
+    bad["qry_total"][r] = 1 << 41
+    from alignasm_amd._abi import HostBatch
+    hb2 = HostBatch(bad)
+    with pytest.raises(api.AlignasmError) as e:
+        api.solve_batch(hb2, max_paths=4)
+    assert e.value.code == -5 and "record %d" % r in str(e.value) and "2^40" in str(e.value)
+    db = api.DeviceBatch(hb2)                                  # resident batch: no host-side scan
+    res = db.solve(max_paths=4)
+    out = res.fetch(); res.close(); db.close()
+    assert list(out["status"]) == [0, 0, -5, 0, 0, 0] and out["stats"]["n_internal_errors"] == 1
+    want = T.oracle_solve(hb, 4)
+    mo = out["main_off"]
+    assert mo[3] == mo[2]                                     # nothing emitted for the refused contig
+    for c in (0, 1, 3, 4, 5):
+        wm = want["main"][want["main_off"][c]:want["main_off"][c + 1]]
+        assert np.array_equal(wm, out["main"][mo[c]:mo[c + 1]]), c
