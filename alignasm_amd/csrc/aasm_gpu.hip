@@ -760,7 +760,7 @@ int aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_
 }
 
 // Contig-sharded solve over n_devices GPUs of one node (devices opts.device .. +n-1):
-// static contiguous partition balanced on a per-contig cost estimate, one host thread and
+// static contiguous partition balanced on a per-contig cost estimate (aasm_shard.cpp), one host thread and
 // one stream per device, results concatenated in contig order.  No collective anywhere:
 // contigs are independent (reference: one TBB task per contig, src/alignasm.cpp:351-359).
 int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n_devices, aasm_batch_out *out) {
@@ -773,18 +773,11 @@ int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n
     const int64_t C = in->n_contigs;
     if (n_devices > C) n_devices = (int)C;
     if (n_devices == 1) return solve_range(in, 0, C, o, out);
-    // cost model: sequential per-contig chains dominate -> cost ~ N (records) + fixed term
-    std::vector<double> pre(C + 1, 0.0);
-    for (int64_t c = 0; c < C; c++) pre[c + 1] = pre[c] + (double)(in->ctg_rec_off[c + 1] - in->ctg_rec_off[c]) + 16.0;
+    // contiguous blocks balanced on the density-aware per-contig cost (aasm_shard.cpp)
+    std::vector<double> cost((size_t)C);
+    contig_costs(in, cost.data());
     std::vector<int64_t> cut(n_devices + 1, 0);
-    cut[n_devices] = C;
-    for (int d = 1; d < n_devices; d++) {
-        const double target = pre[C] * d / n_devices;
-        int64_t c = std::lower_bound(pre.begin(), pre.end(), target) - pre.begin();
-        if (c <= cut[d - 1]) c = cut[d - 1] + 1;
-        if (c > C - (n_devices - d)) c = C - (n_devices - d);
-        cut[d] = c;
-    }
+    partition_by_cost(cost.data(), C, n_devices, cut.data());
     std::vector<aasm_batch_out> parts(n_devices);
     std::vector<int> rcs(n_devices, AASM_OK);
     std::vector<std::string> errs(n_devices);

@@ -52,4 +52,7 @@ void set_last_error(const std::string &msg);
 // message of the tokenizer / get_overlap_range for one record (used when the device reports a bad cs tag)
 std::string cs_error_message(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end);
 int host_threads();                          // aasm_set_host_threads (0 = all hardware threads), resolved
+// aasm_shard.cpp: per-contig cost estimate and the contiguous cost-balanced partition built on it
+void contig_costs(const aasm_batch_in *in, double *cost);
+void partition_by_cost(const double *cost, int64_t C, int n_shards, int64_t *cuts);
 }  // namespace aasm

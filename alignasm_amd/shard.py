@@ -1,33 +1,39 @@
 """Static per-contig partition used when one job spans several GPUs.
 
-Contigs are independent (the reference runs one TBB task per contig,
-/root/reference/src/alignasm.cpp:351-359), so sharding needs no collective on the data
+Contigs are independent (the reference runs one TBB task per contig over ONE input,
+/root/reference/src/alignasm.cpp:346-361), so sharding needs no collective on the data
 path: every rank solves its own contiguous block of contigs and the outputs are
-concatenated in contig order.  The same cost model is used by the C library
-(aasm_solve_batch_multi) for the one-process / many-devices case.
+concatenated in contig order.  The cost model and the cut are the C library's
+(aasm_contig_costs / aasm_partition_contigs, csrc/aasm_shard.cpp), the same ones
+aasm_solve_batch_multi uses for the one-process / many-devices case.
 """
+import ctypes as C
+
 import numpy as np
 
-
-def contig_costs(ctg_rec_off):
-    n = np.diff(np.asarray(ctg_rec_off, dtype=np.int64)).astype(np.float64)
-    return n + 16.0          # per-contig chains dominate: cost ~ records + fixed term
+from ._abi import HostBatch
+from .api import LIB, _check
 
 
-def partition_contigs(ctg_rec_off, n_shards):
-    """Cut points [c_0=0, c_1, ..., c_n=C] of a contiguous, cost-balanced partition."""
-    cost = contig_costs(ctg_rec_off)
-    C = len(cost)
-    n_shards = max(1, min(int(n_shards), C))
-    pre = np.concatenate([[0.0], np.cumsum(cost)])
-    cuts = [0]
-    for d in range(1, n_shards):
-        c = int(np.searchsorted(pre, pre[-1] * d / n_shards, side="left"))
-        c = max(c, cuts[-1] + 1)
-        c = min(c, C - (n_shards - d))
-        cuts.append(c)
-    cuts.append(C)
-    return cuts
+def _view(batch):
+    return batch.view if isinstance(batch, HostBatch) else batch.view()
+
+
+def contig_costs(batch):
+    """Estimated GPU cost per contig: records + a graph-density term from the part sizes."""
+    view = _view(batch)
+    cost = np.zeros(int(view.n_contigs), np.float64)
+    _check(LIB.aasm_contig_costs(C.byref(view), cost.ctypes.data_as(C.c_void_p)))
+    return cost
+
+
+def partition_contigs(batch, n_shards):
+    """Cut points [c_0=0, c_1, ..., c_n=C] of the contiguous, cost-balanced partition."""
+    view = _view(batch)
+    n_shards = max(1, min(int(n_shards), int(view.n_contigs)))
+    cuts = np.zeros(n_shards + 1, np.int64)
+    _check(LIB.aasm_partition_contigs(C.byref(view), n_shards, cuts.ctypes.data_as(C.c_void_p)))
+    return [int(x) for x in cuts]
 
 
 def concat_outputs(parts):

@@ -6,15 +6,25 @@ through torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON lin
 
 A "step" is one pass of the whole hot path (K1..K9 + output compaction) over one batch of
 synthetic contigs that is ALREADY RESIDENT IN HBM (uploaded before the timed region).
-Workload (config.workload): BASELINE.json configs[2] "human whole-genome-scale PAF
-(~5M records, k=4 alt paths), 1 MI355X" concretised by SURVEY.md 8(d) as C3:
-5 000 contigs x 1 000 records, sparse graph mode, K = 4, seed 21.  configs[1] (50 k
-records, K=1) is far too small to occupy the chip and is a parity-test case instead.
 
-Multi-GPU: contigs are independent, so each rank owns its own contigs and no collective
-runs on the data path (only the barrier + MAX-reduce of the wall time).  Per-GPU work is
-fixed as N grows (every rank solves a C3-sized shard generated from seed 21 + 1000*rank),
-hence "scaling": "weak"; value = contigs of ALL ranks / max-over-ranks time.
+N = 1: BASELINE.json configs[2] "human whole-genome-scale PAF (~5M records, k=4 alt paths),
+1 MI355X", concretised by SURVEY.md 8(d) as C3: 5 000 contigs x 1 000 records, sparse graph
+mode, K = 4, seed 21.  (configs[1], 50 k records at K=1, is far too small to occupy the chip and
+is a parity-test case instead.)
+
+N > 1: BASELINE.json configs[3] = C4, "the same file as C3, contig-sharded across the GPUs
+(static per-contig partition)": every rank builds the SAME C3 file (seed 21), cuts it with the
+library's cost-balanced contiguous partition (aasm_partition_contigs, csrc/aasm_shard.cpp) and
+solves only its own block.  Contigs are independent, so no collective runs on the data path
+(only the barrier + MAX-reduce of the wall time).  Total work is fixed as N grows, hence
+"scaling": "strong"; value = 5 000 contigs x steps / max-over-ranks time.  The weak-scaling
+number (every rank solves its own C3-sized file, seed 21 + 1000*rank) is reported beside it
+under "weak".  `--workload c5` (dense, K=16) is defined on 8 GPUs at 1 250 contigs per GPU -- the
+10 000-contig file does not fit one GPU -- and keeps that per-GPU share for any N (weak).
+
+Extra keys of the N = 1 line: `step_with_fetch_ms` (the step plus the D2H + ragged pack of the
+three result lists), `k10000` (the same hot path at the reference's shipped MAX_PATH_COUNT = 10000,
+paf_data.cpp:729, on the first 1 000 contigs of the batch).
 
 roofline: the dominant kernel of the timed region (largest average HIP-event time on the
 library's stream), its ALGORITHMIC bytes per launch (byte model: DESIGN.md "Byte model")
@@ -24,6 +34,7 @@ cpu_baseline: the oracle (oracle/liboracle.so, a CPU restatement: kind "port") t
 this box's host cores over a bounded sample of the same workload, rank 0, N = 1 only.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -61,16 +72,33 @@ def total_bytes(st, n_records):
             + 24 * st["n_heap_nodes"] + 192 * st["n_paths_found"])
 
 
+def timed_steps(db, K, steps, barrier):
+    """K x steps of the resident batch; returns (elapsed seconds, summed phase times, last stats)."""
+    phase_acc, stats = {}, None
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(steps):
+        res = db.solve(max_paths=K, timing=True)          # enqueues the pipeline and syncs its stream
+        stats = res.stats()
+        res.close()
+        for k, v in stats["phase_ms"].items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    elapsed = time.perf_counter() - t_begin
+    barrier()
+    return elapsed, phase_acc, stats
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--contigs", type=int, default=0, help="override contigs per GPU (exploration only)")
+    ap.add_argument("--contigs", type=int, default=0, help="override contigs (exploration only)")
     ap.add_argument("--recs", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip step_with_fetch / k10000 / weak (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="contigs of the workload timed on the CPU oracle")
     args = ap.parse_args()
 
@@ -81,17 +109,27 @@ def main():
         args.gpus = world
     dist = None
     torch = None
+    # AASM_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin, the timing reduction runs over gloo on the CPU); the driver's runs use nccl (= RCCL)
+    backend = os.environ.get("AASM_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import alignasm_amd as A
+    from alignasm_amd import shard
+    from alignasm_amd._abi import HostBatch
 
     if A.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: alignasm_amd has no CPU fallback")
+    if backend != "nccl":
+        local_rank = local_rank % A.device_count()
     nc, nr, dense, K, seed, desc = WORKLOADS[args.workload]
     custom = bool(args.contigs or args.recs or args.k)
     nc = args.contigs or nc
@@ -99,47 +137,93 @@ def main():
     K = args.k or K
     if custom:
         desc = f"CUSTOM {nc} contigs x {nr} records, {'dense' if dense else 'sparse'}, K={K}, seed {seed} (not the BASELINE workload)"
-
-    # ---- synthetic batch of this rank, uploaded before the timed region
-    t0 = time.time()
-    paf = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
-    n_records = int(paf.view().n_records)
-    gen_s = time.time() - t0
-    t0 = time.time()
-    db = A.DeviceBatch(paf, device=local_rank)
-    upload_s = time.time() - t0
+    strong = world > 1 and args.workload != "c5"           # C4: one file, sharded
+    if strong and not custom:
+        desc = ("C4 = the C3 file (5000 contigs x 1000 records, sparse, K=4, seed 21) contig-sharded over %d GPUs, "
+                "static cost-balanced contiguous partition" % world)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    def allreduce(x, op):
+        if dist is None:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    # ---- synthetic batch of this rank, uploaded before the timed region
+    t0 = time.time()
+    if strong:
+        paf = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True)            # the SAME file on every rank
+        cuts = shard.partition_contigs(paf, world)
+        mine = HostBatch.from_view_range(paf.view(), cuts[rank], cuts[rank + 1])
+        paf.close()
+        paf = None
+        my_contigs, n_records = mine.n_contigs, int(mine.view.n_records)
+        contigs_total = nc
+    else:
+        paf = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
+        mine = paf
+        my_contigs, n_records = nc, int(paf.view().n_records)
+        contigs_total = nc * world
+        cuts = None
+    gen_s = time.time() - t0
+    t0 = time.time()
+    db = A.DeviceBatch(mine, device=local_rank)
+    upload_s = time.time() - t0
+
     for _ in range(args.warmup):
         db.solve(max_paths=K, timing=True).close()
-    barrier()
-    phase_acc, stats = {}, None
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        res = db.solve(max_paths=K, timing=True)          # enqueues the pipeline and syncs its stream
-        stats = res.stats()
-        res.close()
-        for k, v in stats["phase_ms"].items():
-            phase_acc[k] = phase_acc.get(k, 0.0) + v
-    elapsed = time.perf_counter() - t_begin
-    barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        e = torch.tensor([float(stats["n_edges"])], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        total_edges = float(e.item())
-    else:
-        total_edges = float(stats["n_edges"])
+    elapsed, phase_acc, stats = timed_steps(db, K, args.steps, barrier)
+    elapsed = allreduce(elapsed, dist.ReduceOp.MAX if dist else None)
+    total_edges = allreduce(stats["n_edges"], dist.ReduceOp.SUM if dist else None)
+    max_contigs = allreduce(my_contigs, dist.ReduceOp.MAX if dist else None)
+
+    extras = {}
+    if not args.no_extras:
+        # the step plus the result fetch (D2H of the three ragged lists + host-side pack)
+        barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            res = db.solve(max_paths=K)
+            res.fetch()
+            res.close()
+        extras["step_with_fetch_ms"] = round(allreduce((time.perf_counter() - t) * 1e3 / max(args.steps, 1), dist.ReduceOp.MAX if dist else None), 3)
+        if world == 1:
+            # the reference's shipped MAX_PATH_COUNT (paf_data.cpp:729) on a slice of the same batch
+            nk = min(1000, my_contigs)
+            hbk = HostBatch.from_view_range(mine.view() if not isinstance(mine, HostBatch) else mine.view, 0, nk)
+            dbk = A.DeviceBatch(hbk, device=local_rank)
+            dbk.solve(max_paths=10000).close()
+            t = time.perf_counter()
+            for _ in range(2):
+                r = dbk.solve(max_paths=10000, timing=True)
+                stk = r.stats()
+                r.close()
+            msk = (time.perf_counter() - t) * 1e3 / 2
+            extras["k10000"] = {"ms_per_step": round(msk, 3), "contigs": nk, "contigs_per_sec": round(nk / msk * 1e3, 1), "max_paths": 10000,
+                                "paths_found": stk["n_paths_found"], "enum_ms": round(stk["phase_ms"].get("enum", 0.0), 3),
+                                "note": "first %d contigs of the same batch at the reference's shipped MAX_PATH_COUNT" % nk}
+            dbk.close()
+        if strong:
+            # weak scaling beside it: every rank solves its own C3-sized file
+            db.close()
+            pw = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
+            dbw = A.DeviceBatch(pw, device=local_rank)
+            dbw.solve(max_paths=K).close()
+            ew, _, _ = timed_steps(dbw, K, args.steps, barrier)
+            ew = allreduce(ew, dist.ReduceOp.MAX)
+            extras["weak"] = {"value": round(nc * world * args.steps / ew, 2), "unit": "contigs/s", "ms_per_step": round(ew * 1e3 / max(args.steps, 1), 3),
+                              "contigs_per_gpu": nc, "note": "every rank solves its own C3-sized file (seed 21 + 1000*rank)"}
+            dbw.close()
+            pw.close()
+            db = None
 
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = elapsed * 1e3 / steps
-        contigs_total = nc * world
         value = contigs_total * steps / elapsed
         edges_relaxed = 2.0 * total_edges * steps / elapsed            # 2*E per contig
         avg = {k: v / steps for k, v in phase_acc.items()}
@@ -154,51 +238,57 @@ def main():
             "metric": "contigs_per_sec", "value": round(value, 2), "unit": "contigs/s",
             "edges_relaxed_per_sec": round(edges_relaxed, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": desc, "contigs_per_gpu": nc, "records_per_contig": nr, "max_paths": K,
-                       "graph_mode": "dense" if dense else "sparse", "parallelism": f"contig-shard x{world}",
-                       "records_per_gpu": n_records},
+            "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": desc, "contigs_total": contigs_total, "contigs_on_rank0": my_contigs, "contigs_on_fullest_rank": int(max_contigs),
+                       "records_per_contig": nr, "max_paths": K, "graph_mode": "dense" if dense else "sparse",
+                       "parallelism": f"contig-shard x{world}", "records_on_rank0": n_records,
+                       "partition": ("aasm_partition_contigs cuts %s" % cuts) if cuts else "none"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(dom_ms, 3), "kernel_bytes": int(dom_bytes),
                          "pipeline_bytes": int(Btot), "pipeline_ms": round(pipe_ms, 3),
-                         "pipeline_achieved": round(Btot / (pipe_ms * 1e-3) / 1e9, 2) if pipe_ms > 0 else 0.0},
+                         "pipeline_achieved": round(Btot / (pipe_ms * 1e-3) / 1e9, 2) if pipe_ms > 0 else 0.0,
+                         "scope": "rank 0" if world > 1 else "the batch"},
             "phase_ms": {k: round(v, 3) for k, v in avg.items() if v > 0},
             "graph": {"V": stats["n_vertices"], "E": stats["n_edges"], "P": stats["n_pairs"], "H": stats["n_heap_nodes"],
                       "paths_found": stats["n_paths_found"], "paths_converted": stats["n_paths_converted"],
                       "device_MB": stats["device_bytes"] >> 20},
             "setup": {"gen_s": round(gen_s, 2), "upload_s": round(upload_s, 2)},
         }
-        pmc = pmc_traffic(args.workload, custom, dom_name)
+        out.update(extras)
+        pmc = pmc_traffic(args.workload, custom or world > 1, dom_name)
         if pmc:
             out["roofline"].update(pmc)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(paf, nc, K, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    db.close()
-    paf.close()
+    if db is not None:
+        db.close()
+    if paf is not None:
+        paf.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(workload, custom, kernel):
+def pmc_traffic(workload, not_profiled_shape, kernel):
     """HBM traffic of the dominant kernel from the committed OFFLINE rocprofv3 --pmc passes
-    (profiles/r01_c3_pmc_fetch_write.json: one pass per counter, --kernel-trace only).
+    (profiles/rNN_c3_pmc_fetch_write.json, newest round: one pass per counter, --kernel-trace only).
     FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half
     the bytes of a wide (16 B/lane) coalesced stream and is uncalibrated for other widths; these
     kernels gather 4-48 B per access, so the raw value is reported and the x2 figure is given
     as the upper bound.  Only attached when the run IS the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r01_c3_pmc_fetch_write.json")
-    if custom or workload != "c3" or not os.path.exists(path):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_c3_pmc_fetch_write.json")))
+    if not_profiled_shape or workload != "c3" or not files:
         return None
+    path = files[-1]
     data = json.load(open(path))
     for name, v in data.items():
-        if kernel in name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if (name.startswith("aasm::" + kernel + "(") or name.startswith(kernel + "(") or name == kernel) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             f, w_ = v["FETCH_SIZE"]["mean_per_launch"] * 1024, v["WRITE_SIZE"]["mean_per_launch"] * 1024
             return {"traffic": int(f + w_), "traffic_fetch_raw": int(f), "traffic_write": int(w_),
                     "traffic_upper_fetch_x2": int(2 * f + w_),
-                    "traffic_source": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_c3_pmc_fetch_write.json"}
+                    "traffic_source": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + os.path.basename(path)}
     return None
 
 
@@ -207,7 +297,7 @@ def cpu_baseline(paf, nc, K, sample):
     import ctypes as C
     import aasm_testlib as T
     from alignasm_amd._abi import BatchOut, HostBatch, Opts
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, os.cpu_count() or 1)
     n = min(sample, nc)
     hb = HostBatch.from_view_range(paf.view(), 0, n)
     lib = T.oracle()

@@ -178,6 +178,13 @@ int  aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch
  * in contig order; no collective (contigs are independent, src/alignasm.cpp:351-359).    */
 int  aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n_devices, aasm_batch_out *out);
 
+/* The partition aasm_solve_batch_multi uses, for callers that run one process per GPU (bench.py, MPI-style
+ * launchers): cost[c] = estimated GPU cost of contig c (records + a graph-density term from the part sizes);
+ * cuts[0..n_shards] = cut points of the contiguous, cost-balanced partition (cuts[0] = 0, cuts[n] = n_contigs).
+ * Host pointers; only ctg_rec_off, qry_str and qry_end are read.                                       */
+int  aasm_contig_costs(const aasm_batch_in *in, double *cost);
+int  aasm_partition_contigs(const aasm_batch_in *in, int n_shards, int64_t *cuts);
+
 /* Same, with the batch already resident in device memory (in->pointers are device
  * pointers; in->ctg_rec_off / rec_rng_off too).  `stream` is a hipStream_t (or NULL).
  * The device result stays resident in an opaque handle until fetched/freed.          */

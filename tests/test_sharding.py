@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
     from alignasm_amd import shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hb = T.synth(9, 60, 17, heavy_tail=True, dup_every=5)     # every rank builds the same file
-    cuts = shard.partition_contigs(hb.arrays["ctg_rec_off"], world)
+    cuts = shard.partition_contigs(hb, world)
     mine = hb.subset(list(range(cuts[rank], cuts[rank + 1])))
     part = T.emul_solve(mine, 64)
     dist.barrier()
@@ -50,14 +50,36 @@ def test_two_rank_contig_sharding_matches_unsharded():
     assert cuts[0] == 0 and cuts[-1] == 9 and all(a < b for a, b in zip(cuts, cuts[1:]))
 
 
-def test_partition_invariants():
+def test_partition_invariants(T):
     from alignasm_amd import shard
-    rng = np.random.default_rng(0)
-    for C_, n in ((1, 4), (7, 8), (100, 8), (5000, 8), (33, 2)):
-        sizes = rng.integers(1, 4000, C_)
-        off = np.concatenate([[0], np.cumsum(sizes)])
-        cuts = shard.partition_contigs(off, n)
-        assert cuts[0] == 0 and cuts[-1] == C_ and all(a < b for a, b in zip(cuts, cuts[1:])) and len(cuts) - 1 == min(n, C_)
-        if C_ >= 50 * n:
-            loads = [shard.contig_costs(off)[a:b].sum() for a, b in zip(cuts, cuts[1:])]
+    for nc, n in ((1, 4), (7, 8), (100, 8), (600, 8), (33, 2)):
+        hb = T.synth(nc, 40, 3 + nc, heavy_tail=True)
+        cuts = shard.partition_contigs(hb, n)
+        assert cuts[0] == 0 and cuts[-1] == nc and all(a < b for a, b in zip(cuts, cuts[1:])) and len(cuts) - 1 == min(n, nc)
+        if nc >= 50 * n:
+            cost = shard.contig_costs(hb)
+            loads = [cost[a:b].sum() for a, b in zip(cuts, cuts[1:])]
             assert max(loads) < 1.25 * (sum(loads) / len(loads))
+
+
+def test_cost_model_sees_graph_density(T):
+    """the partition balances estimated GPU work, not record counts.  A dense contig
+    (large parts -> E ~ N * part size) must weigh an order of magnitude more than a sparse one of the
+    same N, as it does on the GPU (~40x), and a mixed file must be cut accordingly."""
+    from alignasm_amd import shard
+    from alignasm_amd._abi import HostBatch
+    sparse, dense = T.synth(12, 400, 21), T.synth(4, 400, 31, dense=True)
+    cs, cd = shard.contig_costs(sparse), shard.contig_costs(dense)
+    assert 10 < cd.mean() / cs.mean() < 100
+    # E_est tracks the real edge count within a small factor on both kinds
+    for hb, cost in ((sparse, cs), (dense, cd)):
+        E = T.oracle_solve(hb, 1)["stats"]["n_edges"]
+        n = hb.arrays["ctg_rec_off"][-1]
+        assert 0.2 < (cost.sum() - n) / (0.25 * E * np.log2(2 + E / n)) < 5
+    # 4 dense contigs first, then 12 sparse ones, two shards: the cut falls inside the dense block
+    a, b = dense.arrays, sparse.arrays
+    mixed = {k: np.concatenate([a[k], b[k]]) for k in a if k not in ("ctg_rec_off", "rec_rng_off")}
+    mixed["ctg_rec_off"] = np.concatenate([a["ctg_rec_off"], b["ctg_rec_off"][1:] + a["ctg_rec_off"][-1]])
+    mixed["rec_rng_off"] = np.concatenate([a["rec_rng_off"], b["rec_rng_off"][1:] + a["rec_rng_off"][-1]])
+    cuts = shard.partition_contigs(HostBatch(mixed), 2)
+    assert cuts == [0, 2, 16]
