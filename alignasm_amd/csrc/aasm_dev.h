@@ -133,16 +133,31 @@ template <class T> struct LaneArr { T r; AASM_MEM T &at(int) { return r; } };
 #endif
 
 // c[j] <- min of c[i] over j < i < n (INT32_MAX where there is none), n <= 64
+// Device: DPP row shifts (a lane reads the lane d places above it inside its row of 16; out-of-row sources
+// keep the identity) give the inclusive suffix-min of every row in four vector instructions; rows are joined
+// through three broadcast reads when n reaches past the first row; one wavefront shift makes it exclusive.
+#if !defined(AASM_HOST_EMUL)
+template <int CTRL> AASM_DEV int32_t dpp_or(int32_t identity, int32_t x) { return __builtin_amdgcn_update_dpp(identity, x, CTRL, 0xf, 0xf, false); }
+#endif
 AASM_DEV void lane_excl_suffix_min(LaneArr<int32_t> &c, int n, int lane) {
 #if defined(AASM_HOST_EMUL)
     int32_t run = INT32_MAX;
     for (int j = n - 1; j >= 0; j--) { const int32_t t = c.a[j]; c.a[j] = run; run = t < run ? t : run; }
     (void)lane;
 #else
-    int32_t x = lane < n ? c.r : INT32_MAX;
-    for (int d = 1; d < n; d <<= 1) { const int32_t y = __shfl_down(x, d, 64); if (lane + d < AASM_WAVE && y < x) x = y; }   // log2(n) steps: lanes >= n hold INT32_MAX
-    const int32_t e = __shfl_down(x, 1, 64);
-    c.r = (lane + 1 < AASM_WAVE) ? e : INT32_MAX;
+    int32_t x = lane < n ? c.r : INT32_MAX, y;
+    y = dpp_or<0x101>(INT32_MAX, x); x = y < x ? y : x;               // row_shl:1
+    y = dpp_or<0x102>(INT32_MAX, x); x = y < x ? y : x;               // row_shl:2
+    y = dpp_or<0x104>(INT32_MAX, x); x = y < x ? y : x;               // row_shl:4
+    y = dpp_or<0x108>(INT32_MAX, x); x = y < x ? y : x;               // row_shl:8
+    if (n > 16) {                                                     // wave-uniform: spines longer than 15 nodes (heaps of > 32 k nodes)
+        const int32_t s3 = __builtin_amdgcn_readlane(x, 48);
+        int32_t s2 = __builtin_amdgcn_readlane(x, 32), s1 = __builtin_amdgcn_readlane(x, 16);
+        s2 = s3 < s2 ? s3 : s2; s1 = s2 < s1 ? s2 : s1;
+        const int32_t above = lane < 16 ? s1 : lane < 32 ? s2 : lane < 48 ? s3 : INT32_MAX;
+        x = above < x ? above : x;
+    }
+    c.r = dpp_or<0x130>(INT32_MAX, x);                                // wave_shl:1: the value of lane + 1
 #endif
 }
 
@@ -272,6 +287,20 @@ AASM_DEV NodeQ uni(const NodeQ &n) {
 AASM_DEV Dist uni(const Dist &d) {
     Dist r; r.qry = uni(d.qry); r.ref = uni(d.ref); r.anom = uni(d.anom); r.qnz = uni(d.qnz); r.qtot = uni(d.qtot); r.pad = 0; return r;
 }
+// element j (wave-uniform j) of a lane array of distances
+#if defined(AASM_HOST_EMUL)
+AASM_DEV Dist la_get_dist(const LaneArr<Dist> &a, int j) { return a.a[j]; }
+#else
+AASM_DEV Dist la_get_dist(const LaneArr<Dist> &a, int j) {
+    Dist d;
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(uint64_t)a.r.qry, j), q1 = (uint32_t)__builtin_amdgcn_readlane((int32_t)((uint64_t)a.r.qry >> 32), j);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(uint64_t)a.r.ref, j), r1 = (uint32_t)__builtin_amdgcn_readlane((int32_t)((uint64_t)a.r.ref >> 32), j);
+    d.qry = (int64_t)(((uint64_t)q1 << 32) | q0); d.ref = (int64_t)(((uint64_t)r1 << 32) | r0);
+    d.anom = __builtin_amdgcn_readlane(a.r.anom, j); d.qnz = __builtin_amdgcn_readlane(a.r.qnz, j); d.qtot = __builtin_amdgcn_readlane(a.r.qtot, j);
+    d.pad = __builtin_amdgcn_readlane(a.r.pad, j);
+    return d;
+}
+#endif
 AASM_DEV Dist hnode_key(const HNode &n) {
     Dist d; d.qry = n.kq; d.ref = n.kr; d.anom = n.ka; d.qnz = n.kn; d.qtot = n.kt; d.pad = 0; return d;
 }

@@ -92,10 +92,10 @@ struct WS {
     int32_t *status;
     int64_t *counters;
     int64_t *prof_heap, *prof_sel;    // [C * 8] cycle sums per section (diagnostic build only)
-    // ---- K7 pre-pass: sidetrack cost per edge (st_fl: 1 = insert it) and the packed per-vertex header
-    Dist *st_cost;
-    uint8_t *st_fl;
-    I4 *vhdr, *vhdr2;
+    // ---- K7 pre-pass: compacted sidetrack keys and the packed per-vertex header
+    Dist *st_cost;                       // per vertex, at the front of its CSR row: its sidetrack keys in list order, edge head in .pad
+    int32_t *st_n;                       // ... and how many
+    I4 *vhdr, *vhdr2, *cinfo;            // kb_heap_hdr
     I4 *tnx;                             // next four vertices along best[] (path recovery reads one record per four tree edges)
     I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
@@ -1177,45 +1177,64 @@ AASM_DEV void kb_child_fill(const KCtx &k, const WS &w) {           // thread pe
         w.cval[pos] = (int32_t)(gv - vb);
     }
 }
-// K7 pre-pass, thread per vertex u (k_shortest_walks.hpp:204-210 without the insert): for
-// every out-edge the sidetrack cost c = w + d[v] - d[u] and whether it goes into the heap -
-// not when d[v] is max() (:204-205), and not the FIRST edge of the list that is u's tree edge
-// (:207-210).  Plus the header the heap wave reads per vertex, packed into two 16-byte words:
-// {row start (2), row length, #children} {first child, child-list start (2), #inserts}.  This takes
-// d[], best[], the row pointers and, for the common single child, the child list out of the
-// wave's chain of dependent loads, and lets it prefetch the next vertex's header.
+// K7 pre-pass 1, thread per vertex u (k_shortest_walks.hpp:204-210 without the insert): the sidetrack cost
+// c = w + d[v] - d[u] of every out-edge that goes into u's heap - not when d[v] is max() (:204-205), and not
+// the FIRST edge of the list that is u's tree edge (:207-210) - written COMPACTED to the front of u's row of
+// st_cost, in list order, with the edge head v in the pad word.  The heap wave then reads a vertex's keys with
+// one coalesced load (lane t = key t) instead of flag, cost and head through three dependent loads.
+// A sidetrack cost has score sum >= 0 (d[u] is minimal in the CALC_SUM order, whose first key is the sum), so
+// no heap key is ever max() (sum -2): K7's key test needs no sentinel handling.  Checked here.
 AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
-    const int64_t vb = w.voff[w.v_ctg[gv]];
+    const int64_t c = w.v_ctg[gv], vb = w.voff[c];
     const Dist *d = w.sp_d + vb;
     const Dist du = w.sp_d[gv];
     const int32_t bu = w.sp_best[gv];
     const int64_t r0 = w.rowptr[gv], r1 = w.rowptr[gv + 1];
-    bool seen_p = false;
+    const bool reach = !dist_is_max(du);
+    bool seen_p = false, bad = false;
     int32_t n_ins = 0;
     for (int64_t e = r0; e < r1; e++) {
         const int32_t v = w.e_col[e];
         const Dist dv = d[v];
-        uint8_t fl = 0;
         if (!dist_is_max(dv)) {
-            const Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
+            Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
             if (!seen_p && v == bu && dist_eq(cc, dist_zero())) seen_p = true;
-            else { fl = 1; w.st_cost[e] = cc; n_ins++; }
+            else { bad |= reach && (cc.qry + cc.ref) < 0; cc.pad = v; w.st_cost[r0 + n_ins] = cc; n_ins++; }
         }
-        w.st_fl[e] = fl;
     }
-    const int64_t c0 = w.cptr[gv], c1 = w.cptr[gv + 1];
-    I4 a, b;
-    a.x = (int32_t)(uint32_t)(uint64_t)r0; a.y = (int32_t)((uint64_t)r0 >> 32); a.z = (int32_t)(r1 - r0); a.w = (int32_t)(c1 - c0);
-    b.x = (c1 > c0) ? w.cval[c0] : -1; b.y = (int32_t)(uint32_t)(uint64_t)c0; b.z = (int32_t)((uint64_t)c0 >> 32); b.w = n_ins;
-    w.vhdr[gv] = a; w.vhdr2[gv] = b;
+    w.st_n[gv] = n_ins;
+    if (bad) w.status[c] = -6;                                       // must not happen (see above)
     I4 t;                                                            // best[] is final here (K6 done)
     t.x = bu;
     t.y = t.x >= 0 ? w.sp_best[vb + t.x] : -1;
     t.z = t.y >= 0 ? w.sp_best[vb + t.y] : -1;
     t.w = t.z >= 0 ? w.sp_best[vb + t.z] : -1;
     w.tnx[gv] = t;
+}
+// K7 pre-pass 2, thread per vertex u: what the heap wave reads per vertex, 32 bytes:
+//   vhdr  = {so, #keys, #children, first child}          so = start of u's keys, relative to the contig's first edge
+//   vhdr2 = {child-list start (2 words), so(first child), #keys(first child)}
+// and per child-list slot cinfo = {child, so(child), #keys(child), -}.  A parent hands every child the place
+// of its keys, so the wave fetches a vertex's header AND keys while it still works on the vertex before it
+// (the queue front; in a path-like tree the first child of the vertex at hand).
+AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT) return;
+    const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
+    const int64_t c0 = w.cptr[gv], c1 = w.cptr[gv + 1];
+    const int32_t fc = (c1 > c0) ? w.cval[c0] : -1;
+    I4 a, b;
+    a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;
+    b.x = (int32_t)(uint32_t)(uint64_t)c0; b.y = (int32_t)((uint64_t)c0 >> 32);
+    b.z = fc >= 0 ? (int32_t)(w.rowptr[vb + fc] - e_base) : 0; b.w = fc >= 0 ? w.st_n[vb + fc] : 0;
+    w.vhdr[gv] = a; w.vhdr2[gv] = b;
+    for (int64_t t = c0; t < c1; t++) {
+        const int32_t ch = w.cval[t];
+        I4 ci; ci.x = ch; ci.y = (int32_t)(w.rowptr[vb + ch] - e_base); ci.z = w.st_n[vb + ch]; ci.w = 0;
+        w.cinfo[t] = ci;
+    }
 }
 
 // arena capacity per contig: an insert into a heap of s nodes allocates at most
@@ -1227,6 +1246,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     if (V == 0) { w.hcap_cnt[c] = 0; return; }
     const int64_t vb = w.voff[c];
     const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
+    if (E > (int64_t)INT32_MAX - 64) { w.status[c] = -5; w.hcap_cnt[c] = 0; return; }   // contig-local edge ids are int32 (AASM_E_OVERFLOW)
     int64_t I = E - (V - 1);
     if (I < 0) I = 0;
     int lg = 0;
@@ -1236,144 +1256,179 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.hcap_cnt[c] = (int32_t)cap;
 }
 
-// Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index ==
-// allocation order, hazard B3).  Its working set:
-//   spine (registers)  the RIGHT SPINE of the heap the last insert produced, one node per lane
-//                 (lane j = j-th node from the root).  80-96 % of the inserts continue from
-//                 exactly that heap, and an insert's descent path is a prefix of its right
-//                 spine, so the descent is ONE lane-parallel compare + ballot and the copied
-//                 nodes of the path are built and stored by all lanes at once; the rank chain
-//                 (leftist_heap.hpp:36-38) is a min-plus recurrence, solved by one suffix-min
-//                 over the lanes.  A rank swap at position t sends the new spine into an
-//                 old left subtree: the cache then holds positions 0..t plus the node where it
-//                 continues (tail); the walk past the cached prefix (or after a root switch)
-//                 chases pointers and appends what it reads to the cache.
-//   ring (LDS)    read cache of the newest nodes for that pointer chase
-//   cbuf / vbuf   sidetrack costs + heads of one 64-edge chunk of the adjacency row,
-//                 computed by all lanes at once
-//   bqv / bqh     BFS queue window: vertex + inherited heap root
-// Control flow is wave-uniform; uniform data is stored by lane 0 only (64 identical stores to
-// one address are 64 write requests into one L2 channel).
-#define HEAP_RING 32
+// Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
+// hazard B3).  What the counters of the first version said: with ~20 one-wave workgroups per
+// CU the kernel was bound by the ONE scalar unit a CU's four SIMDs share (2.8 G scalar against 1.1 G vector
+// instructions), and per contig by chains of dependent memory round trips.  So this version
+//  * keeps per-insert work on the vector unit: the right spine of the current heap lives in registers, node j
+//    in lane j, with its score sum cached; the descent is two vector compares + a ballot, the rank chain
+//    (leftist_heap.hpp:36-38, a min-plus recurrence) one suffix-min over the lanes by DPP row shifts, and the
+//    new nodes are built by selects in all lanes at once; the scalar unit only steers;
+//  * issues NO global store inside a vertex's work: new nodes go to an LDS ring (also the read cache of the
+//    pointer chase) and reach the arena in one coalesced flush at the START of the next vertex, together with
+//    the finished root of the vertex before.  vmcnt counts loads and stores in issue order, so a load waits
+//    for every older store: with all stores issued ahead of the prefetch loads of a vertex, waiting for those
+//    loads one vertex later costs nothing extra;
+//  * fetches the next vertex's header and sidetrack keys one vertex ahead (kb_heap_hdr).
+//   spine (registers)  80-96 % of the inserts continue from exactly the heap the last insert made, and an
+//                 insert's descent path is a prefix of its right spine.  A rank swap at position t sends the
+//                 new spine into an old left subtree: the cache then holds positions 0..t plus the node where
+//                 it continues (tail); the walk past the cached prefix (or after a root switch) chases
+//                 pointers and appends what it reads to the cache.
+//   ring (LDS)    the newest HEAP_RING nodes: staging for the flush + read cache for that pointer chase
+//   bq (LDS)      BFS queue window: {vertex, inherited heap root, key offset, #keys}; entries beyond the
+//                 window spill to global memory (wide trees)
+#define HEAP_RING 64
 #define HEAP_QN 128
-#define AASM_HEAP_LDS_BYTES 6144
+#define AASM_HEAP_LDS_BYTES 5120
 struct HeapLds {
     HNode ring[HEAP_RING];
-    Dist cbuf[AASM_WAVE];
-    int32_t vbuf[AASM_WAVE];
-    int32_t bqv[HEAP_QN], bqh[HEAP_QN];
+    I4 bq[HEAP_QN];
 };
 static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
-#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-#define HI_PROF_ARGS , int64_t &kp_t0, int64_t *kp_acc
-#define HI_PROF_PASS , kp_t0, kp_acc
-#else
-#define HI_PROF_ARGS
-#define HI_PROF_PASS
-#endif
 struct Spine {
     LaneArr<NodeQ> n;          // cached nodes, position j in lane j
     LaneArr<int32_t> idx;      // their arena indices
+    LaneArr<int64_t> sum;      // key.qry_score + key.ref_score of node j (first key of the CALC_SUM order)
     LaneArr<int32_t> t;        // unwinding result of position j: rank word | swapped << 24
     int32_t root, len, tail;   // heap the cache describes; cached positions; node after them (-1: the spine ends)
 };
+struct HeapState {
+    HNode *nodes;
+    HeapLds *L;
+    int32_t alloc, flushed, cap;   // arena: next index; nodes below `flushed` are in global memory, [flushed, alloc) only in the ring
+    bool ovf;
+};
 
-AASM_DEV NodeQ heap_read(const HNode *nodes, const HeapLds *L, int32_t a, int32_t alloc) {
+AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
     NodeQ n;
-    if (a >= alloc - HEAP_RING) n = nodeq_load(&L->ring[a & (HEAP_RING - 1)]);      // ds_read, lgkmcnt only
-    else { n = nodeq_load(&nodes[a]); asm volatile("" ::: "memory"); }             // keep it a global_load (no flat access)
+    if (a >= hs.alloc - HEAP_RING) n = nodeq_load(&hs.L->ring[a & (HEAP_RING - 1)]);   // ds_read, lgkmcnt only
+    else { n = nodeq_load(&hs.nodes[a]); asm volatile("" ::: "memory"); }             // keep it a global_load (no flat access)
     return n;
 }
-AASM_DEV bool nodeq_key_lt(const NodeQ &n, const Dist &key, int64_t ksum) {          // node.key < key (paf_data.hpp:142-159)
+// node.key < key (paf_data.hpp:142-159, CALC_SUM mode) for keys that are never max() (kb_sidetrack)
+AASM_DEV bool nodeq_key_lt(const NodeQ &n, const Dist &key, int64_t ksum) {
     const Dist nk = nodeq_key(n);
     const int64_t nsum = nk.qry + nk.ref;
     if (nsum != ksum && nsum != -2 && ksum != -2) return nsum < ksum;                // neither side is max() (score sum -2)
     return dist_lt<CALC_SUM_MODE>(nk, key);
 }
+AASM_DEV bool key_tie_lt(const NodeQ &n, const Dist &key) {                          // ... the rest of the order when the sums are equal
+    const int32_t na = n.q1.x, nn = n.q1.y, nt = n.q1.z ? n.q1.z : 1, kt = key.qtot ? key.qtot : 1;
+    return (na < key.anom) | ((na == key.anom) & ((int64_t)nn * (int64_t)kt > (int64_t)key.qnz * (int64_t)nt));
+}
+// the arena receives the ring's unflushed nodes [flushed, alloc): consecutive 48-byte nodes, one per lane
+AASM_DEV void heap_flush(HeapState &hs, int lane) {
+    const int32_t m = hs.alloc - hs.flushed;
+    if (m > 0) {
+        wave_lds_sync();
+        FOR_LANE(t, m, lane) { const int32_t a = hs.flushed + t; nodeq_store(&hs.nodes[a], nodeq_load(&hs.L->ring[a & (HEAP_RING - 1)])); }
+        hs.flushed = hs.alloc;
+    }
+}
 
 // One persistent insert (leftist_heap.hpp:29-40) into heap `hu`; returns the new root.
-AASM_DEV int32_t heap_insert(HNode *nodes, HeapLds *L, Spine &sp, int32_t &alloc, int32_t cap, int32_t hu, const Dist key, int32_t eu, int32_t ev, bool &ovf, int lane HI_PROF_ARGS) {
+template <class KP>
+AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist key, int32_t eu, int32_t ev, int lane, KP &kp) {
     const int64_t ksum = key.qry + key.ref;
     if (hu != sp.root) { sp.root = hu; sp.len = 0; sp.tail = hu; }                   // root switch: nothing cached yet
     // ---- descent (:30): first spine position whose key is NOT < key
     int32_t depth = -1, a_stop = -1, a_rank = 0;
     if (sp.len > 0) {
-        const uint64_t m = wave_index_mask(sp.len, lane, [&](int j) { return !nodeq_key_lt(sp.n.at(j), key, ksum); });
-        if (m) { depth = ffs64(m) - 1; a_stop = LA_GET(sp.idx, depth, ); a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; }
+        uint64_t lt = wave_index_mask(sp.len, lane, [&](int j) { return sp.sum.at(j) < ksum; });
+        const uint64_t eq = wave_index_mask(sp.len, lane, [&](int j) { return sp.sum.at(j) == ksum; });
+        if (eq) lt |= wave_index_mask(sp.len, lane, [&](int j) { return sp.sum.at(j) == ksum && key_tie_lt(sp.n.at(j), key); });
+        const uint64_t stop = ~lt & lanemask_lt(sp.len);
+        if (stop) { depth = ffs64(stop) - 1; a_stop = LA_GET(sp.idx, depth, ); a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; }
     }
     if (depth < 0) {                                                                // past the cached prefix: chase and extend the cache
         depth = sp.len;
         int32_t a = sp.tail;
+        if (a >= 0) wave_lds_sync();                                                // ring writes of earlier inserts before the ring reads
         while (a >= 0) {
-            // the node is the same in every lane; the 64-bit key compare stays on the vector unit (one
-            // v_cmp per 64-bit test, where the scalar unit needs a sequence each) and only its outcome,
-            // the rank and the right pointer become scalars
-            const NodeQ n = heap_read(nodes, L, a, alloc);
+            // the node is the same in every lane; the 64-bit key compare stays on the vector unit and only its
+            // outcome, the rank and the right pointer become scalars
+            const NodeQ n = heap_read(hs, a);
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+            kp.acc[(a >= hs.alloc - HEAP_RING) ? 7 : 6] += 1;                      // diagnostic: chase steps served by the ring / by global memory
+#endif
             if (!uni(nodeq_key_lt(n, key, ksum))) { a_rank = uni(n.q1.w) & 0xff; break; }
-            if (depth >= AASM_WAVE_MAX - 2) { ovf = true; return -1; }
+            if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
             LA_SET(sp.n, depth, lane, n);
             LA_SET(sp.idx, depth, lane, a);
+            LA_SET(sp.sum, depth, lane, nodeq_key(n).qry + nodeq_key(n).ref);
             depth++;
             a = uni(n.q2.y);                                                        // ->right
         }
         a_stop = a;
     }
-    KPROF_STAMP(4);                                                                 // descent
-    if (alloc + depth + 1 > cap) { ovf = true; return -1; }
+    if (hs.alloc + depth + 1 > hs.cap) { hs.ovf = true; return -1; }
+    if (hs.alloc + depth + 1 - hs.flushed > HEAP_RING) heap_flush(hs, lane);        // the new nodes must not overwrite unflushed ring slots
     // ---- rank chain (:34-38).  Bottom-up the recursion computes, with R = rank of the subtree
     // below and R_depth = 1 (the new leaf, :31):  swap iff l == null or rank(l) < R;  rank of the
     // copy R_j = 0 if l == null (the copy then has no right child) else min(rank(l), R) + 1.
     // With a_j = 0 / rank(l_j) + 1 that is R_j = min(a_j, R_{j+1} + 1), a min-plus recurrence with
     // the closed form R_j = min_{i >= j}(a_i + i) - j (a_depth = 1): one suffix-min over the lanes.
     FOR_LANE(j, depth + 1, lane) {
-        if (j == depth) sp.t.at(j) = depth + 1;
-        else { const NodeQ &nj = sp.n.at(j); sp.t.at(j) = ((nj.q2.x < 0) ? 0 : (((nj.q1.w >> 8) & 0xff) + 1)) + j; }
+        const NodeQ &nj = sp.n.at(j);
+        const int32_t aj = (nj.q2.x < 0) ? 0 : (((nj.q1.w >> 8) & 0xff) + 1);
+        sp.t.at(j) = ((j == depth) ? 1 : aj) + j;
     }
     lane_excl_suffix_min(sp.t, depth + 1, lane);                                    // t[j] = R_{j+1} + (j + 1)
-    FOR_LANE(j, depth, lane) {
-        const NodeQ &nj = sp.n.at(j);
-        const int32_t l = nj.q2.x, l_rank = (nj.q1.w >> 8) & 0xff, r_rank = sp.t.at(j) - (j + 1);
-        const bool sw = (l < 0) || (l_rank < r_rank);                               // :36-37
+    // ---- new nodes: leaf = alloc, copy of path position j = alloc + (depth - j)  (allocation order of the recursion)
+    const int32_t alloc = hs.alloc, nalloc = alloc + depth + 1;
+    uint64_t swm = 0;
+#if defined(AASM_HOST_EMUL)
+    for (int j = 0; j <= depth; j++)
+#else
+    const int j = lane;
+    const bool in = j <= depth;
+#endif
+    {
+        const bool leaf = (j == depth);
+        const NodeQ old = sp.n.at(j);
+        const int32_t l = old.q2.x, l_rank = (old.q1.w >> 8) & 0xff, r_rank = sp.t.at(j) - (j + 1);
+        const bool sw = (l < 0) | (l_rank < r_rank);                                // :36-37
         const bool has_right = sw ? (l >= 0) : true;
         const int32_t nr_rank = has_right ? (sw ? l_rank : r_rank) : 0;
         const int32_t nrank = has_right ? nr_rank + 1 : 0;                          // :38
-        sp.t.at(j) = nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16) | ((sw ? 1 : 0) << 24);
-    }
-    // ---- new nodes: leaf = alloc, copy of path position j = alloc + (depth - j)  (allocation order of the recursion)
-    const int32_t nalloc = alloc + depth + 1;
-    FOR_LANE(j, depth + 1, lane) {
+        const int32_t ni = alloc + (depth - j), below = ni - 1;
         NodeQ n;
-        int32_t ni;
-        if (j == depth) {                                                           // :31-32: (1, k, v, left = a, right = null)
-            ni = alloc;
-            n.q0.x = (int32_t)(uint32_t)(uint64_t)key.qry; n.q0.y = (int32_t)((uint64_t)key.qry >> 32);
-            n.q0.z = (int32_t)(uint32_t)(uint64_t)key.ref; n.q0.w = (int32_t)((uint64_t)key.ref >> 32);
-            n.q1.x = key.anom; n.q1.y = key.qnz; n.q1.z = key.qtot; n.q1.w = 1 | (a_rank << 8);
-            n.q2.x = a_stop; n.q2.y = -1; n.q2.z = eu; n.q2.w = ev;
-            sp.t.at(j) = 0;
-        } else {
-            ni = alloc + (depth - j);
-            n = sp.n.at(j);
-            const int32_t below = ni - 1, l = n.q2.x, tw = sp.t.at(j);
-            const bool sw = (tw >> 24) != 0;
-            n.q2.x = sw ? below : l; n.q2.y = sw ? l : below;
-            n.q1.w = tw & 0xffffff;
+        n.q0.x = leaf ? (int32_t)(uint32_t)(uint64_t)key.qry : old.q0.x; n.q0.y = leaf ? (int32_t)((uint64_t)key.qry >> 32) : old.q0.y;
+        n.q0.z = leaf ? (int32_t)(uint32_t)(uint64_t)key.ref : old.q0.z; n.q0.w = leaf ? (int32_t)((uint64_t)key.ref >> 32) : old.q0.w;
+        n.q1.x = leaf ? key.anom : old.q1.x; n.q1.y = leaf ? key.qnz : old.q1.y; n.q1.z = leaf ? key.qtot : old.q1.z;
+        n.q1.w = leaf ? (1 | (a_rank << 8)) : (nrank | ((sw ? r_rank : l_rank) << 8) | (nr_rank << 16));   // :31-32: (1, k, v, left = a, right = null)
+        n.q2.x = leaf ? a_stop : (sw ? below : l); n.q2.y = leaf ? -1 : (sw ? l : below);
+        n.q2.z = leaf ? eu : old.q2.z; n.q2.w = leaf ? ev : old.q2.w;
+#if defined(AASM_HOST_EMUL)
+        nodeq_store(&hs.L->ring[ni & (HEAP_RING - 1)], n);
+        sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;
+        if (!leaf && sw) swm |= 1ull << j;
+#else
+        if (in) {
+            nodeq_store(&hs.L->ring[ni & (HEAP_RING - 1)], n);
+            sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;       // position j of the NEW spine (valid up to the first swap)
         }
-        nodeq_store(&nodes[ni], n);
-        if (ni >= nalloc - HEAP_RING) nodeq_store(&L->ring[ni & (HEAP_RING - 1)], n);
-        sp.n.at(j) = n; sp.idx.at(j) = ni;                                          // position j of the NEW spine (valid up to the first swap)
+        swm = wave_ballot(in && !leaf && sw);
+#endif
     }
-    wave_lds_sync();                                                                   // ring visible
     // ---- spine of the new heap: new nodes down to the first swapped position, then its old left subtree
-    const uint64_t swm = wave_index_mask(depth, lane, [&](int j) { return (sp.t.at(j) >> 24) != 0; });
     if (swm) { const int t = ffs64(swm) - 1; sp.len = t + 1; sp.tail = LA_GET(sp.n, t, .q2.y); }
     else { sp.len = depth + 1; sp.tail = -1; }                                      // ... or all of them and the leaf (right == null)
     sp.root = alloc + depth;
-    alloc = nalloc;
-    KPROF_STAMP(5);                                                                 // chain + node construction
+    hs.alloc = nalloc;
     return sp.root;
 }
 
+// header + this lane's sidetrack key of one vertex, fetched one vertex ahead
+struct VPre { int32_t u; I4 a, b; LaneArr<Dist> key; };
+AASM_DEV void vpre_load(VPre &p, const I4 *vh, const I4 *vh2, const Dist *sk, int32_t u, int32_t so, int32_t n, int lane) {
+    p.u = u;
+    p.a = vh[u]; p.b = vh2[u];
+    FOR_LANE(t, (n < AASM_WAVE_MAX ? n : AASM_WAVE_MAX), lane) p.key.at(t) = sk[(int64_t)so + t];
+}
+
+struct KProfNone {};
 AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
@@ -1382,84 +1437,89 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     const int64_t vb = w.voff[c];
     int32_t *h = w.h_root + vb, *q = w.bq + vb;
     const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
-    HNode *nodes = w.hnodes + w.hoff[c];
-    const int32_t cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
+    const Dist *sk = w.st_cost + w.rowptr[vb];                      // the contig's compacted sidetrack keys (kb_sidetrack)
+    HeapState hs;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.L = L; hs.alloc = 0; hs.flushed = 0; hs.ovf = false;
+    hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (k.lane == 0) w.h_cnt[c] = 0;
+    if (w.status[c] != 0) return;
     if (dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
-    int32_t alloc = 0, head = 0, tail = 1, lds_hi = 1;
+    int32_t head = 0, tail = 0, lds_hi = 0;                          // BFS queue positions; [head, lds_hi) live in the LDS window
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
-    bool ovf = false;
-    if (k.lane == 0) { q[0] = dest; h[dest] = -1; L->bqv[0] = dest; L->bqh[0] = -1; }
-    wave_lds_sync();
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     KPROF_DECL;
     KPROF_START();
-    // the header of the vertex popped next is in flight while the current one is worked on
-    int32_t pf_u = dest;
-    I4 pf_a = vh[dest], pf_b = vh2[dest];
-    while (head < tail && !ovf) {
-        int32_t u, hu;
-        if (head < lds_hi) { u = uni(L->bqv[head & (HEAP_QN - 1)]); hu = uni(L->bqh[head & (HEAP_QN - 1)]); }
-        else { wave_fence(); u = uni(q[head]); hu = uni(h[u]); }     // queue window overflow (wide trees)
-        head++;
-        I4 ha, hb;
-        if (u == pf_u) { ha = uni(pf_a); hb = uni(pf_b); }
-        else { ha = uni(vh[u]); hb = uni(vh2[u]); }
-        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)ha.y << 32) | (uint32_t)ha.x), r1 = r0 + ha.z;
-        const int32_t nch = ha.w, first_child = hb.x;
-        const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)hb.z << 32) | (uint32_t)hb.y);
-        // next pop: the queue front, or - the tree is path-like, the queue is mostly empty - this vertex's first child
-        {
-            int32_t nx = -1;
-            if (head < tail) { if (head < lds_hi) nx = uni(L->bqv[head & (HEAP_QN - 1)]); }
-            else if (nch > 0) nx = first_child;
-            if (nx >= 0) { pf_u = nx; pf_a = vh[nx]; pf_b = vh2[nx]; }
-        }
+    struct KP { int64_t &t0; int64_t *acc; } kp{kp_t0, kp_acc};
+#else
+    KProfNone kp;
+#endif
+    VPre nxt;
+    int32_t u = dest, hu = -1, so, n;                                // the vertex at hand: id, inherited heap, key offset, #keys
+    {   // the root of the SP tree: its header first, then its keys (the only vertex whose loads are not hidden)
+        const I4 a0 = vh[dest];
+        so = uni(a0.x); n = uni(a0.y);
+        vpre_load(nxt, vh, vh2, sk, dest, so, n, k.lane);
+    }
+    int32_t pend_u = -1, pend_root = -1;                             // finished root of the previous vertex (lane 0), stored at the start of the next step
+    while (!hs.ovf) {
+        VPre cur;
+        if (u == nxt.u) cur = nxt; else vpre_load(cur, vh, vh2, sk, u, so, n, k.lane);   // (not predicted: a spilled queue entry)
+        // ---- every global store of this step, ahead of its loads: the root of the vertex before, the staged nodes
+        if (pend_u >= 0) h[pend_u] = pend_root;                      // (lane 0 only: the pair lives in its vector registers)
+        if (hs.alloc - hs.flushed >= HEAP_RING / 2) heap_flush(hs, k.lane);
+        // ---- the vertex after this one: the queue front, or - the queue is empty, the tree path-like - the first child
+        nxt.u = -1;
+        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; vpre_load(nxt, vh, vh2, sk, uni(e.x), uni(e.z), uni(e.w), k.lane); } }
+        else if (uni(cur.a.z) > 0) vpre_load(nxt, vh, vh2, sk, uni(cur.a.w), uni(cur.b.z), uni(cur.b.w), k.lane);
         KPROF_STAMP(0);                                              // vertex header
-        for (int64_t base = r0; hb.w > 0 && base < r1 && !ovf; base += AASM_WAVE) {     // (a vertex without sidetracks does not touch its row)
-            const int64_t e = base + k.lane;
-            bool valid = false;
-            if (e < r1 && w.st_fl[e]) {
-                valid = true;
-                L->cbuf[k.lane] = w.st_cost[e];
-                L->vbuf[k.lane] = w.e_col[e];
+        // ---- inserts in list order (:202-211)
+        for (int32_t base = 0; base < n && !hs.ovf; base += AASM_WAVE_MAX) {
+            const int32_t m = (n - base < AASM_WAVE_MAX) ? (n - base) : AASM_WAVE_MAX;
+            if (base > 0) { FOR_LANE(t, m, k.lane) cur.key.at(t) = sk[(int64_t)so + base + t]; }   // rows with more than 64 sidetracks (dense graphs)
+            for (int32_t t = 0; t < m && !hs.ovf; t++) {
+                const Dist cc = la_get_dist(cur.key, t);
+                hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
             }
-            wave_lds_sync();                                         // cbuf/vbuf visible to every lane
-            KPROF_STAMP(1);                                          // row chunk loads
-            uint64_t vm = wave_ballot(valid);
-            while (vm && !ovf) {                                     // inserts in list order
-                const int t = ffs64(vm) - 1;
-                vm &= vm - 1;
-                const Dist cc = L->cbuf[t];                          // same in every lane; only ever compared / stored by vector code
-                hu = heap_insert(nodes, L, sp, alloc, cap, hu, cc, u, uni(L->vbuf[t]), ovf, k.lane HI_PROF_PASS);
-            }
-            wave_lds_sync();                                         // before the next chunk overwrites cbuf
             KPROF_STAMP(2);                                          // inserts
         }
-        if (k.lane == 0) h[u] = hu;
-        // children adopt the heap (:213); they enter the LDS queue window while it has room
-        int32_t ncache = 0;
-        if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
-        if (nch == 1) {
-            if (k.lane == 0) {
-                h[first_child] = hu; q[tail] = first_child;
-                if (ncache) { L->bqv[tail & (HEAP_QN - 1)] = first_child; L->bqh[tail & (HEAP_QN - 1)] = hu; }
-            }
-        } else {
-            for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
-                const int32_t ch = w.cval[c0 + t];
-                h[ch] = hu; q[tail + t] = ch;
-                if (t < ncache) { L->bqv[(tail + t) & (HEAP_QN - 1)] = ch; L->bqh[(tail + t) & (HEAP_QN - 1)] = hu; }
-            }
+        pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
+        // ---- children adopt the heap (:213)
+        const int32_t nch = uni(cur.a.z);
+        if (nch == 1 && head == tail) {                              // path-like tree: the only child is next, no queue traffic
+            u = uni(cur.a.w); so = uni(cur.b.z); n = uni(cur.b.w);
+            continue;
         }
-        lds_hi += ncache;
-        tail += nch;
-        wave_lds_sync();
+        if (nch > 0) {                                               // they enter the LDS queue window while it has room
+            int32_t ncache = 0;
+            if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
+            const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)uni(cur.b.y) << 32) | (uint32_t)uni(cur.b.x));
+            for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
+                const I4 ci = w.cinfo[c0 + t];
+                if (t < ncache) { I4 e; e.x = ci.x; e.y = hu; e.z = ci.y; e.w = ci.z; L->bq[(tail + t) & (HEAP_QN - 1)] = e; }
+                else { h[ci.x] = hu; q[tail + t] = ci.x; }           // window full: spill (wide trees)
+            }
+            lds_hi += ncache;
+            tail += nch;
+            wave_lds_sync();
+        }
         KPROF_STAMP(3);                                              // children
+        // ---- pop
+        if (head >= tail) break;
+        if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
+        else {                                                       // spilled entry (the window was full when it was pushed)
+            wave_fence();
+            u = uni(q[head]); hu = uni(h[u]);
+            const I4 a0 = vh[u]; so = uni(a0.x); n = uni(a0.y);
+        }
+        head++;
+        if (head >= lds_hi && head == tail) lds_hi = tail;           // spill drained: new entries go to the window again
     }
+    if (pend_u >= 0) h[pend_u] = pend_root;
+    heap_flush(hs, k.lane);
     KPROF_FLUSH(w.prof_heap, c, k.lane);
-    if (ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
-    if (k.lane == 0) { w.h_cnt[c] = alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)alloc); }
+    if (hs.ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
+    if (k.lane == 0) { w.h_cnt[c] = hs.alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)hs.alloc); }
 }
 
 // ====================================================================================
