@@ -91,8 +91,9 @@ AASM_DEV int ffs64(uint64_t m) { return __ffsll((long long)m); }
 // product build compiles these to nothing.
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
 #define KPROF_DECL int64_t kp_t0 = 0, kp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define KPROF_START() do { __builtin_amdgcn_s_waitcnt(0); kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); } while (0)
-#define KPROF_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const int64_t kp_t1 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); kp_acc[i] += kp_t1 - kp_t0; kp_t0 = kp_t1; } while (0)
+#define KPROF_START() do { kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); } while (0)
+// light stamp: no drain of outstanding memory operations (a drain would itself expose every prefetch)
+#define KPROF_STAMP(i) do { const int64_t kp_t1 = (int64_t)__builtin_amdgcn_s_memtime(); kp_acc[i] += kp_t1 - kp_t0; kp_t0 = kp_t1; } while (0)
 #define KPROF_FLUSH(ptr, c, lane) do { if ((ptr) && (lane) == 0) for (int kp_i = 0; kp_i < 8; kp_i++) (ptr)[(c) * 8 + kp_i] = kp_acc[kp_i]; } while (0)
 #else
 #define KPROF_DECL

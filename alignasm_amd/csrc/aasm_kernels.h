@@ -1269,7 +1269,11 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 //    the finished root of the vertex before.  vmcnt counts loads and stores in issue order, so a load waits
 //    for every older store: with all stores issued ahead of the prefetch loads of a vertex, waiting for those
 //    loads one vertex later costs nothing extra;
-//  * fetches the next vertex's header and sidetrack keys one vertex ahead (kb_heap_hdr).
+//  * fetches the next vertex's header and sidetrack keys one vertex ahead (kb_heap_hdr makes it predictable):
+//    the loads are issued right after the step's stores and their registers are only touched again at the END
+//    of the step, where they are parked in an LDS slot.  (Loads whose results are carried to
+//    the next loop iteration in registers do not survive the compiler: it copies them at the loop edge and
+//    waits for them on the spot - measured: 1 500-2 000 of 4 100 cycles per vertex.)
 //   spine (registers)  80-96 % of the inserts continue from exactly the heap the last insert made, and an
 //                 insert's descent path is a prefix of its right spine.  A rank swap at position t sends the
 //                 new spine into an old left subtree: the cache then holds positions 0..t plus the node where
@@ -1280,10 +1284,14 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 //                 window spill to global memory (wide trees)
 #define HEAP_RING 64
 #define HEAP_QN 128
-#define AASM_HEAP_LDS_BYTES 5120
+#define HEAP_KMAX 16                      // sidetrack keys of a vertex that travel through the staging slot
+#define AASM_HEAP_LDS_BYTES 5696
+struct HeapStage { I4 a, b; Dist key[HEAP_KMAX]; };   // kb_heap_hdr's two header words + the first keys of one vertex
 struct HeapLds {
     HNode ring[HEAP_RING];
     I4 bq[HEAP_QN];
+    HeapStage stage;                      // context of the vertex popped next, parked here at the end of a step
+    int32_t tag;                          // ... and whose it is (-1: none)
 };
 static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
 struct Spine {
@@ -1420,14 +1428,6 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
     return sp.root;
 }
 
-// header + this lane's sidetrack key of one vertex, fetched one vertex ahead
-struct VPre { int32_t u; I4 a, b; LaneArr<Dist> key; };
-AASM_DEV void vpre_load(VPre &p, const I4 *vh, const I4 *vh2, const Dist *sk, int32_t u, int32_t so, int32_t n, int lane) {
-    p.u = u;
-    p.a = vh[u]; p.b = vh2[u];
-    FOR_LANE(t, (n < AASM_WAVE_MAX ? n : AASM_WAVE_MAX), lane) p.key.at(t) = sk[(int64_t)so + t];
-}
-
 struct KProfNone {};
 AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
     const int64_t c = k.bid;
@@ -1454,46 +1454,71 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 #else
     KProfNone kp;
 #endif
-    VPre nxt;
     int32_t u = dest, hu = -1, so, n;                                // the vertex at hand: id, inherited heap, key offset, #keys
-    {   // the root of the SP tree: its header first, then its keys (the only vertex whose loads are not hidden)
+    {
         const I4 a0 = vh[dest];
         so = uni(a0.x); n = uni(a0.y);
-        vpre_load(nxt, vh, vh2, sk, dest, so, n, k.lane);
+        if (k.lane == 0) L->tag = -1;
     }
+    wave_lds_sync();
     int32_t pend_u = -1, pend_root = -1;                             // finished root of the previous vertex (lane 0), stored at the start of the next step
     while (!hs.ovf) {
-        VPre cur;
-        if (u == nxt.u) cur = nxt; else vpre_load(cur, vh, vh2, sk, u, so, n, k.lane);   // (not predicted: a spilled queue entry)
+        HeapStage *S = &L->stage;
+        if (uni(L->tag) != u) {                                      // not staged (the root, a spilled queue entry): fetch now
+            const I4 ha = vh[u], hb = vh2[u];
+            LaneArr<Dist> kk;
+            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) kk.at(t) = sk[(int64_t)so + t];
+            if (k.lane == 0) { S->a = ha; S->b = hb; }
+            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) S->key[t] = kk.at(t);
+            wave_lds_sync();
+        }
+        const I4 ca = S->a, cb = S->b;
+        const int32_t nch = uni(ca.z), fc = uni(ca.w), so_fc = uni(cb.z), n_fc = uni(cb.w);
+        KPROF_STAMP(0);                                              // context of this vertex
         // ---- every global store of this step, ahead of its loads: the root of the vertex before, the staged nodes
         if (pend_u >= 0) h[pend_u] = pend_root;                      // (lane 0 only: the pair lives in its vector registers)
         if (hs.alloc - hs.flushed >= HEAP_RING / 2) heap_flush(hs, k.lane);
+        KPROF_STAMP(1);                                              // stores
         // ---- the vertex after this one: the queue front, or - the queue is empty, the tree path-like - the first child
-        nxt.u = -1;
-        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; vpre_load(nxt, vh, vh2, sk, uni(e.x), uni(e.z), uni(e.w), k.lane); } }
-        else if (uni(cur.a.z) > 0) vpre_load(nxt, vh, vh2, sk, uni(cur.a.w), uni(cur.b.z), uni(cur.b.w), k.lane);
-        KPROF_STAMP(0);                                              // vertex header
-        // ---- inserts in list order (:202-211)
-        for (int32_t base = 0; base < n && !hs.ovf; base += AASM_WAVE_MAX) {
-            const int32_t m = (n - base < AASM_WAVE_MAX) ? (n - base) : AASM_WAVE_MAX;
-            if (base > 0) { FOR_LANE(t, m, k.lane) cur.key.at(t) = sk[(int64_t)so + base + t]; }   // rows with more than 64 sidetracks (dense graphs)
-            for (int32_t t = 0; t < m && !hs.ovf; t++) {
-                const Dist cc = la_get_dist(cur.key, t);
-                hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
-            }
-            KPROF_STAMP(2);                                          // inserts
+        int32_t v2 = -1, so2 = 0, n2 = 0;
+        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; v2 = uni(e.x); so2 = uni(e.z); n2 = uni(e.w); } }
+        else if (nch > 0) { v2 = fc; so2 = so_fc; n2 = n_fc; }
+        I4 pa, pb;
+        LaneArr<Dist> pk;
+        pa.x = pa.y = pa.z = pa.w = 0; pb = pa;
+#if !defined(AASM_HOST_EMUL)
+        pk.r = dist_zero();
+#endif
+        if (v2 >= 0) {
+            pa = vh[v2]; pb = vh2[v2];
+            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) pk.at(t) = sk[(int64_t)so2 + t];
         }
+        KPROF_STAMP(2);                                              // prefetch issue
+        // ---- inserts in list order (:202-211)
+        for (int32_t t = 0; t < n && !hs.ovf; t++) {
+            Dist cc;
+            if (t < HEAP_KMAX) cc = S->key[t];
+            else cc = sk[(int64_t)so + t];                           // rows with more sidetracks than a slot holds (dense graphs)
+            hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
+        }
+        KPROF_STAMP(3);                                              // inserts
         pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
+        // ---- park the prefetched context (its loads had the whole step; this vertex's keys are used up)
+        if (v2 >= 0) {
+            if (k.lane == 0) { S->a = pa; S->b = pb; }
+            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) S->key[t] = pk.at(t);
+        }
+        if (k.lane == 0) L->tag = v2;
         // ---- children adopt the heap (:213)
-        const int32_t nch = uni(cur.a.z);
         if (nch == 1 && head == tail) {                              // path-like tree: the only child is next, no queue traffic
-            u = uni(cur.a.w); so = uni(cur.b.z); n = uni(cur.b.w);
+            u = fc; so = so_fc; n = n_fc;
+            wave_lds_sync();
             continue;
         }
         if (nch > 0) {                                               // they enter the LDS queue window while it has room
             int32_t ncache = 0;
             if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
-            const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)uni(cur.b.y) << 32) | (uint32_t)uni(cur.b.x));
+            const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)uni(cb.y) << 32) | (uint32_t)uni(cb.x));
             for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
                 const I4 ci = w.cinfo[c0 + t];
                 if (t < ncache) { I4 e; e.x = ci.x; e.y = hu; e.z = ci.y; e.w = ci.z; L->bq[(tail + t) & (HEAP_QN - 1)] = e; }
@@ -1501,9 +1526,9 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
             }
             lds_hi += ncache;
             tail += nch;
-            wave_lds_sync();
         }
-        KPROF_STAMP(3);                                              // children
+        wave_lds_sync();
+        KPROF_STAMP(4);                                              // children
         // ---- pop
         if (head >= tail) break;
         if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
@@ -1514,6 +1539,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         }
         head++;
         if (head >= lds_hi && head == tail) lds_hi = tail;           // spill drained: new entries go to the window again
+        KPROF_STAMP(5);                                              // pop
     }
     if (pend_u >= 0) h[pend_u] = pend_root;
     heap_flush(hs, k.lane);

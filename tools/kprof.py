@@ -1,7 +1,7 @@
 """Diagnostic: per-section cycle sums of aasm_k7_heap / aasm_k9_select (needs the -DAASM_KPROF build)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["AASM_LIB_OVERRIDE"] = os.path.join(ROOT, "alignasm_amd", "libalignasm_amd_kprof.so")
+os.environ["AASM_LIB_OVERRIDE"] = os.environ.get("AASM_KPROF_LIB") or os.path.join(ROOT, "alignasm_amd", "libalignasm_amd_kprof.so")
 sys.path.insert(0, ROOT)
 import numpy as np, alignasm_amd as A
 nc, nr, K, dense, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
