@@ -124,11 +124,13 @@ AASM_DEV bool uni(bool x) { return uni((int32_t)x) != 0; }
 #if defined(AASM_HOST_EMUL)
 template <class T> struct LaneArr { T a[AASM_WAVE_MAX]; AASM_MEM T &at(int j) { return a[j]; } };
 #define FOR_LANE(j, n, lane) for (int j = 0; j < (n); j++)
+#define FOR_LANE_EQ(j, jj, lane) for (int j = (jj), _fe_once = 1; _fe_once; _fe_once = 0)
 #define LA_GET(arr, j, field) ((arr).a[j] field)
 #define LA_SET(arr, j, lane, value) ((arr).a[j] = (value))
 #else
 template <class T> struct LaneArr { T r; AASM_MEM T &at(int) { return r; } };
 #define FOR_LANE(j, n, lane) for (int j = (lane), _fl_once = 1; _fl_once && j < (n); _fl_once = 0)
+#define FOR_LANE_EQ(j, jj, lane) for (int j = (lane), _fe_once = 1; _fe_once && j == (jj); _fe_once = 0)   // element jj alone (lane jj)
 #define LA_GET(arr, j, field) __builtin_amdgcn_readlane((arr).r field, (j))
 #define LA_SET(arr, j, lane, value) do { if ((lane) == (j)) (arr).r = (value); } while (0)
 #endif

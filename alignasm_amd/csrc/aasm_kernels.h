@@ -1354,19 +1354,22 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         int32_t a = sp.tail;
         if (a >= 0) wave_lds_sync();                                                // ring writes of earlier inserts before the ring reads
         while (a >= 0) {
-            // the node is the same in every lane; the 64-bit key compare stays on the vector unit and only its
-            // outcome, the rank and the right pointer become scalars
-            const NodeQ n = heap_read(hs, a);
-#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-            kp.acc[(a >= hs.alloc - HEAP_RING) ? 7 : 6] += 1;                      // diagnostic: chase steps served by the ring / by global memory
-#endif
-            if (!uni(nodeq_key_lt(n, key, ksum))) { a_rank = uni(n.q1.w) & 0xff; break; }
+            // the chased node goes straight into the registers of the lane that will cache it (lane `depth`):
+            // one lane loads, compares and keeps it; only the outcome and the right pointer become scalars
             if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
-            LA_SET(sp.n, depth, lane, n);
-            LA_SET(sp.idx, depth, lane, a);
-            LA_SET(sp.sum, depth, lane, nodeq_key(n).qry + nodeq_key(n).ref);
+            bool lt = false;
+            FOR_LANE_EQ(j, depth, lane) {
+                const NodeQ n = heap_read(hs, a);
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+                kp.acc[(a >= hs.alloc - HEAP_RING) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
+#endif
+                const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
+                sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum;
+                lt = (nsum < ksum) | ((nsum == ksum) & key_tie_lt(n, key));
+            }
+            if (!wave_ballot(lt)) { a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; break; }   // the stop node (its copy in lane `depth` is overwritten by the new leaf)
+            a = LA_GET(sp.n, depth, .q2.y);                                         // ->right
             depth++;
-            a = uni(n.q2.y);                                                        // ->right
         }
         a_stop = a;
     }
