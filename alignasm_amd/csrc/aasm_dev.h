@@ -308,14 +308,6 @@ AASM_DEV Dist hnode_key(const HNode &n) {
     Dist d; d.qry = n.kq; d.ref = n.kr; d.anom = n.ka; d.qnz = n.kn; d.qtot = n.kt; d.pad = 0; return d;
 }
 
-// priority-queue entry of the k-walk enumeration (k_shortest_walks.hpp:231), 48 bytes
-struct __attribute__((aligned(16))) PQEnt {
-    Dist d;
-    int32_t node;                   // heap node (arena index; stands in for the pointer)
-    int32_t cur;                    // insertion index into `nodes`
-    int32_t pad0, pad1;
-};
-
 // one output element, same layout as aasm_out_elem (include/alignasm_amd.h)
 struct OutElem {
     int64_t qs, qe, rs, re;

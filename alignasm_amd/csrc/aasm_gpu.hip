@@ -64,7 +64,7 @@ AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
 AASM_DEF_KERNEL(aasm_k7_sidetrack, KN_SIDETRACK, 256)
 AASM_DEF_KERNEL(aasm_k7_heap_hdr, KN_HEAP_HDR, 256)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
-AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_LDS_BYTES, 5)
+AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_ENUM_LDS_BYTES, 2)
 AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
 AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
@@ -78,7 +78,7 @@ AASM_DEF_KERNEL(aasm_k9_gather_out, KN_GATHER_OUT, 64)
 // One thread per pair (a, b) of 5-int64 PafDistance tuples {qry, ref, anom, qul_nonzero, qul_total}.
 // out bit 0: dist_lt<CALC_SUM>(a, b)   bit 1: dist_lt<QRY_SCORE>(a, b)   bit 2: dist_eq(a, b)
 //     bit 3: nodeq_key_lt (heap node holding key a, against key b; K7's descent test)
-//     bit 4: pqkey_less (a, b as priority-queue entries with equal node / insertion index; K8)
+//     bit 4: pq_full_less (a, b as priority-queue candidates with equal node / insertion index; K8)
 __global__ void __launch_bounds__(256) aasm_t1_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t *out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -90,15 +90,12 @@ __global__ void __launch_bounds__(256) aasm_t1_predicates(const int64_t *a, cons
     nd.q0.z = (int32_t)(uint32_t)(uint64_t)x.ref; nd.q0.w = (int32_t)((uint64_t)x.ref >> 32);
     nd.q1.x = x.anom; nd.q1.y = x.qnz; nd.q1.z = x.qtot; nd.q1.w = 1;
     nd.q2.x = nd.q2.y = -1; nd.q2.z = nd.q2.w = 0;
-    PQEnt ea, eb;
-    ea.d = x; ea.node = 7; ea.cur = 3; ea.pad0 = ea.pad1 = 0;
-    eb.d = y; eb.node = 7; eb.cur = 3; eb.pad0 = eb.pad1 = 0;
     uint8_t r = 0;
     r |= dist_lt<CALC_SUM_MODE>(x, y) ? 1 : 0;
     r |= dist_lt<QRY_SCORE_MODE>(x, y) ? 2 : 0;
     r |= dist_eq(x, y) ? 4 : 0;
     r |= nodeq_key_lt(nd, y, y.qry + y.ref) ? 8 : 0;
-    r |= pqkey_less(pqkey_of(ea, 0), pqkey_of(eb, 0)) ? 16 : 0;
+    r |= pq_full_less(x, 7, 3, y, 7, 3) ? 16 : 0;
     out[i] = r;
 }
 

@@ -21,6 +21,7 @@
 
 namespace aasm {
 
+struct PqK;
 struct WS {
     // ---- sizes / options
     int64_t C, R, R0, S, VT, ET;
@@ -69,7 +70,8 @@ struct WS {
     // ---- enumeration
     Dist *kd;
     int32_t *klast, *knodes, *kprev, *kfound;
-    PQEnt *pq;
+    PqK *pq;                             // K8: 8-ary heap of 32-byte keys, 3K + 1 per contig
+    int64_t *kcq;                        // K8: qry_score of every candidate, by insertion index
     // ---- selection / outputs
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;    // (u,v) pairs, 2*(N+2) ints per contig
     Dist *dist2;
@@ -1559,21 +1561,30 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 // tuple order is total and any correct min-queue pops the same sequence.  The pointer is
 // replaced by the arena index (DESIGN.md "hazard B3").
 //
-// The queue is a wave-cooperative 8-ARY heap: the children of a node are 8 consecutive
-// 48-byte entries, fetched by 8 lanes in one coalesced load and min-reduced by a 3-step
-// butterfly, so a pop descends log8(n) levels (6 for the 30 001 entries of K = 10 000) instead
-// of log2(n) = 15 pointer-dependent steps; its top three levels (1 + 8 + 64 entries) live in LDS.
-#define PQ8_LDS_N 73
-struct PqKey { int64_t sum; int32_t anom, qnz, qtot, node, cur, slot, valid; };
-AASM_DEV PqKey pqkey_of(const PQEnt &e, int32_t slot) {
-    PqKey k; k.sum = e.d.qry + e.d.ref; k.anom = e.d.anom; k.qnz = e.d.qnz; k.qtot = e.d.qtot; k.node = e.node; k.cur = e.cur; k.slot = slot; k.valid = 1;
-    return k;
+// The queue is a wave-cooperative 8-ARY heap of 32-byte keys {score sum, anom, qul_nonzero, qul_total, heap
+// node, insertion index}: everything the order needs (the query / reference split of the score is not part of
+// it and waits in a side array, kcq, until the candidate is popped).  The 8 children of a heap node are 256
+// contiguous bytes, fetched by 8 lanes in one pass and min-reduced on the score sum by three DPP steps inside
+// the 8 lanes - equal sums are settled by a short scalar loop over the tied lanes - so a pop descends log8(n)
+// levels (6 for the 30 001 entries of K = 10 000) instead of log2(n) = 15; the top four levels (1 + 8 + 64 +
+// 512 entries, 18 KB) live in LDS.  (First version: 48-byte entries, three levels in LDS, an 8-field shuffle
+// butterfly per level: 9 us per pop at K = 10 000.)
+#define PQ8_LDS_N 585
+#define AASM_ENUM_LDS_BYTES (PQ8_LDS_N * 32 + 32)
+struct __attribute__((aligned(16))) PqK { int64_t sum; int32_t anom, qnz, qtot, node, cur, pad; };
+// std::tuple order of (Distance, node, cur) for distances of real walks (never max(), all components >= 0):
+// paf_data.hpp:142-159 then node index then insertion index
+AASM_DEV bool pq_full_less(const Dist &a, int32_t a_node, int32_t a_cur, const Dist &b, int32_t b_node, int32_t b_cur) {
+    const int64_t sa = a.qry + a.ref, sb = b.qry + b.ref;
+    if (sa != sb) return sa < sb;
+    if (a.anom != b.anom) return a.anom < b.anom;
+    const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
+    const int64_t l = (int64_t)a.qnz * (int64_t)tb, r = (int64_t)b.qnz * (int64_t)ta;
+    if (l != r) return l > r;
+    if (a_node != b_node) return a_node < b_node;
+    return a_cur < b_cur;
 }
-// std::tuple order of (Distance, node, cur) for distances of real walks (never max(), all
-// components >= 0): paf_data.hpp:142-159 then node index then insertion index.  invalid = +inf.
-AASM_DEV bool pqkey_less(const PqKey &a, const PqKey &b) {
-    if (!b.valid) return a.valid != 0;
-    if (!a.valid) return false;
+AASM_DEV bool pqk_less(const PqK &a, const PqK &b) {                 // the same order on heap keys
     if (a.sum != b.sum) return a.sum < b.sum;
     if (a.anom != b.anom) return a.anom < b.anom;
     const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
@@ -1582,75 +1593,95 @@ AASM_DEV bool pqkey_less(const PqKey &a, const PqKey &b) {
     if (a.node != b.node) return a.node < b.node;
     return a.cur < b.cur;
 }
-AASM_DEV PqKey pqkey_shfl_xor(const PqKey &k, int m) {
-    PqKey o; o.sum = wave_shfl_xor(k.sum, m); o.anom = wave_shfl_xor(k.anom, m); o.qnz = wave_shfl_xor(k.qnz, m); o.qtot = wave_shfl_xor(k.qtot, m);
-    o.node = wave_shfl_xor(k.node, m); o.cur = wave_shfl_xor(k.cur, m); o.slot = wave_shfl_xor(k.slot, m); o.valid = wave_shfl_xor(k.valid, m);
-    return o;
-}
-struct Pq8 { PQEnt *g, *l; int32_t n; int32_t pc_idx; PQEnt pc_ent; };   // pc_*: last parent read by a push
-AASM_DEV PQEnt pq8_get(const Pq8 &q, int32_t i) {
-    PQEnt e;
+struct Pq8 { PqK *g, *l; int32_t n; int32_t pc_idx; PqK pc; };      // pc*: last parent read by a push
+AASM_DEV PqK pq8_get(const Pq8 &q, int32_t i) {
+    PqK e;
     if (i < PQ8_LDS_N) e = q.l[i];
     else { e = q.g[i]; asm volatile("" ::: "memory"); }              // keep LDS and global reads apart (no flat access)
     return e;
 }
-AASM_DEV void pq8_set(Pq8 &q, int32_t i, const PQEnt &e, int lane) {
+AASM_DEV void pq8_set(Pq8 &q, int32_t i, const PqK &e, int lane) {
     if (lane == 0) { if (i < PQ8_LDS_N) q.l[i] = e; else q.g[i] = e; }
     if (i == q.pc_idx) q.pc_idx = -1;
 }
-AASM_DEV PQEnt pqent_bcast(const PQEnt &e, int src) {
-    PQEnt o;
-    o.d.qry = wave_bcast(e.d.qry, src); o.d.ref = wave_bcast(e.d.ref, src); o.d.anom = wave_bcast(e.d.anom, src); o.d.qnz = wave_bcast(e.d.qnz, src);
-    o.d.qtot = wave_bcast(e.d.qtot, src); o.d.pad = 0; o.node = wave_bcast(e.node, src); o.cur = wave_bcast(e.cur, src); o.pad0 = o.pad1 = 0;
-    return o;
+AASM_DEV PqK pqk_uni(const PqK &k) { PqK r; r.sum = uni(k.sum); r.anom = uni(k.anom); r.qnz = uni(k.qnz); r.qtot = uni(k.qtot); r.node = uni(k.node); r.cur = uni(k.cur); r.pad = 0; return r; }
+#if !defined(AASM_HOST_EMUL)
+AASM_DEV PqK pqk_lane(const PqK &k, int j) {                         // the key lane j holds (wave-uniform j)
+    PqK r;
+    r.sum = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)k.sum >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)k.sum, j));
+    r.anom = __builtin_amdgcn_readlane(k.anom, j); r.qnz = __builtin_amdgcn_readlane(k.qnz, j); r.qtot = __builtin_amdgcn_readlane(k.qtot, j);
+    r.node = __builtin_amdgcn_readlane(k.node, j); r.cur = __builtin_amdgcn_readlane(k.cur, j); r.pad = 0;
+    return r;
 }
-AASM_DEV void pq8_push(Pq8 &q, const PQEnt &x, int lane) {
+#endif
+AASM_DEV void pq8_push(Pq8 &q, const PqK &x, int lane) {
     int32_t i = q.n++;
-    const PqKey xk = pqkey_of(x, 0);
     while (i > 0) {
         const int32_t p = (i - 1) >> 3;
         // the <= 3 pushes of one iteration land side by side and almost always share a parent
-        if (p != q.pc_idx) { q.pc_ent = pq8_get(q, p); q.pc_idx = p; }
-        const PQEnt pe = q.pc_ent;
-        if (!uni(pqkey_less(xk, pqkey_of(pe, 0)))) break;
+        if (p != q.pc_idx) { q.pc = pqk_uni(pq8_get(q, p)); q.pc_idx = p; }
+        const PqK pe = q.pc;
+        if (!pqk_less(x, pe)) break;
         pq8_set(q, i, pe, lane);
         i = p;
     }
     pq8_set(q, i, x, lane);
     wave_lds_sync();
 }
-AASM_DEV PQEnt pq8_pop(Pq8 &q, int lane) {
-    const PQEnt top = pq8_get(q, 0);
-    const PQEnt x = pq8_get(q, --q.n);
-    q.pc_idx = -1;
-    if (q.n == 0) return top;
-    const PqKey xk = pqkey_of(x, 0);
+#if !defined(AASM_HOST_EMUL)
+// the same order, branch-free, for keys held one per lane (the distance sums tie all the time: the K best walks of
+// a contig spread over a few dozen distinct sums, so every field of the order is in play)
+AASM_DEV bool pqk_less_v(const PqK &a, const PqK &b) {
+    const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
+    const int64_t l = (int64_t)a.qnz * (int64_t)tb, r = (int64_t)b.qnz * (int64_t)ta;
+    const int64_t ia = (int64_t)(((uint64_t)(uint32_t)a.node << 32) | (uint32_t)a.cur), ib = (int64_t)(((uint64_t)(uint32_t)b.node << 32) | (uint32_t)b.cur);
+    return (a.sum < b.sum) | ((a.sum == b.sum) & ((a.anom < b.anom) | ((a.anom == b.anom) & ((l > r) | ((l == r) & (ia < ib))))));
+}
+template <int CTRL> AASM_DEV int32_t dpp_mov(int32_t x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> AASM_DEV void pqk_min_step(PqK &k, int32_t &slot) {    // k <- min(k, partner's k) inside a group of 8 lanes
+    PqK o;
+    o.sum = (int64_t)(((uint64_t)(uint32_t)dpp_mov<CTRL>((int)((uint64_t)k.sum >> 32)) << 32) | (uint32_t)dpp_mov<CTRL>((int)(uint32_t)(uint64_t)k.sum));
+    o.anom = dpp_mov<CTRL>(k.anom); o.qnz = dpp_mov<CTRL>(k.qnz); o.qtot = dpp_mov<CTRL>(k.qtot); o.node = dpp_mov<CTRL>(k.node); o.cur = dpp_mov<CTRL>(k.cur); o.pad = 0;
+    const int32_t oslot = dpp_mov<CTRL>(slot);
+    const bool take = pqk_less_v(o, k);
+    k.sum = take ? o.sum : k.sum; k.anom = take ? o.anom : k.anom; k.qnz = take ? o.qnz : k.qnz; k.qtot = take ? o.qtot : k.qtot;
+    k.node = take ? o.node : k.node; k.cur = take ? o.cur : k.cur; slot = take ? oslot : slot;
+}
+#endif
+// x takes the place of the root and sinks to where it belongs
+AASM_DEV void pq8_sink_from_root(Pq8 &q, const PqK &x, int lane) {
     int32_t i = 0;
     while (true) {
         const int32_t c0 = 8 * i + 1;
         if (c0 >= q.n) break;
         const int32_t nchild = (q.n - c0 < 8) ? (q.n - c0) : 8;
-        PqKey best; best.valid = 0; best.sum = 0; best.anom = best.qnz = best.qtot = best.node = best.cur = best.slot = 0;
-        PQEnt mine = x;                                               // the child this lane fetched (lanes 0..7: one each)
-        for (int32_t j = lane; j < nchild; j += AASM_WAVE) {
-            const PQEnt e = pq8_get(q, c0 + j);
-            const PqKey kj = pqkey_of(e, j);
-            if (pqkey_less(kj, best)) { best = kj; mine = e; }
-        }
-        for (int m = 1; m < 8 && m < AASM_WAVE; m <<= 1) {            // butterfly min over lanes 0..7
-            const PqKey o = pqkey_shfl_xor(best, m);
-            if (pqkey_less(o, best)) best = o;
-        }
-        const int32_t bslot = uni(best.slot);
-        if (!uni(pqkey_less(best, xk))) break;
-        const PQEnt be = pqent_bcast(mine, AASM_WAVE > 1 ? bslot : 0);  // winner's entry straight from its lane
-        pq8_set(q, i, be, lane);
+        PqK best;                                                    // the smallest child, wave-uniform
+        int32_t bslot;
+#if defined(AASM_HOST_EMUL)
+        best = pq8_get(q, c0); bslot = 0;
+        for (int32_t j = 1; j < nchild; j++) { const PqK e = pq8_get(q, c0 + j); if (pqk_less(e, best)) { best = e; bslot = j; } }
+#else
+        PqK mine; mine.sum = INT64_MAX; mine.anom = mine.qnz = mine.qtot = mine.node = mine.cur = mine.pad = 0;
+        if (lane < nchild) mine = pq8_get(q, c0 + lane);             // (the children of one node are all in LDS or all in global memory)
+        int32_t slot = lane;
+        pqk_min_step<0xB1>(mine, slot);                              // quad_perm [1,0,3,2]
+        pqk_min_step<0x4E>(mine, slot);                              // quad_perm [2,3,0,1]
+        pqk_min_step<0x141>(mine, slot);                             // row_half_mirror: lane i <-> 7 - i
+        best = pqk_uni(mine); bslot = uni(slot);                     // lanes 0..7 all hold the smallest child now
+#endif
+        if (!pqk_less(best, x)) break;
+        pq8_set(q, i, best, lane);
         i = c0 + bslot;
         wave_lds_sync();
     }
     pq8_set(q, i, x, lane);
     wave_lds_sync();
-    return top;
+}
+AASM_DEV PqK pq8_top(const Pq8 &q) { return pqk_uni(pq8_get(q, 0)); }
+AASM_DEV void pq8_drop_top(Pq8 &q, int lane) {                      // the last entry replaces the root
+    const PqK x = pqk_uni(pq8_get(q, --q.n));
+    q.pc_idx = -1;
+    if (q.n > 0) pq8_sink_from_root(q, x, lane);
 }
 
 AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave per contig
@@ -1662,8 +1693,9 @@ AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave 
     const int64_t K = w.K;
     Dist *kd = w.kd + c * K;
     int32_t *klast = w.klast + c * K, *knodes = w.knodes + c * (3 * K + 1), *kprev = w.kprev + c * (3 * K + 1);
-    Pq8 q; q.g = w.pq + c * (3 * K + 1); q.l = (PQEnt *)k.lds; q.n = 0; q.pc_idx = -1;
-    static_assert(PQ8_LDS_N * sizeof(PQEnt) <= AASM_LDS_BYTES, "LDS budget");
+    int64_t *kcq = w.kcq + c * (3 * K + 1);                          // qry_score of candidate `cur` (the key carries the sum)
+    Pq8 q; q.g = w.pq + c * (3 * K + 1); q.l = (PqK *)k.lds; q.n = 0; q.pc_idx = -1;
+    static_assert(PQ8_LDS_N * sizeof(PqK) <= AASM_ENUM_LDS_BYTES, "LDS budget");
     const HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
@@ -1674,30 +1706,39 @@ AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave 
     found = 1;
     const int32_t hs = uni(h[src]);
     auto emplace = [&](const Dist &dd, int32_t hp, int32_t pre) {    // :232-237
-        PQEnt x; x.d = dd; x.node = hp; x.cur = nn; x.pad0 = x.pad1 = 0;
-        if (L0) { knodes[nn] = hp; kprev[nn] = pre; }
+        PqK x; x.sum = uni(dd.qry + dd.ref); x.anom = uni(dd.anom); x.qnz = uni(dd.qnz); x.qtot = uni(dd.qtot); x.node = hp; x.cur = nn; x.pad = 0;
+        if (L0) { knodes[nn] = hp; kprev[nn] = pre; kcq[nn] = dd.qry; }
         pq8_push(q, x, k.lane);
         nn++;
     };
+    KPROF_DECL;
+    KPROF_START();
     if (hs >= 0) {                                                  // :227-228
         emplace(dist_add(dsrc, hnode_key(nodes[hs])), hs, -1);       // :239
-        int32_t prev_of_top = -1;
         while (q.n > 0 && found < K) {                              // :240-248
-            const PQEnt top = pq8_pop(q, k.lane);
-            const int32_t tcur = uni(top.cur), tnode = uni(top.node);
-            const HNode ch = nodes[tnode];
-            if (L0) { kd[found] = top.d; klast[found] = tcur; }
-            found++;
+            KPROF_STAMP(3);                                          // pushes of the previous pop
+            const PqK top = pq8_top(q);
+            pq8_drop_top(q, k.lane);
+            KPROF_STAMP(0);                                          // pop
+            const int32_t tcur = top.cur, tnode = top.node;
             wave_fence();
-            prev_of_top = uni(kprev[tcur]);
+            Dist dtop; dtop.qry = uni(kcq[tcur]); dtop.ref = top.sum - dtop.qry; dtop.anom = top.anom; dtop.qnz = top.qnz; dtop.qtot = top.qtot; dtop.pad = 0;
+            const HNode ch = nodes[tnode];
+            const int32_t prev_of_top = uni(kprev[tcur]);
+            if (L0) { kd[found] = dtop; klast[found] = tcur; }
+            found++;
             const int32_t hv = uni(h[ch.v]);
-            if (hv >= 0) emplace(dist_add(top.d, hnode_key(nodes[hv])), hv, tcur);
             const Dist chk = hnode_key(ch);
             const int32_t cl = uni(ch.left), cr = uni(ch.right);
-            if (cl >= 0) emplace(dist_sub(dist_add(top.d, hnode_key(nodes[cl])), chk), cl, prev_of_top);
-            if (cr >= 0) emplace(dist_sub(dist_add(top.d, hnode_key(nodes[cr])), chk), cr, prev_of_top);
+            KPROF_STAMP(1);                                          // popped node + cross heap root
+            if (hv >= 0) emplace(dist_add(dtop, hnode_key(nodes[hv])), hv, tcur);
+            if (cl >= 0) emplace(dist_sub(dist_add(dtop, hnode_key(nodes[cl])), chk), cl, prev_of_top);
+            if (cr >= 0) emplace(dist_sub(dist_add(dtop, hnode_key(nodes[cr])), chk), cr, prev_of_top);
         }
     }
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    if (w.K >= 1000) KPROF_FLUSH(w.prof_heap, c, k.lane);            // diagnostic build: K8's sections replace K7's in the dump
+#endif
     if (L0) {
         w.kfound[c] = found;
         atomic_add(&w.counters[CNT_PATHS], (int64_t)found);

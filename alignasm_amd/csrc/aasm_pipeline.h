@@ -247,7 +247,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // ---- K8 enumeration
         const int64_t K = w.K;
         A(kd, Dist, C * K, "kd"); A(klast, int32_t, C * K, "klast");
-        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PQEnt, C * (3 * K + 1), "pq");
+        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PqK, C * (3 * K + 1), "pq"); A(kcq, int64_t, C * (3 * K + 1), "kcq");
         CHECK_ALLOC();
         be.phase_begin(AASM_PH_ENUM);
         be.launch(KN_ENUM, C, AASM_WAVE, w);

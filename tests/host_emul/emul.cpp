@@ -38,7 +38,7 @@ struct EmuBackend {
         for (int64_t b = 0; b < nblocks; b++) {
             // one logical thread per block slot: bodies index with bid*nthreads+tid
             for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {
-                alignas(16) static char lds[AASM_SORT_LDS_BYTES];
+                alignas(16) static char lds[AASM_SORT_LDS_BYTES > AASM_ENUM_LDS_BYTES ? AASM_SORT_LDS_BYTES : AASM_ENUM_LDS_BYTES];
                 static_assert(AASM_SEL_LDS_BYTES <= AASM_SORT_LDS_BYTES && AASM_HEAP_LDS_BYTES <= AASM_SORT_LDS_BYTES && AASM_LDS_BYTES <= AASM_SORT_LDS_BYTES, "emulation LDS");
                 KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0, lds};
                 run_kernel_body(kn, k, w);
