@@ -42,7 +42,7 @@ namespace aasm {
     }
 AASM_DEF_KERNEL(aasm_k0_cs_ranges, KN_CS_RANGES, 256)
 AASM_DEF_KERNEL_LDS(aasm_k1_sort, KN_SORT, 256, AASM_SORT_LDS_BYTES, 2)
-AASM_DEF_KERNEL(aasm_k1_sort_fix, KN_SORT_FIX, 64)
+AASM_DEF_KERNEL_LDS(aasm_k1_sort_fix, KN_SORT_FIX, 64, AASM_SORTFIX_LDS_BYTES, 1)
 AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)
 AASM_DEF_KERNEL(aasm_k2_ov_count, KN_OV_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k2_ov_merge, KN_OV_MERGE, 256)

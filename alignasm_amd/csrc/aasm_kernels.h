@@ -285,42 +285,83 @@ AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
     }
 }
 
-// ---- libstdc++ (GCC 11) std::sort replayed on an index array ------------------------
-struct KeyLess {
-    const int64_t *qs, *qe;
-    AASM_MEM bool operator()(int32_t x, int32_t y) const {
-        if (qs[x] != qs[y]) return qs[x] < qs[y];
-        return qe[x] < qe[y];
+// ---- libstdc++ (GCC 11) std::sort replayed (hazard B1) -------------------------------
+// The algorithm (bits/stl_algo.h: __introsort_loop, __unguarded_partition_pivot, __partial_sort as the
+// depth-limit fallback, __final_insertion_sort) written against an accessor, so that the same statements
+// run on an index array in global memory (contigs too long for LDS) and on (key, index) tuples in LDS.
+struct SortGlob {                        // elements are record indices; keys are looked up
+    int32_t *a; const int64_t *qs, *qe;
+    typedef int32_t E;
+    AASM_MEM E get(int64_t i) const { return a[i]; }
+    AASM_MEM void set(int64_t i, E v) const { a[i] = v; }
+    AASM_MEM bool lt(E x, E y) const { if (qs[x] != qs[y]) return qs[x] < qs[y]; return qe[x] < qe[y]; }
+    // first position >= lo whose element is not < pivot / last position <= hi whose element is not > pivot (a sentinel always exists)
+    AASM_MEM int64_t scan_up(int64_t lo, E pivot) const { while (lt(a[lo], pivot)) ++lo; return lo; }
+    AASM_MEM int64_t scan_down(int64_t hi, E pivot) const { while (lt(pivot, a[hi])) --hi; return hi; }
+};
+struct SortTuple { int64_t qs, qe; int32_t ix; };
+#define SF_MAX 1536                      // records of a contig that fit the LDS form (31 KB: five contigs per CU at a time)
+#define SF_QN 256
+#define SF_PAD 4                         // slack in front of and behind the elements (the partition scans read 4 at a time)
+struct SfLds { int64_t qs[SF_MAX + 2 * SF_PAD], qe[SF_MAX + 2 * SF_PAD]; int32_t ix[SF_MAX + 2 * SF_PAD]; int32_t qf[SF_QN], ql[SF_QN], qd[SF_QN]; int32_t qn, ovf; };
+#define AASM_SORTFIX_LDS_BYTES ((SF_MAX + 2 * SF_PAD) * 20 + SF_QN * 12 + 16)
+static_assert(sizeof(SfLds) <= AASM_SORTFIX_LDS_BYTES, "LDS budget");
+struct SortLdsAcc {                      // elements are (qry_str, qry_end, record index) tuples, moved as a whole
+    SfLds *L;
+    typedef SortTuple E;
+    AASM_MEM E get(int64_t i) const { E e; e.qs = L->qs[i]; e.qe = L->qe[i]; e.ix = L->ix[i]; return e; }   // (callers pass positions shifted by SF_PAD)
+    AASM_MEM void set(int64_t i, const E &v) const { L->qs[i] = v.qs; L->qe[i] = v.qe; L->ix[i] = v.ix; }
+    AASM_MEM bool lt(const E &x, const E &y) const { if (x.qs != y.qs) return x.qs < y.qs; return x.qe < y.qe; }
+    // the partition's two scans, four elements per LDS round trip (reading past the stop is harmless: the arrays
+    // carry 4 elements of slack at both ends of the LDS block)
+    AASM_MEM int64_t scan_up(int64_t lo, const E &pivot) const {
+        while (true) {
+            const int64_t q0 = L->qs[lo], q1 = L->qs[lo + 1], q2 = L->qs[lo + 2], q3 = L->qs[lo + 3];
+            if (!(q0 < pivot.qs || (q0 == pivot.qs && L->qe[lo] < pivot.qe))) return lo;
+            if (!(q1 < pivot.qs || (q1 == pivot.qs && L->qe[lo + 1] < pivot.qe))) return lo + 1;
+            if (!(q2 < pivot.qs || (q2 == pivot.qs && L->qe[lo + 2] < pivot.qe))) return lo + 2;
+            if (!(q3 < pivot.qs || (q3 == pivot.qs && L->qe[lo + 3] < pivot.qe))) return lo + 3;
+            lo += 4;
+        }
+    }
+    AASM_MEM int64_t scan_down(int64_t hi, const E &pivot) const {
+        while (true) {
+            const int64_t q0 = L->qs[hi], q1 = L->qs[hi - 1], q2 = L->qs[hi - 2], q3 = L->qs[hi - 3];
+            if (!(pivot.qs < q0 || (pivot.qs == q0 && pivot.qe < L->qe[hi]))) return hi;
+            if (!(pivot.qs < q1 || (pivot.qs == q1 && pivot.qe < L->qe[hi - 1]))) return hi - 1;
+            if (!(pivot.qs < q2 || (pivot.qs == q2 && pivot.qe < L->qe[hi - 2]))) return hi - 2;
+            if (!(pivot.qs < q3 || (pivot.qs == q3 && pivot.qe < L->qe[hi - 3]))) return hi - 3;
+            hi -= 4;
+        }
     }
 };
-AASM_DEV void ss_swap(int32_t *a, int64_t i, int64_t j) { int32_t t = a[i]; a[i] = a[j]; a[j] = t; }
-AASM_DEV void ss_push_heap(int32_t *f, int64_t hole, int64_t top, int32_t val, const KeyLess &lt) {
+template <class A> AASM_DEV void ss_swap(const A &a, int64_t i, int64_t j) { const typename A::E t = a.get(i); a.set(i, a.get(j)); a.set(j, t); }
+template <class A> AASM_DEV void ss_push_heap(const A &a, int64_t base, int64_t hole, int64_t top, typename A::E val) {
     int64_t parent = (hole - 1) / 2;
-    while (hole > top && lt(f[parent], val)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
-    f[hole] = val;
+    while (hole > top && a.lt(a.get(base + parent), val)) { a.set(base + hole, a.get(base + parent)); hole = parent; parent = (hole - 1) / 2; }
+    a.set(base + hole, val);
 }
-AASM_DEV void ss_adjust_heap(int32_t *f, int64_t hole, int64_t len, int32_t val, const KeyLess &lt) {
+template <class A> AASM_DEV void ss_adjust_heap(const A &a, int64_t base, int64_t hole, int64_t len, typename A::E val) {
     const int64_t top = hole;
     int64_t child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (lt(f[child], f[child - 1])) child--;
-        f[hole] = f[child];
+        if (a.lt(a.get(base + child), a.get(base + child - 1))) child--;
+        a.set(base + hole, a.get(base + child));
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        f[hole] = f[child - 1];
+        a.set(base + hole, a.get(base + child - 1));
         hole = child - 1;
     }
-    ss_push_heap(f, hole, top, val, lt);
+    ss_push_heap(a, base, hole, top, val);
 }
-AASM_DEV void ss_heapsort(int32_t *f, int64_t len, const KeyLess &lt) {   // __partial_sort(f, l, l)
+template <class A> AASM_DEV void ss_heapsort(const A &a, int64_t base, int64_t len) {   // __partial_sort(f, l, l)
     if (len >= 2) {
         int64_t parent = (len - 2) / 2;
         while (true) {
-            int32_t v = f[parent];
-            ss_adjust_heap(f, parent, len, v, lt);
+            ss_adjust_heap(a, base, parent, len, a.get(base + parent));
             if (parent == 0) break;
             parent--;
         }
@@ -328,28 +369,54 @@ AASM_DEV void ss_heapsort(int32_t *f, int64_t len, const KeyLess &lt) {   // __p
     int64_t last = len;
     while (last > 1) {
         --last;
-        int32_t v = f[last];
-        f[last] = f[0];
-        ss_adjust_heap(f, 0, last, v, lt);
+        const typename A::E v = a.get(base + last);
+        a.set(base + last, a.get(base));
+        ss_adjust_heap(a, base, 0, last, v);
     }
 }
-AASM_DEV void ss_unguarded_linear_insert(int32_t *a, int64_t last, const KeyLess &lt) {
-    int32_t val = a[last];
+template <class A> AASM_DEV void ss_unguarded_linear_insert(const A &a, int64_t last) {
+    const typename A::E val = a.get(last);
     int64_t next = last - 1;
-    while (lt(val, a[next])) { a[last] = a[next]; last = next; --next; }
-    a[last] = val;
+    while (a.lt(val, a.get(next))) { a.set(last, a.get(next)); last = next; --next; }
+    a.set(last, val);
 }
-AASM_DEV void ss_insertion_sort(int32_t *a, int64_t first, int64_t last, const KeyLess &lt) {
+template <class A> AASM_DEV void ss_insertion_sort(const A &a, int64_t first, int64_t last) {
     if (first == last) return;
     for (int64_t i = first + 1; i != last; ++i) {
-        if (lt(a[i], a[first])) {
-            int32_t val = a[i];
-            for (int64_t t = i; t > first; --t) a[t] = a[t - 1];
-            a[first] = val;
-        } else ss_unguarded_linear_insert(a, i, lt);
+        if (a.lt(a.get(i), a.get(first))) {
+            const typename A::E val = a.get(i);
+            for (int64_t t = i; t > first; --t) a.set(t, a.get(t - 1));
+            a.set(first, val);
+        } else ss_unguarded_linear_insert(a, i);
     }
 }
-AASM_DEV void ss_std_sort(int32_t *a, int64_t n, const KeyLess &lt, int depth_override) {
+// __unguarded_partition_pivot(first, last): median of three to `first`, Hoare partition around it; returns the cut
+template <class A> AASM_DEV int64_t ss_partition_pivot(const A &a, int64_t first, int64_t last) {
+    const int64_t mid = first + (last - first) / 2;
+    {   // __move_median_to_first(first, first+1, mid, last-1)
+        const int64_t pa = first + 1, pb = mid, pc = last - 1;
+        const typename A::E ea = a.get(pa), eb = a.get(pb), ec = a.get(pc);
+        if (a.lt(ea, eb)) {
+            if (a.lt(eb, ec)) ss_swap(a, first, pb);
+            else if (a.lt(ea, ec)) ss_swap(a, first, pc);
+            else ss_swap(a, first, pa);
+        } else if (a.lt(ea, ec)) ss_swap(a, first, pa);
+        else if (a.lt(eb, ec)) ss_swap(a, first, pc);
+        else ss_swap(a, first, pb);
+    }
+    const typename A::E pivot = a.get(first);                        // (it stays at `first` during the partition)
+    int64_t lo = first + 1, hi = last;
+    while (true) {                                                   // __unguarded_partition(first+1, last, first)
+        lo = a.scan_up(lo, pivot);
+        --hi;
+        hi = a.scan_down(hi, pivot);
+        if (!(lo < hi)) break;
+        ss_swap(a, lo, hi);
+        ++lo;
+    }
+    return lo;
+}
+template <class A> AASM_DEV void ss_std_sort(const A &a, int64_t n, int depth_override) {
     if (n <= 0) return;
     int lg = 0;
     for (int64_t t = n; t > 1; t >>= 1) lg++;
@@ -363,49 +430,89 @@ AASM_DEV void ss_std_sort(int32_t *a, int64_t n, const KeyLess &lt, int depth_ov
         int64_t first = st_first[sp], last = st_last[sp];
         int depth = st_depth[sp];
         while (last - first > 16) {
-            if (depth == 0) { ss_heapsort(a + first, last - first, lt); break; }
+            if (depth == 0) { ss_heapsort(a, first, last - first); break; }
             --depth;
-            // __unguarded_partition_pivot
-            const int64_t mid = first + (last - first) / 2;
-            {   // __move_median_to_first(first, first+1, mid, last-1)
-                const int64_t A = first + 1, B = mid, Cc = last - 1;
-                if (lt(a[A], a[B])) {
-                    if (lt(a[B], a[Cc])) ss_swap(a, first, B);
-                    else if (lt(a[A], a[Cc])) ss_swap(a, first, Cc);
-                    else ss_swap(a, first, A);
-                } else if (lt(a[A], a[Cc])) ss_swap(a, first, A);
-                else if (lt(a[B], a[Cc])) ss_swap(a, first, Cc);
-                else ss_swap(a, first, B);
-            }
-            int64_t lo = first + 1, hi = last;
-            while (true) {                       // __unguarded_partition(first+1, last, first)
-                while (lt(a[lo], a[first])) ++lo;
-                --hi;
-                while (lt(a[first], a[hi])) --hi;
-                if (!(lo < hi)) break;
-                ss_swap(a, lo, hi);
-                ++lo;
-            }
-            const int64_t cut = lo;
+            const int64_t cut = ss_partition_pivot(a, first, last);
             if (sp < 72) { st_first[sp] = cut; st_last[sp] = last; st_depth[sp] = depth; sp++; }
             last = cut;
         }
     }
     // __final_insertion_sort
     if (n > 16) {
-        ss_insertion_sort(a, 0, 16, lt);
-        for (int64_t i = 16; i != n; ++i) ss_unguarded_linear_insert(a, i, lt);
-    } else ss_insertion_sort(a, 0, n, lt);
+        ss_insertion_sort(a, 0, 16);
+        for (int64_t i = 16; i != n; ++i) ss_unguarded_linear_insert(a, i);
+    } else ss_insertion_sort(a, 0, n);
 }
 
-AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {         // thread per contig
-    const int64_t c = k.bid * k.nthreads + k.tid;
+// One wave per contig with duplicate keys.  LDS form (N <= SF_MAX): the partition phase of the introsort is a
+// tree of independent sub-ranges - a range's partition only looks at its own elements - so the lanes take one
+// pending range each per round (a work list in LDS), partition it and put both halves back; ranges of <= 16
+// elements are insertion-sorted on the spot.  That equals libstdc++'s final pass: an insertion sort is a
+// stable sort, the leaf ranges are ordered among themselves (Hoare partition), and an element never moves
+// past an equal one, so the whole-array pass never carries an element across a leaf boundary either.
+// The root range costs one lane N steps, the two halves N/2 each in parallel, ...: ~2N steps instead of
+// N log N, on LDS instead of global memory.
+AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {
+    const int64_t c = k.bid;
     if (c >= w.C || !w.dupflag[c]) return;
     const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
-    int32_t *a = w.perm + b;
-    for (int64_t i = 0; i < N; i++) a[i] = (int32_t)i;             // copy of the input order (:232)
-    KeyLess lt{w.in_qs + gb, w.in_qe + gb};
-    ss_std_sort(a, N, lt, -1);
+    int32_t *perm = w.perm + b;
+    if (N > SF_MAX) {                                                // too long for LDS: one lane replays it in global memory
+        if (k.lane == 0) {
+            for (int64_t i = 0; i < N; i++) perm[i] = (int32_t)i;   // copy of the input order (:232)
+            SortGlob acc{perm, w.in_qs + gb, w.in_qe + gb};
+            ss_std_sort(acc, N, -1);
+        }
+        return;
+    }
+    SfLds *L = (SfLds *)k.lds;
+    SortLdsAcc acc{L};
+    for (int64_t i = k.lane; i < N; i += AASM_WAVE) { L->qs[SF_PAD + i] = w.in_qs[gb + i]; L->qe[SF_PAD + i] = w.in_qe[gb + i]; L->ix[SF_PAD + i] = (int32_t)i; }   // input order (:232)
+    for (int64_t i = k.lane; i < SF_PAD; i += AASM_WAVE) { L->qs[i] = 0; L->qe[i] = 0; L->qs[SF_PAD + N + i] = 0; L->qe[SF_PAD + N + i] = 0; }
+    int lg = 0;
+    for (int64_t t = N; t > 1; t >>= 1) lg++;
+    if (k.lane == 0) { L->qf[0] = SF_PAD; L->ql[0] = (int32_t)(SF_PAD + N); L->qd[0] = 2 * lg; L->qn = 1; L->ovf = 0; }
+    wave_lds_sync();
+    while (true) {
+        const int32_t qn = uni(L->qn);
+        if (qn <= 0) break;
+        // the last min(qn, #lanes) entries of the list, one per lane
+        const int32_t take = qn < AASM_WAVE ? qn : AASM_WAVE;
+        int32_t first = 0, last = 0, depth = 0;
+        const bool mine = k.lane < take;
+        if (mine) { const int32_t e = qn - 1 - k.lane; first = L->qf[e]; last = L->ql[e]; depth = L->qd[e]; }
+        wave_lds_sync();
+        if (k.lane == 0) L->qn = qn - take;
+        wave_lds_sync();
+        if (mine) {
+            if (last - first <= 16) ss_insertion_sort(acc, first, last);
+            else if (depth == 0) ss_heapsort(acc, first, last - first);     // depth limit: __partial_sort(first, last, last); sorted for good
+            else {
+                const int32_t cut = (int32_t)ss_partition_pivot(acc, first, last);
+                // halves of <= 16 elements are finished here; pending ranges are all longer, so there are never more than N / 17 of them
+                const int32_t f2[2] = {first, cut}, l2[2] = {cut, last};
+                for (int t = 0; t < 2; t++) {
+                    if (l2[t] - f2[t] <= 16) ss_insertion_sort(acc, f2[t], l2[t]);
+                    else {
+                        const int32_t at = (int32_t)atomic_add(&L->qn, (int32_t)1);
+                        if (at < SF_QN) { L->qf[at] = f2[t]; L->ql[at] = l2[t]; L->qd[at] = depth - 1; }
+                        else L->ovf = 1;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        if (uni(L->ovf)) break;
+    }
+    if (uni(L->ovf)) {                                               // work list overflow (cannot happen: pending ranges are longer than 16): sequential replay
+        if (k.lane == 0) {
+            for (int64_t i = 0; i < N; i++) perm[i] = (int32_t)i;
+            SortGlob g{perm, w.in_qs + gb, w.in_qe + gb};
+            ss_std_sort(g, N, -1);
+        }
+        return;
+    }
+    for (int64_t i = k.lane; i < N; i += AASM_WAVE) perm[i] = L->ix[SF_PAD + i];
 }
 
 // gather sorted SoA + parts (paf_data.cpp:248-261).  One wave per contig.

@@ -124,7 +124,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     CHECK_ALLOC();
     if (opts.reserved[2] & 1) be.launch(KN_SORT, C, 4096, w);       // test hook: an invalid launch configuration (block size > 1024)
     be.launch(KN_SORT, C, 256, w);
-    be.launch(KN_SORT_FIX, cdiv(C, 64), 64, w);
+    be.launch(KN_SORT_FIX, C, AASM_WAVE, w);
     be.launch(KN_GATHER_PARTS, C, AASM_WAVE, w);
     be.phase_end(AASM_PH_SORT);
 

@@ -38,7 +38,8 @@ struct EmuBackend {
         for (int64_t b = 0; b < nblocks; b++) {
             // one logical thread per block slot: bodies index with bid*nthreads+tid
             for (int t = 0; t < (kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads)); t++) {
-                alignas(16) static char lds[AASM_SORT_LDS_BYTES > AASM_ENUM_LDS_BYTES ? AASM_SORT_LDS_BYTES : AASM_ENUM_LDS_BYTES];
+                alignas(16) static char lds[65536];
+                static_assert(65536 >= AASM_SORTFIX_LDS_BYTES && 65536 >= AASM_SORT_LDS_BYTES && 65536 >= AASM_ENUM_LDS_BYTES, "emulation LDS");
                 static_assert(AASM_SEL_LDS_BYTES <= AASM_SORT_LDS_BYTES && AASM_HEAP_LDS_BYTES <= AASM_SORT_LDS_BYTES && AASM_LDS_BYTES <= AASM_SORT_LDS_BYTES, "emulation LDS");
                 KCtx k{t, kn == KN_SORT ? 1 : nthreads_emul(kn, nthreads), b, nblocks, 0, lds};
                 run_kernel_body(kn, k, w);
@@ -48,7 +49,7 @@ struct EmuBackend {
     // wave-per-X kernels run with ONE lane (AASM_WAVE == 1); thread-per-X kernels keep their block size
     static int nthreads_emul(int kn, int nthreads) {
         switch (kn) {
-            case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_SORT_ROWS_CHILD:
+            case KN_SORT_FIX: case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_SORT_ROWS_CHILD:
             case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_HEAP: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
                 return 1;
             default: return nthreads;
@@ -95,9 +96,20 @@ int64_t emul_debug_fetch(const char *name, void *dst, int64_t cap) {
     if (dst) memcpy(dst, it->second.first, std::min<size_t>((size_t)cap, it->second.second));
     return (int64_t)it->second.second;
 }
+// kb_sort_fix itself (one contig, LDS form when n <= SF_MAX: work list of sub-ranges, leaf insertion sorts)
+void emul_sort_fix_kernel(int32_t *perm, int64_t n, const int64_t *qs, const int64_t *qe) {
+    WS w;
+    memset(&w, 0, sizeof(w));
+    int64_t rec_off[2] = {0, n};
+    int32_t dup = 1;
+    w.C = 1; w.R0 = 0; w.rec_off = rec_off; w.dupflag = &dup; w.in_qs = qs; w.in_qe = qe; w.perm = perm;
+    alignas(16) static char lds[AASM_SORTFIX_LDS_BYTES];
+    KCtx k{0, 1, 0, 1, 0, lds};
+    kb_sort_fix(k, w);
+}
 // libstdc++ std::sort replay used by kb_sort_fix, exposed for a direct test
 void emul_std_sort_replay(int32_t *idx, int64_t n, const int64_t *qs, const int64_t *qe, int depth_override) {
-    KeyLess lt{qs, qe};
-    ss_std_sort(idx, n, lt, depth_override);
+    SortGlob acc{idx, qs, qe};
+    ss_std_sort(acc, n, depth_override);
 }
 }

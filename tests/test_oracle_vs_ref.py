@@ -132,13 +132,15 @@ def test_std_sort_over_real_pafreaddata(T):
     """paf_data.cpp:232,241: std::sort of a copy of std::vector<PafReadData> with the real
     operator< -- against the oracle's std::sort over its own Rec and against the replay the
     product's kb_sort_fix runs (same kernel body, host build)."""
-    from test_sort_replay import _replay, _std
+    from test_sort_replay import _kernel, _replay, _std
     for mono in (True, False):
         R = _need(T, mono)
         for qs, qe in _sort_cases():
             want = _ref_perm(R, qs, qe)
             assert np.array_equal(_std(T, qs, qe), want), (len(qs), mono)
             assert np.array_equal(_replay(T, qs, qe), want), (len(qs), mono)
+            if mono and len(qs) > 1:
+                assert np.array_equal(_kernel(T, qs, qe), want), len(qs)     # kb_sort_fix (LDS work-list form up to 3072 records, sequential beyond)
 
 
 def test_read_predicates_truth_table(T):

@@ -14,6 +14,13 @@ def _replay(T, qs, qe, depth=-1):
     return idx
 
 
+def _kernel(T, qs, qe):
+    """kb_sort_fix as the pipeline runs it for one contig (host build of the kernel body)."""
+    perm = np.full(len(qs), -1, np.int32)
+    T.emul().emul_sort_fix_kernel(perm.ctypes.data_as(C.c_void_p), C.c_int64(len(qs)), qs.ctypes.data_as(C.c_void_p), qe.ctypes.data_as(C.c_void_p))
+    return perm
+
+
 def _std(T, qs, qe, heap_only=0):
     perm = np.zeros(len(qs), np.int32)
     T.oracle().oracle_std_sort_perm(qs.ctypes.data_as(C.c_void_p), qe.ctypes.data_as(C.c_void_p), C.c_int64(len(qs)),
@@ -28,6 +35,8 @@ def test_replay_equals_std_sort_with_heavy_duplicates(T, n):
         qs = rng.integers(0, distinct, n).astype(np.int64)
         qe = qs + rng.integers(0, 3, n).astype(np.int64)
         assert np.array_equal(_replay(T, qs, qe), _std(T, qs, qe)), (n, distinct)
+        if n > 1:
+            assert np.array_equal(_kernel(T, qs, qe), _std(T, qs, qe)), (n, distinct)
 
 
 def test_replay_orders_patterns(T):
@@ -37,6 +46,7 @@ def test_replay_orders_patterns(T):
             qs = np.ascontiguousarray(qs, dtype=np.int64)
             qe = qs + 1
             assert np.array_equal(_replay(T, qs, qe), _std(T, qs, qe))
+            assert np.array_equal(_kernel(T, qs, qe), _std(T, qs, qe))
 
 
 def test_heapsort_fallback_equals_partial_sort(T):

@@ -7,7 +7,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--contigs", type=int, default=500); ap.add_argument("--recs", type=int, default=1000)
 ap.add_argument("--k", type=int, default=4); ap.add_argument("--dense", type=int, default=0)
 ap.add_argument("--seed", type=int, default=21); ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--heavy", type=int, default=0)
+ap.add_argument("--heavy", type=int, default=0); ap.add_argument("--dup", type=int, default=0); ap.add_argument("--shuffle", type=int, default=0)
 ap.add_argument("--cs", type=int, default=0, help="1: the batch carries cs tags and the device derives the match ranges (K0)")
 a = ap.parse_args()
 t = time.time()
@@ -17,7 +17,7 @@ if a.cs:
     hb = A.Paf.read("/tmp/aasm_probe/p.paf", device_ranges=True)
     v = hb.view(); print("gen+read %.2fs records=%d ranges=%d cs_bytes=%d" % (time.time() - t, v.n_records, v.n_ranges, os.path.getsize("/tmp/aasm_probe/p.paf")), flush=True)
 else:
-    paf = A.Paf.synth(a.contigs, a.recs, a.seed, dense=bool(a.dense), heavy_tail=bool(a.heavy), no_cs=True); hb = paf.batch(); paf.close()
+    paf = A.Paf.synth(a.contigs, a.recs, a.seed, dense=bool(a.dense), heavy_tail=bool(a.heavy), dup_every=a.dup, shuffle=bool(a.shuffle), no_cs=True); hb = paf.batch(); paf.close()
     print("gen %.2fs records=%d ranges=%d" % (time.time() - t, hb.view.n_records, hb.view.n_ranges), flush=True)
 t = time.time(); db = A.DeviceBatch(hb); print("upload %.2fs" % (time.time() - t), flush=True)
 for r in range(a.reps):
