@@ -219,12 +219,17 @@ class DeviceResult:
         return st.as_dict()
 
     def fetch(self):
-        out = BatchOut()
-        _check(LIB.aasm_result_fetch(self._h, C.byref(out)))
+        out = self.fetch_raw()
         try:
             return unpack_out(out)
         finally:
             free_out(out)
+
+    def fetch_raw(self) -> BatchOut:
+        """D2H + ragged pack into the C structure (what a C caller gets); release it with free_out()."""
+        out = BatchOut()
+        _check(LIB.aasm_result_fetch(self._h, C.byref(out)))
+        return out
 
     def debug(self, name, dtype):
         n = LIB.aasm_debug_fetch(self._h, name.encode(), None, C.c_int64(0))

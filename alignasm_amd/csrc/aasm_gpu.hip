@@ -167,6 +167,7 @@ struct DevCtx {
     size_t d_scratch2_cap = 0;
     std::vector<ArenaBlock> blocks;
     int64_t *pinned = nullptr;          // host-pinned scalar read-back buffer
+    char *stage[2] = {nullptr, nullptr};   // host-pinned staging chunks of the result fetch (created on first use)
     int64_t *d_scratch = nullptr;       // scan tile sums
     size_t d_scratch_cap = 0;
     uint64_t generation = 0;
@@ -440,12 +441,42 @@ int aasm_result_stats(const aasm_result *res, aasm_stats *stats) {
 
 // minimal backend view for fetch (D2H only)
 namespace {
+#define AASM_STAGE_BYTES ((size_t)16 << 20)
 struct FetchBackend {
-    hipStream_t stream; bool fail = false;
+    DevCtx &cx; hipStream_t stream; bool fail = false;
     void d2h(void *dst, const void *src, size_t n) {
         if (fail || n == 0) return;
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { set_last_error(hip_err("hipMemcpy D2H", e)); fail = true; }
+    }
+    // Large result arrays: a copy into pageable memory goes through the runtime's own staging at a few GB/s and
+    // first-touches every destination page on one thread.  Here the DMA lands in two pinned 16 MB chunks in turn
+    // while host threads move the chunk before it into the caller's array (page faults spread over the threads).
+    void d2h_big(void *dst, const void *src, size_t n) {
+        if (fail || n == 0) return;
+        if (n < (AASM_STAGE_BYTES >> 2)) { d2h(dst, src, n); return; }
+        for (int i = 0; i < 2; i++)
+            if (!cx.stage[i] && hipHostMalloc((void **)&cx.stage[i], AASM_STAGE_BYTES) != hipSuccess) { (void)hipGetLastError(); cx.stage[i] = nullptr; d2h(dst, src, n); return; }
+        const size_t nchunks = (n + AASM_STAGE_BYTES - 1) / AASM_STAGE_BYTES;
+        const int T = std::max(1, std::min(host_threads(), 16));
+        auto issue = [&](size_t c) {
+            const size_t off = c * AASM_STAGE_BYTES, len = std::min(AASM_STAGE_BYTES, n - off);
+            return hipMemcpyAsync(cx.stage[c & 1], (const char *)src + off, len, hipMemcpyDeviceToHost, stream);
+        };
+        hipError_t e = issue(0);
+        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+            e = hipStreamSynchronize(stream);                        // chunk c has landed
+            if (e != hipSuccess) break;
+            if (c + 1 < nchunks) e = issue(c + 1);                   // the next DMA runs beside the host copy of this one
+            const size_t off = c * AASM_STAGE_BYTES, len = std::min(AASM_STAGE_BYTES, n - off);
+            const char *from = cx.stage[c & 1];
+            char *to = (char *)dst + off;
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back([=] { const size_t a = len * t / T, b = len * (t + 1) / T; std::memcpy(to + a, from + a, b - a); });
+            std::memcpy(to, from, len / T);
+            for (auto &x : th) x.join();
+        }
         if (e != hipSuccess) { set_last_error(hip_err("hipMemcpy D2H", e)); fail = true; }
     }
 };
@@ -457,7 +488,7 @@ int aasm_result_fetch(aasm_result *res, aasm_batch_out *out) {
     std::lock_guard<std::mutex> lk(cx.mu);
     if (res->generation != cx.generation) { set_last_error("result was invalidated by a later solve on the same device"); return AASM_E_INVAL; }
     hipSetDevice(res->device);
-    FetchBackend fb{res->stream};
+    FetchBackend fb{cx, res->stream};
     int rc = fetch_results(fb, res->w, res->sz, out);
     if (fb.fail) { aasm_free_out(out); return AASM_E_HIP; }
     if (rc != AASM_OK) return rc;

@@ -364,11 +364,11 @@ int fetch_results(B &be, const WS &w, const PipelineSizes &sz, aasm_batch_out *o
     be.d2h(out->alt_off, w.alt_off, (C + 1) * 8);
     be.d2h(out->ctg_status, w.status, C * 4);
     const int64_t NM = out->main_off[C], NA = out->alt_off[C];
-    out->main_elems = (aasm_out_elem *)calloc(NM + 1, sizeof(aasm_out_elem));
-    out->alt_elems = (aasm_out_elem *)calloc(NA + 1, sizeof(aasm_out_elem));
+    out->main_elems = (aasm_out_elem *)malloc((NM + 1) * sizeof(aasm_out_elem));      // (every element is overwritten: no zero fill of 100s of MB)
+    out->alt_elems = (aasm_out_elem *)malloc((NA + 1) * sizeof(aasm_out_elem));
     static_assert(sizeof(aasm_out_elem) == sizeof(OutElem), "layout");
-    if (NM) be.d2h(out->main_elems, w.main_c, NM * sizeof(OutElem));
-    if (NA) be.d2h(out->alt_elems, w.alt_c, NA * sizeof(OutElem));
+    if (NM) be.d2h_big(out->main_elems, w.main_c, NM * sizeof(OutElem));
+    if (NA) be.d2h_big(out->alt_elems, w.alt_c, NA * sizeof(OutElem));
     int64_t cnt[CNT_N];
     be.d2h(cnt, w.counters, sizeof(cnt));
     // .all paths: keep records of the final generation, ordered by (contig, seq)

@@ -188,7 +188,7 @@ def main():
         t = time.perf_counter()
         for _ in range(args.steps):
             res = db.solve(max_paths=K)
-            res.fetch()
+            A.api.free_out(res.fetch_raw())                          # aasm_result_fetch: D2H + ragged pack, as a C caller receives it
             res.close()
         extras["step_with_fetch_ms"] = round(allreduce((time.perf_counter() - t) * 1e3 / max(args.steps, 1), dist.ReduceOp.MAX if dist else None), 3)
         if world == 1:
