@@ -43,6 +43,9 @@ template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return f
 template <class T> AASM_DEV T wave_shfl_xor(T x, int) { return x; }
 AASM_DEV void wave_lds_sync() {}
 AASM_DEV void block_barrier() {}
+AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return *p; }
+AASM_DEV void wave_sleep() {}
+AASM_DEV void store_drain() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
 AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
@@ -76,6 +79,11 @@ AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
 AASM_DEV void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // barrier + LDS/global visibility inside a multi-wave workgroup (K1 sort)
 AASM_DEV void block_barrier() { __syncthreads(); }
+// a word another wave of the SAME workgroup may have just stored (global memory): workgroup-scope load
+AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AASM_DEV void wave_sleep() { __builtin_amdgcn_s_sleep(2); }
+// every store of this wave has reached the cache its workgroup shares (before it tells another wave about them)
+AASM_DEV void store_drain() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 // order this wave's global-memory writes before its later reads (same CU, same L1)
 AASM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 template <class T> AASM_DEV T atomic_add(T *p, T v) { return atomicAdd(p, v); }

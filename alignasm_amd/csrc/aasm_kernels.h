@@ -98,6 +98,14 @@ struct WS {
     Dist *st_cost;                       // per vertex, at the front of its CSR row: its sidetrack keys in list order, edge head in .pad
     int32_t *st_n;                       // ... and how many
     I4 *vhdr, *vhdr2, *cinfo;            // kb_heap_hdr
+    // ---- K7, several waves per contig (kb_heap_mw)
+    int32_t mw_mode;                     // 0: by graph density, 1: every contig, 2: none (tests)
+    int32_t *mw_flag, *mw_lg;            // per contig: class, per-insert node bound
+    HNode *hprov;                        // provisional arena: one region per vertex, regions in BFS order
+    int64_t *mw_off;                     // per contig: start of its part of the provisional arena
+    int32_t *mw_cap;                     // per contig: provisional capacity (0 for the one-wave class)
+    int32_t *mw_order, *mw_rs, *mw_fb;   // per BFS position: vertex, region start, final base
+    int32_t *mw_rsv, *mw_used;           // per vertex: region start, nodes used
     I4 *tnx;                             // next four vertices along best[] (path recovery reads one record per four tree edges)
     I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
@@ -1352,6 +1360,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     const int64_t c = k.bid * k.nthreads + k.tid;
     if (c >= w.C) return;
     const int64_t V = w.ctgV[c];
+    w.mw_flag[c] = 0; w.mw_cap[c] = 0; w.mw_lg[c] = 2;
     if (V == 0) { w.hcap_cnt[c] = 0; return; }
     const int64_t vb = w.voff[c];
     const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
@@ -1363,6 +1372,10 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     int64_t cap = I * (lg + 2) + 8;
     if (cap > 0x7fffff00) cap = 0x7fffff00;                          // arena indices are int32: a contig that really needs more ends with status AASM_E_OVERFLOW (kb_heap)
     w.hcap_cnt[c] = (int32_t)cap;
+    w.mw_lg[c] = lg + 2;
+    // dense / high-multiplicity graphs (tens of sidetracks per vertex, a wide SP tree): several waves per contig
+    w.mw_flag[c] = (w.mw_mode == 1 || (w.mw_mode == 0 && I >= 6 * V && V >= 128)) ? 1 : 0;
+    w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
@@ -1412,14 +1425,15 @@ struct Spine {
 };
 struct HeapState {
     HNode *nodes;
-    HeapLds *L;
+    HNode *ring;                   // HEAP_RING nodes of LDS, this wave's
     int32_t alloc, flushed, cap;   // arena: next index; nodes below `flushed` are in global memory, [flushed, alloc) only in the ring
+    int32_t ring_lo;               // nodes below it were never in this wave's ring (0, or the start of the vertex region being filled)
     bool ovf;
 };
 
 AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
     NodeQ n;
-    if (a >= hs.alloc - HEAP_RING) n = nodeq_load(&hs.L->ring[a & (HEAP_RING - 1)]);   // ds_read, lgkmcnt only
+    if (a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) n = nodeq_load(&hs.ring[a & (HEAP_RING - 1)]);   // ds_read, lgkmcnt only
     else { n = nodeq_load(&hs.nodes[a]); asm volatile("" ::: "memory"); }             // keep it a global_load (no flat access)
     return n;
 }
@@ -1439,7 +1453,7 @@ AASM_DEV void heap_flush(HeapState &hs, int lane) {
     const int32_t m = hs.alloc - hs.flushed;
     if (m > 0) {
         wave_lds_sync();
-        FOR_LANE(t, m, lane) { const int32_t a = hs.flushed + t; nodeq_store(&hs.nodes[a], nodeq_load(&hs.L->ring[a & (HEAP_RING - 1)])); }
+        FOR_LANE(t, m, lane) { const int32_t a = hs.flushed + t; nodeq_store(&hs.nodes[a], nodeq_load(&hs.ring[a & (HEAP_RING - 1)])); }
         hs.flushed = hs.alloc;
     }
 }
@@ -1470,7 +1484,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
             FOR_LANE_EQ(j, depth, lane) {
                 const NodeQ n = heap_read(hs, a);
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-                kp.acc[(a >= hs.alloc - HEAP_RING) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
+                kp.acc[(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
 #endif
                 const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
                 sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum;
@@ -1521,12 +1535,12 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         n.q2.x = leaf ? a_stop : (sw ? below : l); n.q2.y = leaf ? -1 : (sw ? l : below);
         n.q2.z = leaf ? eu : old.q2.z; n.q2.w = leaf ? ev : old.q2.w;
 #if defined(AASM_HOST_EMUL)
-        nodeq_store(&hs.L->ring[ni & (HEAP_RING - 1)], n);
+        nodeq_store(&hs.ring[ni & (HEAP_RING - 1)], n);
         sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;
         if (!leaf && sw) swm |= 1ull << j;
 #else
         if (in) {
-            nodeq_store(&hs.L->ring[ni & (HEAP_RING - 1)], n);
+            nodeq_store(&hs.ring[ni & (HEAP_RING - 1)], n);
             sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;       // position j of the NEW spine (valid up to the first swap)
         }
         swm = wave_ballot(in && !leaf && sw);
@@ -1551,9 +1565,10 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
     const Dist *sk = w.st_cost + w.rowptr[vb];                      // the contig's compacted sidetrack keys (kb_sidetrack)
     HeapState hs;
-    hs.nodes = w.hnodes + w.hoff[c]; hs.L = L; hs.alloc = 0; hs.flushed = 0; hs.ovf = false;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
+    if (w.mw_flag[c]) return;                                        // wide trees: kb_heap_mw
     if (k.lane == 0) w.h_cnt[c] = 0;
     if (w.status[c] != 0) return;
     if (dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
@@ -1658,6 +1673,172 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     KPROF_FLUSH(w.prof_heap, c, k.lane);
     if (hs.ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
     if (k.lane == 0) { w.h_cnt[c] = hs.alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)hs.alloc); }
+}
+
+// ====================================================================================
+// K7 with SEVERAL WAVES PER CONTIG (wide SP trees: dense / high-multiplicity graphs, giant contigs)
+// ====================================================================================
+// Persistence means that the heaps of two vertices of which neither is an ancestor of the other share
+// nothing they write: independent branches of the SP tree can be built at the same time.  What ties the
+// branches together is only the ORDER of allocation - the arena index is the k-walk tie-break (hazard B3) and
+// the reference allocates in BFS order of the tree.  So:
+//   phase 0  (wave 0) numbers the tree's vertices in BFS order, 64 queue entries per step, and gives every
+//            vertex a region of the PROVISIONAL arena sized by the per-insert bound (#keys * (floor(log2(I+1)) + 2)),
+//            regions laid out in BFS order;
+//   phase 1  every wave builds vertices: it keeps going down its own branch (the first child inherits the heap
+//            whose right spine is in its registers) and hands the other children to the waves that wait, through
+//            a ticket queue (tickets and counters in LDS, entries in global memory; a producer drains its stores
+//            before it publishes);
+//   phase 2  all waves compact: nodes move from their regions to the final arena in BFS order - exactly the
+//            reference's allocation order - and child pointers / roots are translated (own region: arithmetic,
+//            ancestor's region: binary search over the region starts).
+// The result is bit-identical to the one-wave kernel's, arena indices included.
+#define MW_WAVES 4
+struct MwLds {
+    HNode ring[MW_WAVES][HEAP_RING];
+    int32_t q_head, q_tail, n_done, n_total, stop, n_nodes, pad0, pad1;
+};
+#define AASM_MW_LDS_BYTES (MW_WAVES * HEAP_RING * 48 + 32)
+static_assert(sizeof(MwLds) <= AASM_MW_LDS_BYTES, "LDS budget");
+
+// last position i in [0, n) with a[i] <= x (a non-decreasing, a[0] <= x)
+AASM_DEV int32_t mw_last_le(const int32_t *a, int32_t n, int32_t x) {
+    int32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const int32_t m = (lo + hi) >> 1; if (a[m] <= x) lo = m; else hi = m; }
+    return lo;
+}
+
+AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES waves per contig
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0 || !w.mw_flag[c]) return;
+    MwLds *L = (MwLds *)k.lds;
+    const int64_t vb = w.voff[c];
+    const int wv = k.tid / AASM_WAVE;                                // this wave
+    int32_t *h = w.h_root + vb, *q = w.bq + vb;
+    const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
+    const Dist *sk = w.st_cost + w.rowptr[vb];
+    int32_t *order = w.mw_order + vb, *rs = w.mw_rs + vb, *fb = w.mw_fb + vb, *rsv = w.mw_rsv + vb, *used = w.mw_used + vb;
+    const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
+    const int32_t per_insert = w.mw_lg[c];
+    if (k.tid == 0) w.h_cnt[c] = 0;
+    if (w.status[c] != 0) return;
+    if (dist_is_max(w.sp_d[vb + src])) { if (k.tid == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
+    // ---- phase 0: BFS numbering (k_shortest_walks.hpp:196-214 without the inserts) + region starts
+    if (wv == 0) {
+        if (k.lane == 0) order[0] = dest;
+        wave_fence();
+        int32_t n = 1, head = 0, rbase = 0;
+        while (head < n) {
+            const int32_t chunk = (n - head < AASM_WAVE) ? (n - head) : AASM_WAVE;
+            int32_t v = -1, nch = 0, nin = 0;
+            int64_t c0 = 0;
+            if (k.lane < chunk) {
+                v = order[head + k.lane];
+                const I4 a = vh[v], b = vh2[v];
+                nin = a.y; nch = a.z;
+                c0 = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+            }
+            const int32_t capv = nin * per_insert, cincl = wave_incl_add(capv), nincl = wave_incl_add(nch);
+            if (k.lane < chunk) { rs[head + k.lane] = rbase + cincl - capv; rsv[v] = rbase + cincl - capv; used[v] = 0; }
+            for (int32_t j = 0; j < nch; j++) order[n + (nincl - nch) + j] = w.cval[c0 + j];   // children in ascending id (:191-194)
+            rbase += wave_bcast(cincl, AASM_WAVE - 1);
+            n += wave_bcast(nincl, AASM_WAVE - 1);
+            head += chunk;
+            wave_fence();
+        }
+        if (k.lane == 0) { L->n_total = n; L->q_head = 0; L->q_tail = 0; L->n_done = 0; L->stop = 0; L->n_nodes = 0; }
+        store_drain();
+    }
+    block_barrier();
+    const int32_t nv = uni(ld_shared_i32(&L->n_total));
+    // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
+    HeapState hs;
+    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
+    Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
+    KProfNone kp;
+    int32_t u = (wv == 0) ? dest : -1, hu = -1;
+    int64_t guard = 0;
+    while (true) {
+        if (uni(ld_shared_i32(&L->stop))) break;
+        if (u < 0) {                                                 // nothing of its own left: a ticket for the shared queue
+            int32_t s = 0;
+            if (k.lane == 0) s = atomic_add(&L->q_head, (int32_t)1);
+            s = wave_bcast(s, 0);
+            while (true) {
+                if (uni(ld_shared_i32(&L->stop)) || uni(ld_shared_i32(&L->n_done)) >= nv) { u = -2; break; }
+                const int32_t e = (s < V) ? uni(ld_shared_i32(&q[s])) : -1;
+                if (e >= 0) { u = e; hu = uni(ld_shared_i32(&h[u])); break; }
+                if (++guard > ((int64_t)1 << 34)) { u = -2; if (k.lane == 0) L->stop = 2; break; }   // (never: every wait ends with an entry or with n_done == nv)
+                wave_sleep();
+            }
+            if (u == -2) break;
+        }
+        const I4 ha = vh[u], hb = vh2[u];
+        const int32_t so = uni(ha.x), n = uni(ha.y), nch = uni(ha.z), fc = uni(ha.w);
+        const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)uni(hb.y) << 32) | (uint32_t)uni(hb.x));
+        const int32_t r0 = uni(rsv[u]);
+        heap_flush(hs, k.lane);
+        hs.alloc = r0; hs.flushed = r0; hs.ring_lo = r0; hs.cap = r0 + n * per_insert;
+        for (int32_t base = 0; base < n && !hs.ovf; base += AASM_WAVE_MAX) {   // inserts in list order (:202-211)
+            const int32_t m = (n - base < AASM_WAVE_MAX) ? (n - base) : AASM_WAVE_MAX;
+            LaneArr<Dist> key;
+            FOR_LANE(t, m, k.lane) key.at(t) = sk[(int64_t)so + base + t];
+            for (int32_t t = 0; t < m && !hs.ovf; t++) {
+                const Dist cc = la_get_dist(key, t);
+                hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
+            }
+        }
+        if (hs.ovf) { if (k.lane == 0) L->stop = 1; break; }
+        heap_flush(hs, k.lane);
+        if (k.lane == 0) { used[u] = hs.alloc - r0; h[u] = hu; }     // (the inherited root this word carried has been read)
+        // children adopt the heap (:213): the first one stays with this wave, the others go to whoever waits
+        if (nch >= 2) {
+            for (int32_t t = 1 + k.lane; t < nch; t += AASM_WAVE) h[w.cval[c0 + t]] = hu;
+            store_drain();                                           // nodes, roots: in the shared cache before the entries appear
+            int32_t at = 0;
+            if (k.lane == 0) at = atomic_add(&L->q_tail, nch - 1);
+            at = wave_bcast(at, 0);
+            for (int32_t t = 1 + k.lane; t < nch; t += AASM_WAVE) q[at + t - 1] = w.cval[c0 + t];
+        }
+        store_drain();
+        if (k.lane == 0) atomic_add(&L->n_done, (int32_t)1);
+        u = (nch > 0) ? fc : -1;
+    }
+    heap_flush(hs, k.lane);
+    store_drain();
+    block_barrier();
+    const int32_t stop = uni(ld_shared_i32(&L->stop));
+    if (stop) { if (k.tid == 0) set_status(w, c, stop == 1 ? -5 : -6); return; }
+    // ---- phase 2: compaction into the final arena, BFS order = the reference's allocation order
+    if (wv == 0) {
+        int32_t carry = 0;
+        for (int32_t base = 0; base < nv; base += AASM_WAVE) {
+            const int32_t i = base + k.lane;
+            const int32_t x = (i < nv) ? used[order[i]] : 0, incl = wave_incl_add(x);
+            if (i < nv) fb[i] = carry + incl - x;
+            carry += wave_bcast(incl, AASM_WAVE - 1);
+        }
+        if (k.lane == 0) L->n_nodes = carry;
+        store_drain();
+    }
+    block_barrier();
+    const int32_t H = uni(ld_shared_i32(&L->n_nodes));
+    HNode *fin = w.hnodes + w.hoff[c];
+    if (H > (int32_t)(w.hoff[c + 1] - w.hoff[c])) { if (k.tid == 0) set_status(w, c, -5); return; }
+    auto translate = [&](int32_t x, int32_t i_own) -> int32_t {     // provisional index -> final index
+        if (x < 0) return x;
+        const int32_t j = (i_own >= 0 && x >= rs[i_own]) ? i_own : mw_last_le(rs, i_own >= 0 ? i_own : nv, x);
+        return fb[j] + (x - rs[j]);
+    };
+    for (int32_t f = k.tid; f < H; f += k.nthreads) {
+        const int32_t i = mw_last_le(fb, nv, f);
+        HNode nd = hs.nodes[rs[i] + (f - fb[i])];
+        nd.left = translate(nd.left, i); nd.right = translate(nd.right, i);
+        fin[f] = nd;
+    }
+    for (int32_t i = k.tid; i < nv; i += k.nthreads) { const int32_t v = order[i]; h[v] = translate(h[v], -1); }
+    if (k.tid == 0) { w.h_cnt[c] = H; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)H); }
 }
 
 // ====================================================================================

@@ -22,7 +22,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP,
-    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -53,6 +53,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
         case KN_HEAP: kb_heap(k, w); break;
+        case KN_HEAP_MW: kb_heap_mw(k, w); break;
         case KN_ENUM: kb_enum(k, w); break;
         case KN_SELECT: kb_select(k, w); break;
         case KN_GATHER_OUT: kb_gather_out(k, w); break;
@@ -224,6 +225,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP_PREP);
         AZ(ccnt, int32_t, VT, "ccnt"); AZ(ccur, int32_t, VT, "ccur"); A(cptr, int64_t, VT + 1, "cptr"); A(cval, int32_t, VT, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
+        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off");
+        w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, VT, "cinfo"); A(tnx, I4, VT, "tnx");
         CHECK_ALLOC();
         be.launch(KN_CHILD_COUNT, cdiv(VT, 256), 256, w);
@@ -234,14 +237,19 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
-        const int64_t HT = be.read_i64(w.hoff + C);
+        be.scan_i32(w.mw_cap, C, w.mw_off);
+        const int64_t HT = be.read_i64(w.hoff + C), HTM = be.read_i64(w.mw_off + C);
         sz.HT = HT;
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
+        A(hprov, HNode, HTM, "hprov");
+        A(mw_order, int32_t, VT, "mw_order"); A(mw_rs, int32_t, VT, "mw_rs"); A(mw_fb, int32_t, VT, "mw_fb"); A(mw_rsv, int32_t, VT, "mw_rsv"); A(mw_used, int32_t, VT, "mw_used");
         CHECK_ALLOC();
         be.fill_ff(w.h_root, sizeof(int32_t) * (size_t)VT);
+        be.fill_ff(w.bq, sizeof(int32_t) * (size_t)VT);
         be.phase_end(AASM_PH_HEAP_PREP);
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
+        if (HTM > 0) be.launch(KN_HEAP_MW, C, AASM_WAVE * MW_WAVES, w);      // contigs of the wide-tree class (kb_heap skips them)
         be.phase_end(AASM_PH_HEAP);
 
         // ---- K8 enumeration

@@ -87,7 +87,8 @@ typedef struct aasm_opts {
     int32_t collect_timing;    /* 1: bracket every kernel with HIP events            */
     int32_t keep_debug;        /* 1: keep device intermediates for aasm_debug_fetch   */
     int32_t reserved[3];       /* test hooks, 0 in production:
-                                * [0] bit 0: force the sequential selection kernel
+                                * [0] bit 0: force the sequential selection kernel; bit 1: build every contig's heaps with the
+                                *            several-waves-per-contig kernel; bit 2: none of them (default: by graph density)
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP)  */

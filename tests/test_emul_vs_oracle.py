@@ -45,3 +45,17 @@ def test_sequential_select_fallback(T, case):
     want = T.oracle_solve(hb, K, nsl)
     got = T.emul_solve(hb, K, nsl, sequential_select=True)
     assert T.diff_outputs(want, got) == []
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[9], CASES[10], CASES[12]], ids=lambda c: "mw_c%dx%d_s%d" % (c[0], c[1], c[2]))
+def test_multiwave_heap_kernel_is_bit_identical(T, case):
+    """kb_heap_mw (several waves per contig: BFS numbering, per-vertex regions of a provisional arena, ticket
+    queue, compaction into BFS order) forced on every contig: final outputs AND the heap arena (indices
+    included), roots and k distances equal the oracle's, as with the one-wave kernel.  (One lane here: the
+    logic; the GPU tier runs it with four real waves.)"""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = T.emul_solve(hb, K, nsl, heap_waves="all")
+    assert T.diff_outputs(want, got) == []
+    assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []

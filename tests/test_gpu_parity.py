@@ -207,3 +207,27 @@ def test_input_guards_report_overflow(T):
     for c in (0, 1, 3, 4, 5):
         wm = want["main"][want["main_off"][c]:want["main_off"][c + 1]]
         assert np.array_equal(wm, out["main"][mo[c]:mo[c + 1]]), c
+
+
+# ---- K7 with several waves per contig (kb_heap_mw), forced on every contig
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[4], CASES[5], CASES[10], CASES[13], CASES[15]], ids=_id)
+def test_multiwave_heaps_match_oracle(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, heap_waves="all")
+    assert T.diff_outputs(want, got) == []
+
+
+@pytest.mark.parametrize("case", [CASES[3], CASES[5], CASES[13]], ids=_id)
+def test_multiwave_heap_arena_is_bit_identical(T, case):
+    """The compaction restores the reference's allocation order: arena indices, child pointers, roots and the k
+    distances equal the oracle's exactly (and so the one-wave kernel's)."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    db = api.DeviceBatch(hb)
+    res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves="all")
+    assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+    res.close(); db.close()
