@@ -111,7 +111,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -1376,6 +1376,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     // dense / high-multiplicity graphs (tens of sidetracks per vertex, a wide SP tree): several waves per contig
     w.mw_flag[c] = (w.mw_mode == 1 || (w.mw_mode == 0 && I >= 6 * V && V >= 128)) ? 1 : 0;
     w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
+    if (w.mw_flag[c]) atomic_add(&w.counters[CNT_MW], (int64_t)1);
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
@@ -1693,13 +1694,13 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 //            reference's allocation order - and child pointers / roots are translated (own region: arithmetic,
 //            ancestor's region: binary search over the region starts).
 // The result is bit-identical to the one-wave kernel's, arena indices included.
-#define MW_WAVES 4
+#define MW_WAVES 16                      // most waves a contig can get (the launch picks 4, 8 or 16 by how many contigs share the chip)
 struct MwLds {
-    HNode ring[MW_WAVES][HEAP_RING];
     int32_t q_head, q_tail, n_done, n_total, stop, n_nodes, pad0, pad1;
+    HNode ring[MW_WAVES][HEAP_RING];     // (a launch with fewer waves declares only its share)
 };
-#define AASM_MW_LDS_BYTES (MW_WAVES * HEAP_RING * 48 + 32)
-static_assert(sizeof(MwLds) <= AASM_MW_LDS_BYTES, "LDS budget");
+#define AASM_MW_LDS_BYTES(waves) ((waves) * HEAP_RING * 48 + 32)
+static_assert(sizeof(MwLds) <= AASM_MW_LDS_BYTES(MW_WAVES), "LDS budget");
 
 // last position i in [0, n) with a[i] <= x (a non-decreasing, a[0] <= x)
 AASM_DEV int32_t mw_last_le(const int32_t *a, int32_t n, int32_t x) {

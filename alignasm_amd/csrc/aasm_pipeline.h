@@ -22,7 +22,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP,
-    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -53,7 +53,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
         case KN_HEAP: kb_heap(k, w); break;
-        case KN_HEAP_MW: kb_heap_mw(k, w); break;
+        case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
         case KN_ENUM: kb_enum(k, w); break;
         case KN_SELECT: kb_select(k, w); break;
         case KN_GATHER_OUT: kb_gather_out(k, w); break;
@@ -238,7 +238,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
         be.scan_i32(w.mw_cap, C, w.mw_off);
-        const int64_t HT = be.read_i64(w.hoff + C), HTM = be.read_i64(w.mw_off + C);
+        const int64_t HT = be.read_i64(w.hoff + C), HTM = be.read_i64(w.mw_off + C), NMW = HTM > 0 ? be.read_i64(w.counters + CNT_MW) : 0;
         sz.HT = HT;
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
         A(hprov, HNode, HTM, "hprov");
@@ -249,7 +249,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_end(AASM_PH_HEAP_PREP);
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
-        if (HTM > 0) be.launch(KN_HEAP_MW, C, AASM_WAVE * MW_WAVES, w);      // contigs of the wide-tree class (kb_heap skips them)
+        // contigs of the wide-tree class (kb_heap skips them): 16, 8 or 4 waves each, by how many of them share the chip's ~8 k wave slots
+        if (HTM > 0) { const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4; be.launch(mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW, C, AASM_WAVE * mw, w); }
         be.phase_end(AASM_PH_HEAP);
 
         // ---- K8 enumeration

@@ -231,3 +231,14 @@ def test_multiwave_heap_arena_is_bit_identical(T, case):
     res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves="all")
     assert T.diff_intermediates(hb, res.debug, K, nsl) == []
     res.close(); db.close()
+
+
+@pytest.mark.parametrize("nc", [500, 900], ids=["8waves", "4waves"])
+def test_multiwave_heaps_with_fewer_waves_per_contig(T, nc):
+    """The launch gives a contig 16, 8 or 4 waves depending on how many contigs share the chip: the many-contig
+    variants (the small cases above all get 16)."""
+    api = T.api()
+    hb = T.synth(nc, 40, 77, dense=True, dup_every=4)
+    want = T.oracle_solve(hb, 8)
+    got = api.solve_batch(hb, max_paths=8, heap_waves="all")
+    assert T.diff_outputs(want, got) == []
