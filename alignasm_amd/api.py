@@ -48,7 +48,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_contig_costs", "aasm_partition_contigs", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_contig_costs", "aasm_partition_contigs", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
@@ -65,6 +65,19 @@ def set_host_threads(n):
 
 def device_count():
     return int(LIB.aasm_device_count())
+
+
+def sssp_dijkstra(g_voff, rowptr, col, w5, src, device=0):
+    """dijkstra() of the reference's solver (k_shortest_walks.hpp:69-87) on the GPU over a batch of graphs.
+    Returns (d: [V, 5] int64, prev: [V] int32)."""
+    g_voff = np.ascontiguousarray(g_voff, np.int64); rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int32); w5 = np.ascontiguousarray(w5, np.int64).reshape(-1); src = np.ascontiguousarray(src, np.int32)
+    VT = int(g_voff[-1])
+    d = np.zeros((VT, 5), np.int64)
+    prev = np.zeros(VT, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(LIB.aasm_sssp_dijkstra(C.c_int64(len(g_voff) - 1), P(g_voff), P(rowptr), P(col), P(w5), P(src), P(d), P(prev), int(device)))
+    return d, prev
 
 
 def debug_counter(name):

@@ -102,6 +102,87 @@ __global__ void __launch_bounds__(256) aasm_t1_predicates(const int64_t *a, cons
     out[i] = r;
 }
 
+// ---- generic SSSP: the solver's dijkstra() (k_shortest_walks.hpp:69-87) ------------------------------
+// The reference's CLI never reaches it (is_dag = true, paf_data.cpp:728: the shortest-path tree is the DAG
+// relaxation, K6), but the solver class offers it for graphs with cycles and BASELINE.json's north_star names it.
+// One wave per graph, wave-uniform control: a binary min-heap of (Distance, vertex) in global memory with the
+// reference's order (std::greater on std::pair: PafDistance operator< in CALC_SUM mode, then the vertex), lazy
+// deletion by `dv != d[v]` (operator==), strict `d[to] > dv + w` relaxation of the popped vertex's list in list
+// order (sequential: a list may name a vertex twice).  Results equal the reference's d[] and prev[] exactly.
+struct DjEnt { Dist d; int32_t v, p0, p1, p2; };
+__device__ __forceinline__ bool dj_ent_less(const DjEnt &a, const DjEnt &b) {       // std::pair<Distance, int64_t> operator<
+    if (dist_lt<CALC_SUM_MODE>(a.d, b.d)) return true;
+    if (dist_lt<CALC_SUM_MODE>(b.d, a.d)) return false;
+    return a.v < b.v;
+}
+__global__ void __launch_bounds__(64) aasm_sssp_dijkstra_kernel(int64_t n_graphs, const int64_t *voff, const int64_t *rowptr, const int32_t *col,
+                                                                const int64_t *w5, const int32_t *src, Dist *d, int32_t *prv, DjEnt *heap, const int64_t *hoff) {
+    const int64_t g = blockIdx.x;
+    if (g >= n_graphs) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t vb = voff[g], V = voff[g + 1] - vb;
+    Dist *dg = d + vb;
+    int32_t *pg = prv + vb;
+    DjEnt *H = heap + hoff[g];
+    for (int64_t v = lane; v < V; v += 64) { dg[v] = dist_max(); pg[v] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    int64_t n = 0;
+    const int64_t cap = hoff[g + 1] - hoff[g];
+    bool over = false;
+    auto push = [&](const Dist &dd, int32_t v) {
+        DjEnt x; x.d = dd; x.v = v; x.p0 = x.p1 = x.p2 = 0;
+        if (n >= cap) { over = true; return; }                       // more relaxations than edges: a cycle keeps improving the order (the reference would not return)
+        int64_t i = n++;
+        while (i > 0) {
+            const int64_t p = (i - 1) >> 1;
+            const DjEnt pe = H[p];
+            if (!uni(dj_ent_less(x, pe))) break;
+            if (lane == 0) H[i] = pe;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            i = p;
+        }
+        if (lane == 0) H[i] = x;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    };
+    const int32_t s = src[g];
+    if (lane == 0) dg[s] = dist_zero();                              // IDENTITY_DISTANCE (:74)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    push(dist_zero(), s);
+    while (n > 0 && !over) {
+        const DjEnt top = H[0];
+        const DjEnt x = H[--n];
+        if (n > 0) {                                                 // pop: the last entry sinks from the root
+            int64_t i = 0;
+            while (true) {
+                int64_t c = 2 * i + 1;
+                if (c >= n) break;
+                DjEnt ce = H[c];
+                if (c + 1 < n) { const DjEnt ce2 = H[c + 1]; if (uni(dj_ent_less(ce2, ce))) { ce = ce2; c++; } }
+                if (!uni(dj_ent_less(ce, x))) break;
+                if (lane == 0) H[i] = ce;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                i = c;
+            }
+            if (lane == 0) H[i] = x;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        const int32_t v = uni(top.v);
+        const Dist dv = uni(top.d);
+        if (!uni(dist_eq(dv, dg[v]))) continue;                      // :79 (operator!=)
+        for (int64_t e = rowptr[vb + v]; e < rowptr[vb + v + 1]; e++) {
+            const int32_t to = uni(col[e]);
+            Dist wd; wd.qry = w5[5 * e]; wd.ref = w5[5 * e + 1]; wd.anom = (int32_t)w5[5 * e + 2]; wd.qnz = (int32_t)w5[5 * e + 3]; wd.qtot = (int32_t)w5[5 * e + 4]; wd.pad = 0;
+            const Dist cand = uni(dist_add(dv, wd));
+            if (uni(dist_lt<CALC_SUM_MODE>(cand, dg[to]))) {         // d_[to] > dv + w (:81)
+                if (lane == 0) { dg[to] = cand; pg[to] = v; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                push(cand, to);
+            }
+        }
+    }
+    if (over && lane == 0) pg[s] = -2;                               // reported by the host entry
+}
+
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
 #define SCAN_TPB 256
 #define SCAN_IPT 8
@@ -348,6 +429,7 @@ struct GpuBackend {
 }  // namespace aasm
 
 using namespace aasm;
+static inline bool host_coord_ok(int64_t x) { return x >= 0 && x < AASM_COORD_LIMIT; }
 
 struct aasm_result {
     int device;
@@ -537,6 +619,63 @@ int aasm_debug_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t
     return AASM_OK;
 }
 
+// dijkstra (k_shortest_walks.hpp:69-87) over a batch of graphs; host pointers in and out
+int aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int64_t *w5,
+                       const int32_t *src, int64_t *d5, int32_t *prev, int device) {
+    if (n_graphs <= 0 || !g_voff || !rowptr || !col || !w5 || !src || !d5 || !prev) return AASM_E_INVAL;
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    hipSetDevice(device);
+    const int64_t VT = g_voff[n_graphs], ET = rowptr[VT];
+    if (VT <= 0 || g_voff[0] != 0 || rowptr[0] != 0) { set_last_error("inconsistent graph offsets"); return AASM_E_INVAL; }
+    std::vector<int64_t> hoff((size_t)n_graphs + 1, 0);
+    for (int64_t g = 0; g < n_graphs; g++) {
+        const int64_t v0 = g_voff[g], v1 = g_voff[g + 1];
+        if (v1 <= v0 || src[g] < 0 || src[g] >= v1 - v0) { set_last_error("graph " + std::to_string(g) + ": empty, or source outside it"); return AASM_E_INVAL; }
+        hoff[(size_t)g + 1] = hoff[(size_t)g] + (rowptr[v1] - rowptr[v0]) + 2;   // every successful relaxation pushes once: <= E + 1 entries
+        for (int64_t e = rowptr[v0]; e < rowptr[v1]; e++)
+            if (col[e] < 0 || col[e] >= v1 - v0) { set_last_error("graph " + std::to_string(g) + ": edge head outside the graph"); return AASM_E_INVAL; }
+    }
+    for (int64_t e = 0; e < ET; e++)
+        if (!(host_coord_ok(w5[5 * e] + AASM_COORD_LIMIT / 2) && host_coord_ok(w5[5 * e + 1] + AASM_COORD_LIMIT / 2)) || w5[5 * e + 2] < 0 || w5[5 * e + 2] > 2 || w5[5 * e + 3] < 0 || w5[5 * e + 3] > 1 ||
+            w5[5 * e + 4] < 0 || w5[5 * e + 4] > 1 || w5[5 * e] + w5[5 * e + 1] < 0) {
+            set_last_error("edge " + std::to_string(e) + ": weight outside the supported range (score sum >= 0, |scores| < 2^39, anom 0..2, mapq counts 0..1)");
+            return AASM_E_OVERFLOW;
+        }
+    std::vector<void *> dev;
+    bool ok = true;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *p, size_t bytes) -> void * {
+        void *q = nullptr;
+        if (!ok) return nullptr;
+        if ((e = hipMalloc(&q, bytes ? bytes : 8)) != hipSuccess) { ok = false; return nullptr; }
+        dev.push_back(q);
+        if (p && bytes && (e = hipMemcpy(q, p, bytes, hipMemcpyHostToDevice)) != hipSuccess) ok = false;
+        return q;
+    };
+    const int64_t *d_voff = (const int64_t *)up(g_voff, (size_t)(n_graphs + 1) * 8), *d_rowptr = (const int64_t *)up(rowptr, (size_t)(VT + 1) * 8);
+    const int32_t *d_col = (const int32_t *)up(col, (size_t)ET * 4), *d_src = (const int32_t *)up(src, (size_t)n_graphs * 4);
+    const int64_t *d_w = (const int64_t *)up(w5, (size_t)ET * 40), *d_hoff = (const int64_t *)up(hoff.data(), (size_t)(n_graphs + 1) * 8);
+    Dist *d_d = (Dist *)up(nullptr, (size_t)VT * sizeof(Dist));
+    int32_t *d_prv = (int32_t *)up(nullptr, (size_t)VT * 4);
+    DjEnt *d_heap = (DjEnt *)up(nullptr, (size_t)hoff[(size_t)n_graphs] * sizeof(DjEnt));
+    std::vector<Dist> hd((size_t)VT);
+    if (ok) {
+        hipLaunchKernelGGL(aasm_sssp_dijkstra_kernel, dim3((unsigned)n_graphs), dim3(64), 0, g_ctx[device].stream, n_graphs, d_voff, d_rowptr, d_col, d_w, d_src, d_d, d_prv, d_heap, d_hoff);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
+        if (e == hipSuccess) e = hipMemcpy(hd.data(), d_d, (size_t)VT * sizeof(Dist), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(prev, d_prv, (size_t)VT * 4, hipMemcpyDeviceToHost);
+        ok = e == hipSuccess;
+    }
+    for (void *q : dev) hipFree(q);
+    if (!ok) { set_last_error(hip_err("aasm_sssp_dijkstra", e)); return e == hipErrorOutOfMemory ? AASM_E_NOMEM : AASM_E_HIP; }
+    for (int64_t g = 0; g < n_graphs; g++)
+        if (prev[g_voff[g] + src[g]] == -2) { set_last_error("graph " + std::to_string(g) + ": dijkstra does not terminate (a cycle that keeps improving the distance order)"); return AASM_E_INTERNAL; }
+    for (int64_t v = 0; v < VT; v++) { d5[5 * v] = hd[(size_t)v].qry; d5[5 * v + 1] = hd[(size_t)v].ref; d5[5 * v + 2] = hd[(size_t)v].anom; d5[5 * v + 3] = hd[(size_t)v].qnz; d5[5 * v + 4] = hd[(size_t)v].qtot; }
+    return AASM_OK;
+}
+
 int64_t aasm_debug_counter(const char *name) {
     if (!name) return -1;
     const std::string n(name);
@@ -675,7 +814,6 @@ static void concat_parts(std::vector<aasm_batch_out> &parts, const std::vector<i
     }
 }
 
-static inline bool host_coord_ok(int64_t x) { return x >= 0 && x < AASM_COORD_LIMIT; }
 static int validate_batch(const aasm_batch_in *in) {
     if (!in || in->n_contigs <= 0 || !in->ctg_rec_off || in->ctg_rec_off[0] != 0 || in->ctg_rec_off[in->n_contigs] != in->n_records) {
         set_last_error("inconsistent contig offsets");

@@ -186,6 +186,15 @@ int  aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int 
 int  aasm_contig_costs(const aasm_batch_in *in, double *cost);
 int  aasm_partition_contigs(const aasm_batch_in *in, int n_shards, int64_t *cuts);
 
+/* The solver's generic single-source shortest paths, dijkstra() (src/k_shortest_walks.hpp:69-87), over a batch of
+ * graphs that may contain cycles: graph g owns vertices [g_voff[g], g_voff[g+1]) (local ids 0..), rowptr is one CSR
+ * row-pointer array over all vertices, col holds LOCAL head ids, w5 five int64 per edge {qry_score, ref_score, anom,
+ * qul_nonzero, qul_total}, src the local source per graph.  d5 (5 int64 per vertex; unreachable = PafDistance::max()
+ * = {-1,-1,-1,-1,0}) and prev (-1 = none) are exactly the reference's return values.  The reference's CLI never
+ * calls dijkstra (is_dag = true, paf_data.cpp:728); this entry exists because the solver class offers it.  */
+int  aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int64_t *w5,
+                        const int32_t *src, int64_t *d5, int32_t *prev, int device);
+
 /* Same, with the batch already resident in device memory (in->pointers are device
  * pointers; in->ctg_rec_off / rec_rng_off too).  `stream` is a hipStream_t (or NULL).
  * The device result stays resident in an opaque handle until fetched/freed.          */

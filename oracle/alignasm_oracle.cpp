@@ -1048,6 +1048,44 @@ void oracle_std_sort_perm(const int64_t *qs, const int64_t *qe, int64_t n, int32
     for (int64_t i = 0; i < n; i++) perm[i] = v[i].ctg_index;
 }
 
+// dijkstra (k_shortest_walks.hpp:69-87) restated: std::priority_queue of (Distance, vertex) with std::greater,
+// lazy deletion by `dv != d[v]`, strict `d[to] > dv + w` relaxation in list order.  Dead code from the reference's
+// CLI (is_dag = true, paf_data.cpp:728); north_star names it, so the product carries a device version
+// (aasm_sssp_dijkstra) and this is its checker.  Pinned to the real header by tests/test_dijkstra.py.
+int64_t oracle_generic_dijkstra(int64_t n, const int64_t *rowptr, const int64_t *col, const int64_t *w, int64_t src, int64_t *d_out, int64_t *prv_out) {
+    std::vector<Dist> d((size_t)n, dist_max());
+    std::vector<int64_t> prv((size_t)n, -1);
+    struct Ent { Dist d; int64_t v; };
+    auto ent_lt = [](const Ent &a, const Ent &b) {                  // std::pair operator<
+        if (d_lt(a.d, b.d, CALC_SUM_MODE)) return true;
+        if (d_lt(b.d, a.d, CALC_SUM_MODE)) return false;
+        return a.v < b.v;
+    };
+    auto cmp = [&](const Ent &a, const Ent &b) { return ent_lt(b, a); };   // std::greater
+    std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> heap(cmp);
+    d[(size_t)src] = Dist{};
+    heap.push(Ent{Dist{}, src});
+    while (!heap.empty()) {
+        const Ent top = heap.top();
+        heap.pop();
+        if (!d_eq(top.d, d[(size_t)top.v])) continue;               // :79
+        for (int64_t e = rowptr[top.v]; e < rowptr[top.v + 1]; e++) {
+            const int64_t to = col[e];
+            const Dist cand = d_add(top.d, Dist{w[5 * e], w[5 * e + 1], w[5 * e + 2], w[5 * e + 3], w[5 * e + 4]});
+            if (d_lt(cand, d[(size_t)to], CALC_SUM_MODE)) {          // d_[to] > dv + w (:81)
+                d[(size_t)to] = cand;
+                heap.push(Ent{cand, to});
+                prv[(size_t)to] = top.v;
+            }
+        }
+    }
+    for (int64_t v = 0; v < n; v++) {
+        d_out[5 * v] = d[(size_t)v].qry; d_out[5 * v + 1] = d[(size_t)v].ref; d_out[5 * v + 2] = d[(size_t)v].anom; d_out[5 * v + 3] = d[(size_t)v].qnz; d_out[5 * v + 4] = d[(size_t)v].qtot;
+        prv_out[v] = prv[(size_t)v];
+    }
+    return n;
+}
+
 // K1 / K2 predicates and the PafOutputData constructor exposed for truth tables against the
 // real header (oracle/ref_harness.cpp: ref_read_lt, ref_qry_contains, ref_qry_partial_overlap,
 // ref_output_from_read).

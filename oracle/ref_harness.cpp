@@ -213,6 +213,19 @@ int64_t ref_generic_arena_inversions(void) {
     return inv;
 }
 
+// ---- the generic SSSP of the solver (k_shortest_walks.hpp:69-87), which the CLI never reaches (is_dag = true,
+// paf_data.cpp:728) but BASELINE.json's north_star names: the REAL dijkstra() on a caller-supplied graph.
+// d_out: 5 int64 per vertex, prv_out: 1 per vertex.
+int64_t ref_generic_dijkstra(int64_t n, const int64_t *rowptr, const int64_t *col, const int64_t *w, int64_t src, int64_t *d_out, int64_t *prv_out) {
+    G g(n);
+    for (int64_t u = 0; u < n; u++)
+        for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) add_edge(g, u, col[e], mk(w + 5 * e));
+    Solver s(g, PafDistance::max(), PafDistance(true), false, false);
+    auto res = s.dijkstra(g, src);
+    for (int64_t v = 0; v < n; v++) { put(d_out + 5 * v, res.first[v]); prv_out[v] = res.second[v]; }
+    return n;
+}
+
 // ---- K1 / K2 pieces that are header-only in the reference (paf_data.hpp:69-86,101-104) ----
 // The sort is driven exactly as paf_data.cpp:232,241 drive it: a copy of the contig's
 // std::vector<PafReadData> (the full 200-byte struct with its strings and range vectors, so

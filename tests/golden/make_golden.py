@@ -103,6 +103,14 @@ def ref_algos():
         a, b = np.ascontiguousarray(ta[i]), np.ascontiguousarray(tb[i])
         res[i] = R.ref_dist_lt(P(a), P(b), 0) | (R.ref_dist_lt(P(a), P(b), 1) << 1) | (R.ref_dist_eq(P(a), P(b)) << 2)
     out["t1_a"], out["t1_b"], out["t1_res"] = ta, tb, res
+    # *J: the REAL dijkstra() (k_shortest_walks.hpp:69-87) on digraphs with cycles / parallel edges
+    from test_dijkstra import cases as dj_cases, run as dj_run
+    djs = dj_cases()
+    out["n_dj"] = np.array([len(djs)])
+    for i, (n, rp, col, w, src) in enumerate(djs):
+        d, prv = dj_run(R, "ref_", n, rp, col, w, src)
+        out[f"dj{i}_meta"] = np.array([n, src], np.int64)
+        out[f"dj{i}_rowptr"], out[f"dj{i}_col"], out[f"dj{i}_w"], out[f"dj{i}_d"], out[f"dj{i}_prv"] = rp, col, w, d, prv
     np.savez_compressed(os.path.join(HERE, "ref_algos.npz"), **out)
     print("ref_algos.npz:", len(graphs), "graphs,", len(cases), "sorts,", len(tab), "predicate rows")
 
