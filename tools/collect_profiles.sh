@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards).
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+set -o pipefail
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 3 > $O/${TAG}_c3_bench.json 2> $O/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_c3_bench_under_rocprof.json 2> $O/kt.err || exit 1
+cp $O/kt/*/*kernel_stats.csv $O/${TAG}_c3_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_fetch.err || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_write.err || exit 1
+python3 $R/tools/pmc_summary.py $O/${TAG}_c3_pmc_fetch_write.json $O/pmc_fetch $O/pmc_write
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_sq.err || exit 1
+python3 $R/tools/pmc_summary.py $O/${TAG}_c3_pmc_sq.json $O/pmc_sq
+python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --cpu-sample 200 > $O/${TAG}_c5_bench_1gpu_share.json 2> $O/c5.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -- python3 $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/kt5.err || exit 1
+cp $O/kt5/*/*kernel_stats.csv $O/${TAG}_c5_kernel_stats.csv
+for n in 250 625 1000 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
+python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --dup 3 --shuffle 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_dup3_shuffled.json
+python3 $R/tools/phase_probe.py --contigs 1000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_1000contigs.json
+rm -rf $O/kt $O/kt5 $O/pmc_fetch $O/pmc_write $O/pmc_sq
+ls -la $O
