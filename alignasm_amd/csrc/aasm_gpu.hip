@@ -420,7 +420,7 @@ struct GpuBackend {
     }
     // second stream: fork = side waits for the main stream's work so far; join = main waits for side
     void fork() { if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
-    void use_side(bool on) { if (std::getenv("AASM_NO_SIDE")) return; on_side = on; stream = on ? cx.side : main_stream; }
+    void use_side(bool on) { on_side = on; stream = on ? cx.side : main_stream; }
     void join() { if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
     void phase_begin(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_b[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); phase_used[ph] = true; } }
     void phase_end(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_e[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); } }

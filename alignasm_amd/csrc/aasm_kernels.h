@@ -49,7 +49,8 @@ struct WS {
     int32_t *ctgV, *v_i, *v_j, *v_ctg;
     int64_t *voff, *v_slot;
     // ---- forward CSR + reversed CSR
-    int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e, *r_src, *tmp_a, *tmp_b;
+    int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e, *tmp_a;
+    I4 *tmp_pk;                          // rank-sort scratch of the packed in-edge records (rows longer than 32)
     int64_t *rowptr, *e_wq, *rptr;
     uint8_t *e_fl;
     // ---- sweeps
@@ -107,8 +108,9 @@ struct WS {
     int32_t *mw_order, *mw_rs, *mw_fb;   // per BFS position: vertex, region start, final base
     int32_t *mw_rsv, *mw_used;           // per vertex: region start, nodes used
     I4 *tnx;                             // next four vertices along best[] (path recovery reads one record per four tree edges)
-    I4 *rvh;                             // K6: per-vertex in-list header, 4 words (see kb_rev_hdr)
-    I4 *fvh;                             // K5: per-vertex out-list header, 2 words: {row start (2), degree, col0} {flags0, col1, flags1, -}
+    I4 *rvh;                             // K6: per-vertex in-list header, 3 words (see kb_rev_hdr)
+    I4 *r_pk;                            // K6: one packed record per in-edge, in in-list order
+    I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_N };
@@ -953,6 +955,11 @@ AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 
 // reversed CSR (k_shortest_walks.hpp:180-183): in-list of v = its in-edges in ascending
 // (source id, list position) = ascending contig-local edge id.
 // ====================================================================================
+// one in-edge as the sweeps read it: {source, qry weight (2 words), ref weight | flags << 24}
+AASM_DEV I4 pack_in_edge(int32_t srcv, int64_t wq, int32_t wr, uint8_t fl) {
+    I4 r; r.x = srcv; r.y = (int32_t)(uint32_t)(uint64_t)wq; r.z = (int32_t)((uint64_t)wq >> 32); r.w = (wr & 0xffffff) | ((int32_t)fl << 24);   // 0 <= wr <= SV_BASELINE < 2^24
+    return r;
+}
 AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread per vertex (row loop)
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
@@ -962,21 +969,24 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
         const int64_t tv = vb + w.e_col[e];
         const int64_t pos = w.rptr[tv] + atomic_add(&w.rcur[tv], (int32_t)1);
         w.r_e[pos] = (int32_t)(e - e_base);
-        w.r_src[pos] = u;
+        w.r_pk[pos] = pack_in_edge(u, w.e_wq[e], w.e_wr[e], w.e_fl[e]);
     }
 }
 
 // sort every row of (key, payload) ascending by key; keys inside a row are distinct.
 // Lanes insertion-sort their own short rows; long rows are rank-sorted by the whole wave
 // through the tmp arrays.
-AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, int32_t *pay, int64_t nrows) {
+template <class P>
+AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows) {
     const int64_t row = k.bid * AASM_WAVE + k.lane;
     const bool act = row < nrows;
     const int64_t p0 = act ? ptr[row] : 0, L = act ? ptr[row + 1] - p0 : 0;
     const bool big = L > 32;
     if (act && !big) {
         for (int64_t a = 1; a < L; a++) {
-            const int32_t kx = key[p0 + a], px = pay ? pay[p0 + a] : 0;
+            const int32_t kx = key[p0 + a];
+            P px = P();
+            if (pay) px = pay[p0 + a];
             int64_t t = a - 1;
             while (t >= 0 && key[p0 + t] > kx) { key[p0 + t + 1] = key[p0 + t]; if (pay) pay[p0 + t + 1] = pay[p0 + t]; t--; }
             key[p0 + t + 1] = kx; if (pay) pay[p0 + t + 1] = px;
@@ -992,10 +1002,10 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
             int64_t rank = 0;
             for (int64_t t = 0; t < QL; t++) rank += key[q0 + t] < kx ? 1 : 0;
             w.tmp_a[q0 + rank] = kx;
-            if (pay) w.tmp_b[q0 + rank] = pay[q0 + a];
+            if (pay) tmp_pay[q0 + rank] = pay[q0 + a];
         }
         wave_fence();
-        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) { key[q0 + a] = w.tmp_a[q0 + a]; if (pay) pay[q0 + a] = w.tmp_b[q0 + a]; }
+        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) { key[q0 + a] = w.tmp_a[q0 + a]; if (pay) pay[q0 + a] = tmp_pay[q0 + a]; }
         wave_fence();
     }
 }
@@ -1009,56 +1019,50 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
 // without any extra key: targets inside one in-list are distinct, so the 64 lanes relax a
 // whole in-list at once; newly free vertices are appended in list order by ballot+prefix.
 //
-// The sweep is a chain of dependent memory round trips per popped vertex, so the data is laid
-// out to shorten the chain: kb_rev_hdr (thread per vertex) packs {in-list start, in-degree} and
-// the first TWO in-edges with their weights (the mean in-degree is ~2) into 64 bytes that are
-// read together with d[v]; the queue's front window lives in LDS.  That leaves three trips per
-// pop: {header, d[v]} -> {d[u], cnt[u]} -> the stores becoming visible.
+// The sweep is a chain of dependent steps per popped vertex, and at 5 000 resident waves the chip is bound by
+// instruction issue (profiles/r02_c3_pmc_sq.json), so a pop is written to cost few instructions and one memory
+// round trip:
+//  * every in-edge is ONE 16-byte record {source, qry weight (2 words), ref weight | flags << 24} (r_pk: written by
+//    kb_rev_fill, put in in-list order by kb_sort_rows), and kb_rev_hdr packs per vertex {in-list start,
+//    in-degree} plus its first two records (the mean in-degree is ~2) into 48 bytes (rvh);
+//  * the queue's front window lives in LDS, and an entry carries the vertex's 48-byte header and its final
+//    distance - both are known to the lane that appends the vertex (it fetched the header together with its
+//    relax loads) - so a pop reads nothing from global memory;
+//  * the lanes work on the entry directly (lane t takes in-edge t: its record straight from LDS): nothing is
+//    broadcast into scalar registers except the in-degree.
 #define REVQ_N 32
-#define AASM_REV_LDS_BYTES (REVQ_N * 100)
+struct RevEnt { I4 hdr; Dist d; I4 rec[2]; };                        // hdr = {in-list start (2 words), in-degree, vertex}
+struct RevQ { RevEnt e[REVQ_N]; };
+#define AASM_REV_LDS_BYTES (REVQ_N * 80)
+static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
-    const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
     const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
-    I4 h[4];
-    for (int t = 0; t < 4; t++) { h[t].x = h[t].y = h[t].z = h[t].w = 0; }
+    I4 h[3];
+    for (int t = 0; t < 3; t++) { h[t].x = h[t].y = h[t].z = h[t].w = 0; }
     h[0].x = (int32_t)(uint32_t)(uint64_t)r0; h[0].y = (int32_t)((uint64_t)r0 >> 32); h[0].z = (int32_t)(r1 - r0);
-    if (r1 > r0) {
-        const int64_t e = e_base + w.r_e[r0], wq = w.e_wq[e];
-        h[0].w = w.r_src[r0];
-        h[1].x = (int32_t)(uint32_t)(uint64_t)wq; h[1].y = (int32_t)((uint64_t)wq >> 32); h[1].z = w.e_wr[e]; h[1].w = w.e_fl[e];
-    }
-    if (r1 > r0 + 1) {
-        const int64_t e = e_base + w.r_e[r0 + 1], wq = w.e_wq[e];
-        h[2].x = w.r_src[r0 + 1]; h[2].y = (int32_t)(uint32_t)(uint64_t)wq; h[2].z = (int32_t)((uint64_t)wq >> 32); h[2].w = w.e_wr[e];
-        h[3].x = w.e_fl[e];
-    }
-    for (int t = 0; t < 4; t++) w.rvh[4 * gv + t] = h[t];
-    // the same for the forward sweep: row start, out-degree and the first two out-edges (head, anomaly weight)
+    if (r1 > r0) h[1] = w.r_pk[r0];                                   // (kb_rev_fill packed the records, kb_sort_rows put them in list order)
+    if (r1 > r0 + 1) h[2] = w.r_pk[r0 + 1];
+    for (int t = 0; t < 3; t++) w.rvh[3 * gv + t] = h[t];
+    // the same for the forward sweep: {row start (2 words), out-degree, -} {-, head 0, head 1, anomaly weight 0 | weight 1 << 8}
     const int64_t o0 = w.rowptr[gv], o1 = w.rowptr[gv + 1];
     I4 f0, f1;
-    f0.x = (int32_t)(uint32_t)(uint64_t)o0; f0.y = (int32_t)((uint64_t)o0 >> 32); f0.z = (int32_t)(o1 - o0); f0.w = (o1 > o0) ? w.e_col[o0] : 0;
-    f1.x = (o1 > o0) ? (w.e_fl[o0] & 3) : 0; f1.y = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0; f1.z = (o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0; f1.w = 0;
+    f0.x = (int32_t)(uint32_t)(uint64_t)o0; f0.y = (int32_t)((uint64_t)o0 >> 32); f0.z = (int32_t)(o1 - o0); f0.w = 0;
+    f1.x = 0; f1.y = (o1 > o0) ? w.e_col[o0] : 0; f1.z = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0;
+    f1.w = ((o1 > o0) ? (w.e_fl[o0] & 3) : 0) | (((o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0) << 8);
     w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
 }
 
-// LDS queue window of the reverse sweep: besides the vertex, an entry carries the vertex's
-// in-list header and its final distance.  Both are known when the vertex is appended (the header
-// is static and was fetched together with the relax loads, the distance is the value the
-// appending lane has just computed or read), so a pop finds everything in LDS and the only
-// memory round trip left per pop is {d[u], cnt[u], header[u]} of its in-neighbours.
-struct RevQ { int32_t v[REVQ_N]; I4 h[REVQ_N][4]; Dist d[REVQ_N]; };
-static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
-    const int64_t vb = w.voff[c], e_base = w.rowptr[vb];
+    const int64_t vb = w.voff[c];
     RevQ *Q = (RevQ *)k.lds;                                         // queue positions [head, lds_hi)
     Dist *d = w.sp_d + vb;
     int32_t *best = w.sp_best + vb, *q = w.rev_order + vb, *cnt = w.cnt_tmp + vb;
-    const I4 *rvh = w.rvh + 4 * vb;
+    const I4 *rvh = w.rvh + 3 * vb;
     const int32_t dest = (int32_t)(V - 1);
     int32_t tail = 0, lds_hi = 0;
     for (int64_t base = 0; base < V; base += AASM_WAVE) {          // init + sources in ascending id (:139-141)
@@ -1078,7 +1082,7 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
         const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
         if (z) {
             q[at] = (int32_t)v;
-            if (at < REVQ_N) { Q->v[at] = (int32_t)v; for (int t = 0; t < 4; t++) Q->h[at][t] = rvh[4 * v + t]; Q->d[at] = dv0; }
+            if (at < REVQ_N) { RevEnt *E = &Q->e[at]; I4 hd = rvh[3 * v]; hd.w = (int32_t)v; E->hdr = hd; E->d = dv0; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
         }
         tail += popc64(m);
     }
@@ -1087,40 +1091,42 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     wave_lds_sync();
     int32_t head = 0;
     while (head < tail) {
-        int32_t v;
-        I4 h0, h1, h2, h3;
-        Dist dv;
-        if (head < lds_hi) {
-            const int32_t sl = head & (REVQ_N - 1);
-            v = uni(Q->v[sl]); h0 = uni(Q->h[sl][0]); h1 = uni(Q->h[sl][1]); h2 = uni(Q->h[sl][2]); h3 = uni(Q->h[sl][3]); dv = uni(Q->d[sl]);
-        } else {
-            v = uni(q[head]);
-            h0 = uni(rvh[4 * v]); h1 = uni(rvh[4 * v + 1]); h2 = uni(rvh[4 * v + 2]); h3 = uni(rvh[4 * v + 3]); dv = uni(d[v]);
+        RevEnt *E = &Q->e[head & (REVQ_N - 1)];
+        if (head >= lds_hi) {                                        // beyond the LDS window (wide frontiers): bring the entry in
+            const int32_t v = uni(q[head]);
+            if (k.lane == 0) { I4 hd = rvh[3 * v]; hd.w = v; E->hdr = hd; E->d = d[v]; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
+            wave_lds_sync();
         }
         head++;
-        const bool reach = !dist_is_max(dv);                         // :166
-        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)h0.y << 32) | (uint32_t)h0.x);
-        const int32_t deg = h0.z;
+        const I4 hd = E->hdr;
+        const Dist dv = E->d;
+        const int32_t deg = uni(hd.z), v = hd.w;
+        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)hd.y << 32) | (uint32_t)hd.x);
+        const bool reach = dv.anom >= 0;                             // max() is the only distance with a negative anom here (:166)
         for (int32_t base = 0; base < deg; base += AASM_WAVE) {
             const int32_t t = base + k.lane;
             const bool act = t < deg;
             bool z = false;
             int32_t u = 0;
-            I4 uh0, uh1, uh2, uh3;
+            I4 uh0, uh1, uh2;
             Dist du = dist_max();
-            uh0.x = uh0.y = uh0.z = uh0.w = 0; uh1 = uh0; uh2 = uh0; uh3 = uh0;
+            uh0.x = uh0.y = uh0.z = uh0.w = 0; uh1 = uh0; uh2 = uh0;
             if (act) {
-                int64_t wq; int32_t wr; uint8_t fl;
-                if (t == 0) { u = h0.w; wq = (int64_t)(((uint64_t)(uint32_t)h1.y << 32) | (uint32_t)h1.x); wr = h1.z; fl = (uint8_t)h1.w; }
-                else if (t == 1) { u = h2.x; wq = (int64_t)(((uint64_t)(uint32_t)h2.z << 32) | (uint32_t)h2.y); wr = h2.w; fl = (uint8_t)h3.x; }
-                else { const int64_t p = r0 + t; u = w.r_src[p]; const int64_t e = e_base + w.r_e[p]; wq = w.e_wq[e]; wr = w.e_wr[e]; fl = w.e_fl[e]; }
+                const I4 rc = (t < 2) ? E->rec[t] : w.r_pk[r0 + t];
+                u = rc.x;
+                Dist wd;
+                wd.qry = (int64_t)(((uint64_t)(uint32_t)rc.z << 32) | (uint32_t)rc.y); wd.ref = rc.w & 0xffffff;
+                const int32_t fl = (int32_t)((uint32_t)rc.w >> 24);
+                wd.anom = fl & 3; wd.qnz = (fl >> 2) & 1; wd.qtot = (fl >> 3) & 1; wd.pad = 0;
                 du = d[u];
                 const int32_t left = cnt[u] - 1;
-                uh0 = rvh[4 * u]; uh1 = rvh[4 * u + 1]; uh2 = rvh[4 * u + 2]; uh3 = rvh[4 * u + 3];     // in case u becomes free now
-                if (reach) {
-                    const Dist cand = dist_add(dv, edge_dist(wq, wr, fl));
-                    if (dist_lt<CALC_SUM_MODE>(cand, du)) { du = cand; d[u] = cand; best[u] = v; }   // :168-171
-                }
+                uh0 = rvh[3 * u]; uh1 = rvh[3 * u + 1]; uh2 = rvh[3 * u + 2];   // in case u becomes free now
+                const Dist cand = dist_add(dv, wd);
+                // cand < d[u] (:168): d[u] is max() (anom < 0) or a real distance; cand is a real distance
+                const int64_t sc = cand.qry + cand.ref, su = du.qry + du.ref;
+                const int32_t tc = cand.qtot ? cand.qtot : 1, tu = du.qtot ? du.qtot : 1;
+                const bool better = reach & ((du.anom < 0) | (sc < su) | ((sc == su) & ((cand.anom < du.anom) | ((cand.anom == du.anom) & ((int64_t)cand.qnz * tu > (int64_t)du.qnz * tc)))));
+                if (better) { du = cand; d[u] = cand; best[u] = v; }                  // :168-171
                 cnt[u] = left;
                 z = left == 0;
             }
@@ -1128,13 +1134,10 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
             const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
             if (z) {
                 q[at] = u;
-                if (lds_hi == tail && at - head < REVQ_N) {
-                    const int32_t sl = at & (REVQ_N - 1);
-                    Q->v[sl] = u; Q->h[sl][0] = uh0; Q->h[sl][1] = uh1; Q->h[sl][2] = uh2; Q->h[sl][3] = uh3; Q->d[sl] = du;
-                }
+                if (lds_hi == tail && at - head < REVQ_N - 1) { RevEnt *N = &Q->e[at & (REVQ_N - 1)]; uh0.w = u; N->hdr = uh0; N->d = du; N->rec[0] = uh1; N->rec[1] = uh2; }
             }
             const int32_t nnew = popc64(m);
-            if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
+            if (lds_hi == tail) { int32_t room = REVQ_N - 1 - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }   // (the slot of the entry at hand stays untouched)
             tail += nnew;
         }
         wave_fence();
@@ -1146,9 +1149,10 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
 // forward Kahn order (paf_data.cpp:742-746) + anomaly distance to dest.  The reference
 // runs Dial's bucketed BFS on the 0/1/2 anomaly weights (k_weighted_bfs.hpp:16-37) and
 // keeps only anom_dis[dest] (paf_data.cpp:715,1615); on a DAG the same scalar is the
-// min-plus DP along the topological order, folded into this sweep.
-#define AASM_FWD_LDS_BYTES (REVQ_N * 40)
-struct FwdQ { int32_t v[REVQ_N], an[REVQ_N]; I4 f[REVQ_N][2]; };       // same idea as RevQ: out-list header + final anomaly distance
+// min-plus DP along the topological order, folded into this sweep.  Same shape as the reverse sweep.
+struct FwdEnt { I4 a, b; };                                          // a = {row start (2 words), out-degree, vertex}, b = {anomaly distance, head 0, head 1, weights}
+struct FwdQ { FwdEnt e[REVQ_N]; };
+#define AASM_FWD_LDS_BYTES (REVQ_N * 32)
 static_assert(sizeof(FwdQ) <= AASM_FWD_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
@@ -1170,7 +1174,7 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
         if (z) {
             const int32_t t = tail + popc64(m & lanemask_lt(k.lane));
             q[t] = (int32_t)v; pos[v] = t;
-            if (t < REVQ_N) { Q->v[t] = (int32_t)v; Q->an[t] = a0; Q->f[t][0] = fvh[2 * v]; Q->f[t][1] = fvh[2 * v + 1]; }
+            if (t < REVQ_N) { I4 fa = fvh[2 * v], fb = fvh[2 * v + 1]; fa.w = (int32_t)v; fb.x = a0; Q->e[t].a = fa; Q->e[t].b = fb; }
         }
         tail += popc64(m);
     }
@@ -1179,36 +1183,32 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
     wave_lds_sync();
     int32_t head = 0;
     while (head < tail) {
-        int32_t u, au;
-        I4 f0, f1;
-        if (head < lds_hi) {
-            const int32_t sl = head & (REVQ_N - 1);
-            u = uni(Q->v[sl]); au = uni(Q->an[sl]); f0 = uni(Q->f[sl][0]); f1 = uni(Q->f[sl][1]);
-        } else {
-            u = uni(q[head]); au = uni(an[u]); f0 = uni(fvh[2 * u]); f1 = uni(fvh[2 * u + 1]);
+        FwdEnt *E = &Q->e[head & (REVQ_N - 1)];
+        if (head >= lds_hi) {
+            const int32_t u = uni(q[head]);
+            if (k.lane == 0) { I4 fa = fvh[2 * u], fb = fvh[2 * u + 1]; fa.w = u; fb.x = an[u]; E->a = fa; E->b = fb; }
+            wave_lds_sync();
         }
         head++;
-        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)f0.y << 32) | (uint32_t)f0.x);
-        const int32_t deg = f0.z;
+        const I4 fa = E->a, fb = E->b;
+        const int32_t deg = uni(fa.z), au = fb.x;
+        const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)fa.y << 32) | (uint32_t)fa.x);
         for (int32_t base = 0; base < deg; base += AASM_WAVE) {
             const int32_t t = base + k.lane;
             const bool act = t < deg;
             bool z = false;
             int32_t v = 0, av = -1;
-            I4 vf0, vf1;
-            vf0.x = vf0.y = vf0.z = vf0.w = 0; vf1 = vf0;
+            I4 va, vbb;
+            va.x = va.y = va.z = va.w = 0; vbb = va;
             if (act) {
                 int32_t wa;
-                if (t == 0) { v = f0.w; wa = f1.x; }
-                else if (t == 1) { v = f1.y; wa = f1.z; }
+                if (t < 2) { v = t == 0 ? fb.y : fb.z; wa = (fb.w >> (8 * t)) & 3; }
                 else { v = w.e_col[r0 + t]; wa = w.e_fl[r0 + t] & 3; }
                 av = an[v];
                 const int32_t left = cnt[v] - 1;
-                vf0 = fvh[2 * v]; vf1 = fvh[2 * v + 1];                // in case v becomes free now
-                if (au >= 0) {
-                    const int32_t nd = au + wa;
-                    if (av < 0 || nd < av) { av = nd; an[v] = nd; }
-                }
+                va = fvh[2 * v]; vbb = fvh[2 * v + 1];                // in case v becomes free now
+                const int32_t nd = au + wa;
+                if ((au >= 0) & ((av < 0) | (nd < av))) { av = nd; an[v] = nd; }
                 cnt[v] = left;
                 z = left == 0;
             }
@@ -1216,10 +1216,10 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
             const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
             if (z) {
                 q[at] = v; pos[v] = at;
-                if (lds_hi == tail && at - head < REVQ_N) { const int32_t sl = at & (REVQ_N - 1); Q->v[sl] = v; Q->an[sl] = av; Q->f[sl][0] = vf0; Q->f[sl][1] = vf1; }
+                if (lds_hi == tail && at - head < REVQ_N - 1) { FwdEnt *N = &Q->e[at & (REVQ_N - 1)]; va.w = v; vbb.x = av; N->a = va; N->b = vbb; }
             }
             const int32_t nnew = popc64(m);
-            if (lds_hi == tail) { int32_t room = REVQ_N - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
+            if (lds_hi == tail) { int32_t room = REVQ_N - 1 - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
             tail += nnew;
         }
         wave_fence();

@@ -42,13 +42,13 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_COUNT: kb_row_count(k, w); break;
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
-        case KN_SORT_ROWS_REV: kb_sort_rows(k, w, w.rptr, w.r_e, w.r_src, w.VT); break;
+        case KN_SORT_ROWS_REV: kb_sort_rows<I4>(k, w, w.rptr, w.r_e, w.r_pk, w.tmp_pk, w.VT); break;
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep(k, w); break;
         case KN_FWD_SWEEP: kb_fwd_sweep(k, w); break;
         case KN_CHILD_COUNT: kb_child_count(k, w); break;
         case KN_CHILD_FILL: kb_child_fill(k, w); break;
-        case KN_SORT_ROWS_CHILD: kb_sort_rows(k, w, w.cptr, w.cval, nullptr, w.VT); break;
+        case KN_SORT_ROWS_CHILD: kb_sort_rows<int32_t>(k, w, w.cptr, w.cval, (int32_t *)nullptr, (int32_t *)nullptr, w.VT); break;
         case KN_HEAP_CAP: kb_heap_cap(k, w); break;
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
@@ -189,12 +189,12 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // ---- reversed CSR
         be.phase_begin(AASM_PH_REVCSR);
         A(rptr, int64_t, VT + 1, "rptr"); AZ(rcur, int32_t, VT, "rcur");
-        A(r_e, int32_t, ET, "r_e"); A(r_src, int32_t, ET, "r_src"); A(tmp_a, int32_t, ET > VT ? ET : VT, "tmp_a"); A(tmp_b, int32_t, ET > VT ? ET : VT, "tmp_b");
+        A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_a, int32_t, ET > VT ? ET : VT, "tmp_a"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
         be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
         be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
-        A(rvh, I4, 4 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
+        A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
         CHECK_ALLOC();
         be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
