@@ -184,6 +184,7 @@ template <class P> AASM_DEV uint64_t wave_index_mask(int n, int lane, P pred) {
 #endif
 }
 
+AASM_DEV bool wave_any(bool p) { return wave_ballot(p) != 0; }
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 
 // inclusive wave scans (Hillis-Steele over 64 lanes; identity with one lane)

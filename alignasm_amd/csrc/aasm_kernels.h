@@ -1052,59 +1052,75 @@ AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread pe
     f1.x = 0; f1.y = (o1 > o0) ? w.e_col[o0] : 0; f1.z = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0;
     f1.w = ((o1 > o0) ? (w.e_fl[o0] & 3) : 0) | (((o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0) << 8);
     w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
+    // the sweeps' per-vertex state (:139-141, paf_data.cpp:704-713): pending degrees, d = max() except d[dest] = 0, no best edge; anomaly distance -1 except src = 0
+    const int64_t vend = w.voff[w.v_ctg[gv] + 1];                    // dest = vend - 1, src = vend - 2
+    w.cnt_tmp[gv] = (int32_t)(o1 - o0);
+    w.cnt_tmp2[gv] = (int32_t)(r1 - r0);
+    w.sp_d[gv] = (gv == vend - 1) ? dist_zero() : dist_max();
+    w.sp_best[gv] = -1;
+    w.an[gv] = (gv == vend - 2) ? 0 : -1;
 }
 
+// Contigs per wave: the graphs are long chains (~1.4 vertices per Kahn level, in-degree ~2), so a wave that
+// holds ONE contig issues every instruction of a pop for two busy lanes, and at 5 000 contigs the sweeps were
+// bound by instruction issue.  A wave therefore carries AASM_WAVE / G contigs, G lanes each (G = 16 for sparse
+// batches, 64 for dense ones: aasm_pipeline.h picks by mean degree): what used to be wave-uniform (queue head
+// and tail, the popped vertex) is uniform per lane group and lives in vector registers; ballots are cut to the
+// group's bits.
+#define AASM_SWEEP_G (AASM_WAVE >= 16 ? 16 : 1)
+template <int G> struct SweepGrp {
+    static constexpr int N = AASM_WAVE / G;                          // contigs per wave
+    int g, gl;
+    AASM_MEM explicit SweepGrp(int lane) : g(lane / G), gl(lane % G) {}
+    AASM_MEM uint32_t bits(uint64_t m) const { return G >= 64 ? 0u : (uint32_t)(m >> (g * (G & 63))) & ((1u << (G & 31)) - 1u); }
+    AASM_MEM int32_t below(uint64_t m) const {                       // set bits of my group below my lane
+        if (G >= 64) return popc64(m & lanemask_lt(gl));
+        return __builtin_popcount(bits(m) & ((1u << gl) - 1u));
+    }
+    AASM_MEM int32_t count(uint64_t m) const { return G >= 64 ? popc64(m) : __builtin_popcount(bits(m)); }
+};
+
+template <int G>
 AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
-    const int64_t c = k.bid;
-    const int64_t V = w.ctgV[c];
-    if (V == 0) return;
-    const int64_t vb = w.voff[c];
-    RevQ *Q = (RevQ *)k.lds;                                         // queue positions [head, lds_hi)
+    const SweepGrp<G> sg(k.lane);
+    const int64_t c = k.bid * SweepGrp<G>::N + sg.g;
+    const bool valid = c < w.C;
+    const int64_t V = valid ? (int64_t)w.ctgV[c] : 0;
+    const int64_t vb = valid ? w.voff[c] : 0;
+    RevQ *Q = (RevQ *)k.lds + sg.g;                                  // queue positions [head, lds_hi)
     Dist *d = w.sp_d + vb;
     int32_t *best = w.sp_best + vb, *q = w.rev_order + vb, *cnt = w.cnt_tmp + vb;
     const I4 *rvh = w.rvh + 3 * vb;
-    const int32_t dest = (int32_t)(V - 1);
     int32_t tail = 0, lds_hi = 0;
-    for (int64_t base = 0; base < V; base += AASM_WAVE) {          // init + sources in ascending id (:139-141)
-        const int64_t v = base + k.lane;
-        const bool act = v < V;
-        int32_t od = 0;
-        Dist dv0 = dist_max();
-        if (act) {
-            od = (int32_t)(w.rowptr[vb + v + 1] - w.rowptr[vb + v]);
-            cnt[v] = od;
-            if (v == dest) dv0 = dist_zero();
-            d[v] = dv0;
-            best[v] = -1;
-        }
-        const bool z = act && od == 0;
+    for (int64_t base = 0; wave_any(base < V); base += G) {        // sources in ascending id (:139-141); kb_rev_hdr initialised cnt / d / best
+        const int64_t v = base + sg.gl;
+        const bool z = v < V && cnt[v] == 0;
         const uint64_t m = wave_ballot(z);
-        const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+        const int32_t at = tail + sg.below(m);
         if (z) {
             q[at] = (int32_t)v;
-            if (at < REVQ_N) { RevEnt *E = &Q->e[at]; I4 hd = rvh[3 * v]; hd.w = (int32_t)v; E->hdr = hd; E->d = dv0; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
+            if (at < REVQ_N) { RevEnt *E = &Q->e[at]; I4 hd = rvh[3 * v]; hd.w = (int32_t)v; E->hdr = hd; E->d = d[v]; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
         }
-        tail += popc64(m);
+        tail += sg.count(m);
     }
     lds_hi = tail < REVQ_N ? tail : REVQ_N;
-    wave_fence();
     wave_lds_sync();
     int32_t head = 0;
-    while (head < tail) {
+    while (wave_any(head < tail)) {
+        const bool live = head < tail;
         RevEnt *E = &Q->e[head & (REVQ_N - 1)];
-        if (head >= lds_hi) {                                        // beyond the LDS window (wide frontiers): bring the entry in
-            const int32_t v = uni(q[head]);
-            if (k.lane == 0) { I4 hd = rvh[3 * v]; hd.w = v; E->hdr = hd; E->d = d[v]; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
+        if (wave_any(live && head >= lds_hi)) {                      // beyond the LDS window (wide frontiers): bring the entry in
+            if (live && head >= lds_hi && sg.gl == 0) { const int32_t v = q[head]; I4 hd = rvh[3 * v]; hd.w = v; E->hdr = hd; E->d = d[v]; E->rec[0] = rvh[3 * v + 1]; E->rec[1] = rvh[3 * v + 2]; }
             wave_lds_sync();
         }
-        head++;
-        const I4 hd = E->hdr;
-        const Dist dv = E->d;
-        const int32_t deg = uni(hd.z), v = hd.w;
+        I4 hd; hd.x = hd.y = hd.z = hd.w = 0;
+        Dist dv = dist_max();
+        if (live) { hd = E->hdr; dv = E->d; head++; }
+        const int32_t deg = hd.z, v = hd.w;
         const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)hd.y << 32) | (uint32_t)hd.x);
         const bool reach = dv.anom >= 0;                             // max() is the only distance with a negative anom here (:166)
-        for (int32_t base = 0; base < deg; base += AASM_WAVE) {
-            const int32_t t = base + k.lane;
+        for (int32_t base = 0; wave_any(base < deg); base += G) {
+            const int32_t t = base + sg.gl;
             const bool act = t < deg;
             bool z = false;
             int32_t u = 0;
@@ -1131,19 +1147,18 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
-            const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+            const int32_t at = tail + sg.below(m);
             if (z) {
                 q[at] = u;
                 if (lds_hi == tail && at - head < REVQ_N - 1) { RevEnt *N = &Q->e[at & (REVQ_N - 1)]; uh0.w = u; N->hdr = uh0; N->d = du; N->rec[0] = uh1; N->rec[1] = uh2; }
             }
-            const int32_t nnew = popc64(m);
+            const int32_t nnew = sg.count(m);
             if (lds_hi == tail) { int32_t room = REVQ_N - 1 - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }   // (the slot of the entry at hand stays untouched)
             tail += nnew;
         }
-        wave_fence();
         wave_lds_sync();
     }
-    if (tail != (int32_t)V && k.lane == 0) set_status(w, c, -6);    // cycle: cannot happen (:144-148)
+    if (valid && tail != (int32_t)V && sg.gl == 0) set_status(w, c, -6);   // cycle: cannot happen (:144-148)
 }
 
 // forward Kahn order (paf_data.cpp:742-746) + anomaly distance to dest.  The reference
@@ -1154,47 +1169,44 @@ struct FwdEnt { I4 a, b; };                                          // a = {row
 struct FwdQ { FwdEnt e[REVQ_N]; };
 #define AASM_FWD_LDS_BYTES (REVQ_N * 32)
 static_assert(sizeof(FwdQ) <= AASM_FWD_LDS_BYTES, "LDS budget");
+template <int G>
 AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
-    const int64_t c = k.bid;
-    const int64_t V = w.ctgV[c];
-    if (V == 0) return;
-    const int64_t vb = w.voff[c];
-    FwdQ *Q = (FwdQ *)k.lds;                                         // queue positions [head, lds_hi)
+    const SweepGrp<G> sg(k.lane);
+    const int64_t c = k.bid * SweepGrp<G>::N + sg.g;
+    const bool valid = c < w.C;
+    const int64_t V = valid ? (int64_t)w.ctgV[c] : 0;
+    const int64_t vb = valid ? w.voff[c] : 0;
+    FwdQ *Q = (FwdQ *)k.lds + sg.g;                                  // queue positions [head, lds_hi)
     int32_t *q = w.fwd_order + vb, *pos = w.fwd_pos + vb, *cnt = w.cnt_tmp2 + vb, *an = w.an + vb;
     const I4 *fvh = w.fvh + 2 * vb;
-    const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     int32_t tail = 0, lds_hi = 0;
-    for (int64_t base = 0; base < V; base += AASM_WAVE) {
-        const int64_t v = base + k.lane;
-        const bool act = v < V;
-        int32_t id = 1, a0 = -1;
-        if (act) { id = w.indeg[vb + v]; cnt[v] = id; a0 = (v == src) ? 0 : -1; an[v] = a0; }
-        const bool z = act && id == 0;
+    for (int64_t base = 0; wave_any(base < V); base += G) {        // kb_rev_hdr initialised cnt / an
+        const int64_t v = base + sg.gl;
+        const bool z = v < V && cnt[v] == 0;
         const uint64_t m = wave_ballot(z);
         if (z) {
-            const int32_t t = tail + popc64(m & lanemask_lt(k.lane));
+            const int32_t t = tail + sg.below(m);
             q[t] = (int32_t)v; pos[v] = t;
-            if (t < REVQ_N) { I4 fa = fvh[2 * v], fb = fvh[2 * v + 1]; fa.w = (int32_t)v; fb.x = a0; Q->e[t].a = fa; Q->e[t].b = fb; }
+            if (t < REVQ_N) { I4 fa = fvh[2 * v], fb = fvh[2 * v + 1]; fa.w = (int32_t)v; fb.x = an[v]; Q->e[t].a = fa; Q->e[t].b = fb; }
         }
-        tail += popc64(m);
+        tail += sg.count(m);
     }
     lds_hi = tail < REVQ_N ? tail : REVQ_N;
-    wave_fence();
     wave_lds_sync();
     int32_t head = 0;
-    while (head < tail) {
+    while (wave_any(head < tail)) {
+        const bool live = head < tail;
         FwdEnt *E = &Q->e[head & (REVQ_N - 1)];
-        if (head >= lds_hi) {
-            const int32_t u = uni(q[head]);
-            if (k.lane == 0) { I4 fa = fvh[2 * u], fb = fvh[2 * u + 1]; fa.w = u; fb.x = an[u]; E->a = fa; E->b = fb; }
+        if (wave_any(live && head >= lds_hi)) {
+            if (live && head >= lds_hi && sg.gl == 0) { const int32_t u = q[head]; I4 fa = fvh[2 * u], fb = fvh[2 * u + 1]; fa.w = u; fb.x = an[u]; E->a = fa; E->b = fb; }
             wave_lds_sync();
         }
-        head++;
-        const I4 fa = E->a, fb = E->b;
-        const int32_t deg = uni(fa.z), au = fb.x;
+        I4 fa, fb; fa.x = fa.y = fa.z = fa.w = 0; fb = fa;
+        if (live) { fa = E->a; fb = E->b; head++; }
+        const int32_t deg = fa.z, au = fb.x;
         const int64_t r0 = (int64_t)(((uint64_t)(uint32_t)fa.y << 32) | (uint32_t)fa.x);
-        for (int32_t base = 0; base < deg; base += AASM_WAVE) {
-            const int32_t t = base + k.lane;
+        for (int32_t base = 0; wave_any(base < deg); base += G) {
+            const int32_t t = base + sg.gl;
             const bool act = t < deg;
             bool z = false;
             int32_t v = 0, av = -1;
@@ -1213,20 +1225,19 @@ AASM_DEV void kb_fwd_sweep(const KCtx &k, const WS &w) {
                 z = left == 0;
             }
             const uint64_t m = wave_ballot(z);
-            const int32_t at = tail + popc64(m & lanemask_lt(k.lane));
+            const int32_t at = tail + sg.below(m);
             if (z) {
                 q[at] = v; pos[v] = at;
                 if (lds_hi == tail && at - head < REVQ_N - 1) { FwdEnt *N = &Q->e[at & (REVQ_N - 1)]; va.w = v; vbb.x = av; N->a = va; N->b = vbb; }
             }
-            const int32_t nnew = popc64(m);
+            const int32_t nnew = sg.count(m);
             if (lds_hi == tail) { int32_t room = REVQ_N - 1 - (tail - head); if (room > nnew) room = nnew; if (room < 0) room = 0; lds_hi += room; }
             tail += nnew;
         }
-        wave_fence();
         wave_lds_sync();
     }
-    if (k.lane == 0) {
-        w.anom_dest[c] = an[dest];
+    if (valid && sg.gl == 0 && V > 0) {
+        w.anom_dest[c] = an[V - 1];
         if (tail != (int32_t)V) set_status(w, c, -6);
     }
 }

@@ -21,7 +21,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
@@ -44,8 +44,10 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_SORT_ROWS_REV: kb_sort_rows<I4>(k, w, w.rptr, w.r_e, w.r_pk, w.tmp_pk, w.VT); break;
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
-        case KN_REV_SWEEP: kb_rev_sweep(k, w); break;
-        case KN_FWD_SWEEP: kb_fwd_sweep(k, w); break;
+        case KN_REV_SWEEP: kb_rev_sweep<AASM_WAVE>(k, w); break;
+        case KN_FWD_SWEEP: kb_fwd_sweep<AASM_WAVE>(k, w); break;
+        case KN_REV_SWEEP_G: kb_rev_sweep<AASM_SWEEP_G>(k, w); break;
+        case KN_FWD_SWEEP_G: kb_fwd_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_CHILD_COUNT: kb_child_count(k, w); break;
         case KN_CHILD_FILL: kb_child_fill(k, w); break;
         case KN_SORT_ROWS_CHILD: kb_sort_rows<int32_t>(k, w, w.cptr, w.cval, (int32_t *)nullptr, (int32_t *)nullptr, w.VT); break;
@@ -195,21 +197,25 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
         be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
+        A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
         CHECK_ALLOC();
         be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
 
         // ---- K6 / K5 sweeps.  The forward sweep + the topologically ordered CSR copy only feed
         // K9, so they run on a second stream beside rev_sweep -> heaps -> enumeration.
-        A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(rev_order, int32_t, VT, "rev_order"); A(cnt_tmp, int32_t, VT, "cnt_tmp");
-        A(fwd_order, int32_t, VT, "fwd_order"); A(fwd_pos, int32_t, VT, "fwd_pos"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
+        A(rev_order, int32_t, VT, "rev_order"); A(fwd_order, int32_t, VT, "fwd_order"); A(fwd_pos, int32_t, VT, "fwd_pos");
         A(tp_deg, int32_t, VT, "tp_deg"); A(tp_vj, int32_t, VT, "tp_vj"); A(tp_ptr, int64_t, VT + 1, "tp_ptr");
         A(te_tgt, int32_t, ET, "te_tgt"); A(te_wq, int64_t, ET, "te_wq"); A(te_wr, int32_t, ET, "te_wr"); A(te_fl, uint8_t, ET, "te_fl");
         CHECK_ALLOC();
         be.fork();                                                   // side stream waits for everything enqueued so far
         be.use_side(true);
         be.phase_begin(AASM_PH_FWD);
-        be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
+        // sparse batches (mean degree <= 6): several contigs per wave, AASM_SWEEP_G lanes each; dense ones: a wave per contig
+        const bool grouped = ET <= 6 * VT;
+        const int64_t sweep_n = AASM_WAVE / AASM_SWEEP_G;
+        if (grouped) be.launch(KN_FWD_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
+        else be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_FWD);
         be.phase_begin(AASM_PH_TOPO);
         be.launch(KN_TOPO_COUNT, cdiv(VT, 256), 256, w);
@@ -218,7 +224,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_end(AASM_PH_TOPO);
         be.use_side(false);
         be.phase_begin(AASM_PH_SPTREE);
-        be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
+        if (grouped) be.launch(KN_REV_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
+        else be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_SPTREE);
 
         // ---- K7 heaps
