@@ -14,11 +14,13 @@
 #define AASM_DEV static inline
 #define AASM_MEM inline
 #define AASM_WAVE 1
+#define AASM_UNROLL
 #else
 #include <hip/hip_runtime.h>
 #define AASM_DEV static __device__ __forceinline__
 #define AASM_MEM __device__ __forceinline__
 #define AASM_WAVE 64
+#define AASM_UNROLL _Pragma("unroll")
 #endif
 
 namespace aasm {

@@ -186,57 +186,77 @@ __global__ void __launch_bounds__(64) aasm_sssp_dijkstra_kernel(int64_t n_graphs
 }
 
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
+// ONE launch per scan (the pipeline runs ~14 per batch, most over 7-15 M entries): tiles take their number from a
+// ticket (so every tile's predecessors are running or done), publish their sum, and find their prefix by looking back
+// over the published words, 64 tiles per look (single-pass scan with decoupled look-back).  A word is
+// {state : 2, value : 62}; the sums here are counts (>= 0, far below 2^62).  The tile that finishes last clears the
+// words and the counters, so the scratch buffer is ready for the next scan on the same stream.
 #define SCAN_TPB 256
 #define SCAN_IPT 8
 #define SCAN_TILE (SCAN_TPB * SCAN_IPT)
+#define SCAN_AGG 1ull
+#define SCAN_PREFIX 2ull
+#define SCAN_HDR 2                           // words ahead of the tile words: ticket, #tiles done
+__device__ __forceinline__ int64_t scan_wave_incl(int64_t x, int lane) {
+    for (int d = 1; d < 64; d <<= 1) { const int64_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    return x;
+}
 template <class T>
-__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_tiles(const T *in, int64_t n, int64_t *out, int64_t *tile_sum) {
-    __shared__ int64_t sh[SCAN_TPB];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t n, int64_t *out, unsigned long long *scr, int64_t nt) {
+    __shared__ int64_t sh_wave[SCAN_TPB / 64];
+    __shared__ int64_t sh_prefix;
+    __shared__ unsigned long long sh_tile;
+    __shared__ int sh_last;
+    unsigned long long *words = scr + SCAN_HDR;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sh_tile = atomicAdd(&scr[0], 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)sh_tile;
+    const int64_t base = tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
     int64_t v[SCAN_IPT], s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_IPT; i++) { v[i] = (base + i < n) ? (int64_t)in[base + i] : 0; s += v[i]; }
-    sh[threadIdx.x] = s;
+    const int64_t incl = scan_wave_incl(s, lane);
+    if (lane == 63) sh_wave[wv] = incl;
     __syncthreads();
-    for (int d = 1; d < SCAN_TPB; d <<= 1) {           // Hillis-Steele inclusive over thread sums
-        int64_t t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    int64_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_TPB / 64; i++) { const int64_t t = sh_wave[i]; if (i < wv) wave_off += t; total += t; }
+    if (wv == 0) {                                                   // the first wave publishes and looks back
+        int64_t prefix = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&words[tile], (SCAN_AGG << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t j = tile - 1;                                    // lane i looks at tile j - i
+            for (;;) {
+                const int64_t mine = j - lane;
+                unsigned long long x = SCAN_PREFIX << 62;            // (tiles before the first one: an empty prefix)
+                if (mine >= 0) do { x = __hip_atomic_load(&words[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 62) == 0);
+                const uint64_t pm = __ballot((x >> 62) == SCAN_PREFIX);
+                const int stop = pm ? __ffsll((long long)pm) - 1 : 64;   // nearest tile that knows its prefix
+                int64_t val = (lane <= stop) ? (int64_t)(x & ((1ull << 62) - 1)) : 0;
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+                prefix += val;
+                if (pm) break;
+                j -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&words[tile], (SCAN_PREFIX << 62) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_prefix = prefix;
+            if (tile == nt - 1) out[n] = prefix + total;
+        }
     }
-    int64_t run = sh[threadIdx.x] - s;                 // exclusive prefix of this thread
+    __syncthreads();
+    int64_t run = sh_prefix + wave_off + incl - s;                   // exclusive prefix of this thread
 #pragma unroll
     for (int i = 0; i < SCAN_IPT; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
-    if (threadIdx.x == SCAN_TPB - 1) tile_sum[blockIdx.x] = sh[SCAN_TPB - 1];
-}
-__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_sums(int64_t *tile_sum, int64_t nt, int64_t *total) {
-    __shared__ int64_t sh[SCAN_TPB];
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    // ---- the last tile to get here resets the scratch words (every look-back is over by then)
+    if (threadIdx.x == 0) sh_last = (atomicAdd(&scr[1], 1ull) == (unsigned long long)(nt - 1)) ? 1 : 0;
     __syncthreads();
-    for (int64_t base = 0; base < nt; base += SCAN_TPB) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t x = i < nt ? tile_sum[i] : 0;
-        sh[threadIdx.x] = x;
-        __syncthreads();
-        for (int d = 1; d < SCAN_TPB; d <<= 1) {
-            int64_t t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nt) tile_sum[i] = carry + sh[threadIdx.x] - x;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += sh[SCAN_TPB - 1];
-        __syncthreads();
+    if (sh_last) {
+        for (int64_t i = threadIdx.x; i < nt; i += SCAN_TPB) __hip_atomic_store(&words[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) { __hip_atomic_store(&scr[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&scr[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
-    if (threadIdx.x == 0) *total = carry;
-}
-__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_add(int64_t *out, int64_t n, const int64_t *tile_sum) {
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
-    const int64_t add = tile_sum[blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < SCAN_IPT; i++) if (base + i < n) out[base + i] += add;
 }
 
 // ------------------------------------------------------------------------------------
@@ -391,11 +411,10 @@ struct GpuBackend {
             if (scr) hipFree(scr);
             scr_cap = (size_t)nt * 2 + 1024;
             hipError_t e = hipMalloc((void **)&scr, scr_cap * 8);
+            if (e == hipSuccess) e = hipMemsetAsync(scr, 0, scr_cap * 8, stream);   // (the scan kernel leaves the words zero again)
             if (e != hipSuccess) { scr = nullptr; scr_cap = 0; hip_fail("hipMalloc(scan)", e); return; }
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_tiles<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, scr);
-        hipLaunchKernelGGL(aasm_scan_sums, dim3(1), dim3(SCAN_TPB), 0, stream, scr, nt, out + n);
-        hipLaunchKernelGGL(aasm_scan_add, dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, out, n, scr);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_chain<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, (unsigned long long *)scr, nt);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) hip_fail("scan launch", e);
     }

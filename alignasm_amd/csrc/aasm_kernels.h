@@ -975,14 +975,14 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
 
 // sort every row of (key, payload) ascending by key; keys inside a row are distinct.
 // Lanes insertion-sort their own short rows; long rows are rank-sorted by the whole wave
-// through the tmp arrays.
+// through the tmp arrays.  Rows of at most `skip_len` entries are left alone (their reader sorts them in registers).
 template <class P>
-AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows) {
+AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows, int64_t skip_len) {
     const int64_t row = k.bid * AASM_WAVE + k.lane;
     const bool act = row < nrows;
     const int64_t p0 = act ? ptr[row] : 0, L = act ? ptr[row + 1] - p0 : 0;
     const bool big = L > 32;
-    if (act && !big) {
+    if (act && !big && L > skip_len) {
         for (int64_t a = 1; a < L; a++) {
             const int32_t kx = key[p0 + a];
             P px = P();
@@ -1035,6 +1035,7 @@ struct RevEnt { I4 hdr; Dist d; I4 rec[2]; };                        // hdr = {i
 struct RevQ { RevEnt e[REVQ_N]; };
 #define AASM_REV_LDS_BYTES (REVQ_N * 80)
 static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
+#define REV_REG_SORT 8
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
@@ -1042,8 +1043,32 @@ AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread pe
     I4 h[3];
     for (int t = 0; t < 3; t++) { h[t].x = h[t].y = h[t].z = h[t].w = 0; }
     h[0].x = (int32_t)(uint32_t)(uint64_t)r0; h[0].y = (int32_t)((uint64_t)r0 >> 32); h[0].z = (int32_t)(r1 - r0);
-    if (r1 > r0) h[1] = w.r_pk[r0];                                   // (kb_rev_fill packed the records, kb_sort_rows put them in list order)
-    if (r1 > r0 + 1) h[2] = w.r_pk[r0 + 1];
+    const int32_t ideg = (int32_t)(r1 - r0);
+    if (ideg >= 2 && ideg <= REV_REG_SORT) {
+        // kb_rev_fill left the row in the order its atomics landed: a short row (the mean in-degree is ~2) is put in
+        // list order here, in registers - an entry's place is the number of smaller edge ids (they are distinct)
+        int32_t key[REV_REG_SORT];
+        I4 rec[REV_REG_SORT];
+AASM_UNROLL
+        for (int i = 0; i < REV_REG_SORT; i++) {
+            key[i] = INT32_MAX;
+            if (i < ideg) { key[i] = w.r_e[r0 + i]; rec[i] = w.r_pk[r0 + i]; } else rec[i] = h[0];
+        }
+AASM_UNROLL
+        for (int i = 0; i < REV_REG_SORT; i++) {
+            int32_t rank = 0;
+AASM_UNROLL
+            for (int j = 0; j < REV_REG_SORT; j++) rank += (key[j] < key[i]) ? 1 : 0;
+            if (i < ideg) {
+                if (rank != i) w.r_pk[r0 + rank] = rec[i];
+                if (rank == 0) h[1] = rec[i];
+                if (rank == 1) h[2] = rec[i];
+            }
+        }
+    } else {
+        if (r1 > r0) h[1] = w.r_pk[r0];                               // (longer rows: kb_sort_rows put them in list order)
+        if (r1 > r0 + 1) h[2] = w.r_pk[r0 + 1];
+    }
     for (int t = 0; t < 3; t++) w.rvh[3 * gv + t] = h[t];
     // the same for the forward sweep: {row start (2 words), out-degree, -} {-, head 0, head 1, anomaly weight 0 | weight 1 << 8}
     const int64_t o0 = w.rowptr[gv], o1 = w.rowptr[gv + 1];
