@@ -975,13 +975,15 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
 
 // sort every row of (key, payload) ascending by key; keys inside a row are distinct.
 // Lanes insertion-sort their own short rows; long rows are rank-sorted by the whole wave
-// through the tmp arrays.  Rows of at most `skip_len` entries are left alone (their reader sorts them in registers).
+// through the tmp arrays (rows longer than `coop_len`: with a 16-byte payload a lane's insertion sort of a dozen
+// entries is dozens of dependent memory round trips the other 63 lanes wait for).  Rows of at most `skip_len`
+// entries are left alone (their reader sorts them in registers).
 template <class P>
-AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows, int64_t skip_len) {
+AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows, int64_t skip_len, int64_t coop_len) {
     const int64_t row = k.bid * AASM_WAVE + k.lane;
     const bool act = row < nrows;
     const int64_t p0 = act ? ptr[row] : 0, L = act ? ptr[row + 1] - p0 : 0;
-    const bool big = L > 32;
+    const bool big = L > coop_len;
     if (act && !big && L > skip_len) {
         for (int64_t a = 1; a < L; a++) {
             const int32_t kx = key[p0 + a];

@@ -42,7 +42,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_COUNT: kb_row_count(k, w); break;
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
-        case KN_SORT_ROWS_REV: kb_sort_rows<I4>(k, w, w.rptr, w.r_e, w.r_pk, w.tmp_pk, w.VT, REV_REG_SORT); break;   // (kb_rev_hdr sorts the short rows)
+        case KN_SORT_ROWS_REV: kb_sort_rows<I4>(k, w, w.rptr, w.r_e, w.r_pk, w.tmp_pk, w.VT, REV_REG_SORT, REV_REG_SORT); break;   // (kb_rev_hdr sorts the short rows)
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep<AASM_WAVE>(k, w); break;
         case KN_FWD_SWEEP: kb_fwd_sweep<AASM_WAVE>(k, w); break;
@@ -50,7 +50,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_FWD_SWEEP_G: kb_fwd_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_CHILD_COUNT: kb_child_count(k, w); break;
         case KN_CHILD_FILL: kb_child_fill(k, w); break;
-        case KN_SORT_ROWS_CHILD: kb_sort_rows<int32_t>(k, w, w.cptr, w.cval, (int32_t *)nullptr, (int32_t *)nullptr, w.VT, 1); break;
+        case KN_SORT_ROWS_CHILD: kb_sort_rows<int32_t>(k, w, w.cptr, w.cval, (int32_t *)nullptr, (int32_t *)nullptr, w.VT, 1, 32); break;
         case KN_HEAP_CAP: kb_heap_cap(k, w); break;
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
