@@ -242,3 +242,16 @@ def test_multiwave_heaps_with_fewer_waves_per_contig(T, nc):
     want = T.oracle_solve(hb, 8)
     got = api.solve_batch(hb, max_paths=8, heap_waves="all")
     assert T.diff_outputs(want, got) == []
+
+
+# ---- K7, one wave per contig (kb_heap) forced on every contig, the dense ones included (by default those go to
+# kb_heap_mw): both kernels must leave the same arena
+@pytest.mark.parametrize("case", [CASES[2], CASES[5], CASES[9], CASES[13]], ids=_id)
+def test_one_wave_heap_kernel_arena_is_bit_identical(T, case):
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    db = api.DeviceBatch(hb)
+    res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves="none")
+    assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+    res.close(); db.close()
