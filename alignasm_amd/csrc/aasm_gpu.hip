@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) aasm_sssp_dijkstra_kernel(int64_t n_graphs
 // {state : 2, value : 62}; the sums here are counts (>= 0, far below 2^62).  The tile that finishes last clears the
 // words and the counters, so the scratch buffer is ready for the next scan on the same stream.
 #define SCAN_TPB 256
-#define SCAN_IPT 8
+#define SCAN_IPT 16
 #define SCAN_TILE (SCAN_TPB * SCAN_IPT)
 #define SCAN_AGG 1ull
 #define SCAN_PREFIX 2ull
