@@ -107,7 +107,8 @@ struct WS {
     int32_t *mw_cap;                     // per contig: provisional capacity (0 for the one-wave class)
     int32_t *mw_order, *mw_rs, *mw_fb;   // per BFS position: vertex, region start, final base
     int32_t *mw_rsv, *mw_used;           // per vertex: region start, nodes used
-    I4 *tnx;                             // next four vertices along best[] (path recovery reads one record per four tree edges)
+    I4 *tnx;                             // next four vertices along best[] (kb_sidetrack) ...
+    int32_t *tnx16;                      // ... and the next sixteen (kb_heap_hdr): path recovery reads one 64-byte record per sixteen tree edges
     I4 *rvh;                             // K6: per-vertex in-list header, 3 words (see kb_rev_hdr)
     I4 *r_pk;                            // K6: one packed record per in-edge, in in-list order
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
@@ -1385,6 +1386,13 @@ AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
     b.x = (int32_t)(uint32_t)(uint64_t)c0; b.y = (int32_t)((uint64_t)c0 >> 32);
     b.z = fc >= 0 ? (int32_t)(w.rowptr[vb + fc] - e_base) : 0; b.w = fc >= 0 ? w.st_n[vb + fc] : 0;
     w.vhdr[gv] = a; w.vhdr2[gv] = b;
+    {   // sixteen tree hops = four 4-hop records chained (kb_sidetrack wrote those; -1 past dest)
+        I4 neg; neg.x = neg.y = neg.z = neg.w = -1;
+        I4 *o = (I4 *)(w.tnx16 + 16 * gv);
+        I4 j = w.tnx[gv];
+        o[0] = j;
+        for (int t = 1; t < 4; t++) { j = (j.w >= 0) ? w.tnx[vb + j.w] : neg; o[t] = j; }
+    }
     for (int64_t t = c0; t < c1; t++) {
         const int32_t ch = w.cval[t];
         I4 ci; ci.x = ch; ci.y = (int32_t)(w.rowptr[vb + ch] - e_base); ci.z = w.st_n[vb + ch]; ci.w = 0;
@@ -2145,6 +2153,23 @@ AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
     s.last_head = v;
     if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
 }
+// the same for up to 16 edges at once: lane t < m appends (u, v) of its edge (m wave-uniform, m <= 16 <= SEL_WIN)
+#if !defined(AASM_HOST_EMUL)
+AASM_DEV void sel_push_lanes(SelCtx &s, int32_t m, int32_t u, int32_t v) {
+    SelLds *L = (SelLds *)s.lds;
+    if (s.out_n + m > s.cap) { s.err = true; return; }
+    const int32_t slot0 = s.out_n - s.out_flushed, room = SEL_WIN - slot0;
+    const int32_t first = m < room ? m : room;
+    if (s.lane < first) { L->pb_buf[2 * (slot0 + s.lane)] = u; L->pb_buf[2 * (slot0 + s.lane) + 1] = v; }
+    s.out_n += first;
+    if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
+    if (m > first) {
+        if (s.lane >= first && s.lane < m) { L->pb_buf[2 * (s.lane - first)] = u; L->pb_buf[2 * (s.lane - first) + 1] = v; }
+        s.out_n += m - first;
+    }
+    s.last_head = wave_bcast(v, m - 1);
+}
+#endif
 // edge `it` of pathA through a 64-edge LDS window.  A refill also fetches, for every edge of the
 // window at once, whether its head is a single-record vertex and its v_j (what the upgrade asks
 // about every edge), so the edge loop itself has no dependent global loads for them - and it
@@ -2230,16 +2255,28 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
             sel_push(s, cv, st_v);
             cv = st_v; idx--;
             if (idx >= 0) { st_u = uni(s.pathT[2 * idx]); st_v = uni(s.pathT[2 * idx + 1]); }
-        } else {                                                     // up to four tree edges per load
-            const I4 nx4 = uni(w.tnx[s.vb + cv]);
-            const int32_t nxv[4] = {nx4.x, nx4.y, nx4.z, nx4.w};
-            for (int t = 0; t < 4; t++) {
-                const int32_t nx = nxv[t];
+        } else {                                                     // up to sixteen tree edges per load, appended by sixteen lanes
+            const int32_t *rec = w.tnx16 + 16 * (s.vb + cv);
+#if defined(AASM_HOST_EMUL)
+            for (int t = 0; t < 16; t++) {
+                const int32_t nx = rec[t];
                 if (nx < 0) { s.err = true; return -1; }
                 sel_push(s, cv, nx);
                 cv = nx;
                 if (s.err || cv == s.dest || (idx >= 0 && cv == st_u)) break;   // the outer loop decides what comes next
             }
+#else
+            const bool in = s.lane < 16;
+            const int32_t x = in ? rec[s.lane] : -1;
+            const uint64_t stop = wave_ballot(in && (x == s.dest || (idx >= 0 && x == st_u)));   // the walk ends AFTER such an edge
+            const uint64_t bad = wave_ballot(in && x < 0);
+            const int32_t m = stop ? ffs64(stop) : 16;
+            if (bad && ffs64(bad) <= m) { s.err = true; return -1; }
+            int32_t from = wave_shfl_up(x, 1, cv);
+            if (s.lane == 0) from = cv;
+            sel_push_lanes(s, m, from, x);
+            cv = wave_bcast(x, m - 1);
+#endif
         }
     }
     if (s.err) return -1;
