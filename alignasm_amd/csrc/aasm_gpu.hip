@@ -10,6 +10,7 @@
 // There is NO CPU fallback here: without a usable HIP device every solve entry point
 // returns AASM_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <initializer_list>
 
 #include <atomic>
 #include <chrono>
@@ -427,6 +428,19 @@ struct GpuBackend {
         g_n_stream_syncs++;
         if (e != hipSuccess) { hip_fail("scalar read-back", e); return 0; }
         return cx.pinned[0];
+    }
+    // several scalars, ONE wait: the copies queue up behind the kernels that produce them
+    void read_i64s(std::initializer_list<const int64_t *> ps, int64_t *out) {
+        int n = 0;
+        for (auto p : ps) { (void)p; out[n++] = 0; }
+        if (fail) return;
+        hipError_t e = hipSuccess;
+        int i = 0;
+        for (auto p : ps) { if (e == hipSuccess) e = hipMemcpyAsync(cx.pinned + i, p, 8, hipMemcpyDeviceToHost, stream); i++; }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        g_n_stream_syncs++;
+        if (e != hipSuccess) { hip_fail("scalar read-back", e); return; }
+        for (i = 0; i < n; i++) out[i] = cx.pinned[i];
     }
     void d2h(void *dst, const void *src, size_t n) {
         if (fail || n == 0) return;

@@ -80,7 +80,9 @@ template <class B>
 int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, PipelineSizes &sz) {
     std::memset(&w, 0, sizeof(w));
     const int64_t C = in.n_contigs;
-    const int64_t R0 = be.read_i64(in.ctg_rec_off), R1 = be.read_i64(in.ctg_rec_off + C);
+    int64_t rr[2];
+    be.read_i64s({in.ctg_rec_off, in.ctg_rec_off + C}, rr);
+    const int64_t R0 = rr[0], R1 = rr[1];
     const int64_t R = R1 - R0;
     w.C = C; w.R = R; w.R0 = R0;
     w.K = opts.max_paths > 0 ? opts.max_paths : 10000;
@@ -104,7 +106,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     // ---- K0 (optional): match ranges from the cs tags, on the device
     if (!in.rng_qry_l && in.cs_text && in.rec_cs_off) {
         if (R > INT32_MAX) return AASM_E_INVAL;
-        const int64_t G0 = be.read_i64(in.rec_rng_off + R0), G1 = be.read_i64(in.rec_rng_off + R1);
+        int64_t gg[2];
+        be.read_i64s({in.rec_rng_off + R0, in.rec_rng_off + R1}, gg);
+        const int64_t G0 = gg[0], G1 = gg[1];
         be.phase_begin(AASM_PH_CS);
         w.cs_text = in.cs_text; w.cs_off = in.rec_cs_off;
         A(rql_w, int64_t, G1 - G0, "rql_w"); A(rqr_w, int64_t, G1 - G0, "rqr_w"); A(rrl_w, int64_t, G1 - G0, "rrl_w"); A(cs_bad, int32_t, 2, "cs_bad");
@@ -245,7 +249,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
         be.scan_i32(w.mw_cap, C, w.mw_off);
-        const int64_t HT = be.read_i64(w.hoff + C), HTM = be.read_i64(w.mw_off + C), NMW = HTM > 0 ? be.read_i64(w.counters + CNT_MW) : 0;
+        int64_t hh[3];
+        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW}, hh);
+        const int64_t HT = hh[0], HTM = hh[1], NMW = HTM > 0 ? hh[2] : 0;
         sz.HT = HT;
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
         A(hprov, HNode, HTM, "hprov");
@@ -295,7 +301,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.launch(KN_SEL_PLANFILL, C, AASM_WAVE, w);
             be.scan_i32(w.cv_szr, NCONV, w.cv_roff);
             be.scan_i32(w.cv_szv, NCONV, w.cv_voff);
-            SR = be.read_i64(w.cv_roff + NCONV); SV = be.read_i64(w.cv_voff + NCONV);
+            int64_t sv[2];
+            be.read_i64s({w.cv_roff + NCONV, w.cv_voff + NCONV}, sv);
+            SR = sv[0]; SV = sv[1];
             const int64_t bytes = SR * (24 + (int64_t)sizeof(OutElem)) + SV * ((int64_t)sizeof(Dist) + 8);
             if (bytes > ((int64_t)24 << 30)) sequential = true;
         }
@@ -312,7 +320,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         }
         be.phase_begin(AASM_PH_FINAL);
         be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
-        const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
+        int64_t np2[2];
+        be.read_i64s({w.counters + CNT_POOL, w.counters + CNT_AR}, np2);
+        const int64_t need_pool = np2[0], need_ar = np2[1];
         if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow: exact-size re-run of the pick only
             w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
             A(pool, OutElem, w.pool_cap, "pool");
@@ -331,7 +341,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_SELECT);
         be.launch(KN_SELECT, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_SELECT);
-        const int64_t need_pool = be.read_i64(w.counters + CNT_POOL), need_ar = be.read_i64(w.counters + CNT_AR);
+        int64_t np2[2];
+        be.read_i64s({w.counters + CNT_POOL, w.counters + CNT_AR}, np2);
+        const int64_t need_pool = np2[0], need_ar = np2[1];
         if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow (tie-heavy inputs): one exact-size re-run
             w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
             A(pool, OutElem, w.pool_cap, "pool");
@@ -355,7 +367,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     be.phase_begin(AASM_PH_GATHER);
     be.scan_i32(w.main_len, C, w.main_off);
     be.scan_i32(w.alt_len, C, w.alt_off);
-    const int64_t NM = be.read_i64(w.main_off + C), NA = be.read_i64(w.alt_off + C);
+    int64_t nm[2];
+    be.read_i64s({w.main_off + C, w.alt_off + C}, nm);
+    const int64_t NM = nm[0], NA = nm[1];
     A(main_c, OutElem, NM, "main_c"); A(alt_c, OutElem, NA, "alt_c");
     CHECK_ALLOC();
     be.launch(KN_GATHER_OUT, C, AASM_WAVE, w);

@@ -1,3 +1,4 @@
+#include <initializer_list>
 // tests/host_emul/emul.cpp -- TEST INFRASTRUCTURE ONLY.
 //
 // Compiles the product's kernel bodies (alignasm_amd/csrc/aasm_kernels.h) and launch
@@ -58,6 +59,7 @@ struct EmuBackend {
     void scan_i32(const int32_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
     void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
     int64_t read_i64(const int64_t *p) { return *p; }
+    void read_i64s(std::initializer_list<const int64_t *> ps, int64_t *out) { int i = 0; for (auto p : ps) out[i++] = *p; }
     void d2h(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
     void d2h_big(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
     void fork() {}
