@@ -54,7 +54,7 @@ AASM_DEF_KERNEL(aasm_k4_nsl, KN_NSL, 256)
 AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
 AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
-AASM_DEF_KERNEL(aasm_k6_sort_rows_rev, KN_SORT_ROWS_REV, 64)
+AASM_DEF_KERNEL_LDS(aasm_k6_rev_place, KN_SORT_ROWS_REV, 64, AASM_REVP_LDS_BYTES, 4)
 AASM_DEF_KERNEL(aasm_k6_rev_hdr, KN_REV_HDR, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_sweep, KN_REV_SWEEP, 64, AASM_REV_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k5_fwd_sweep, KN_FWD_SWEEP, 64, AASM_FWD_LDS_BYTES, 8)
@@ -390,7 +390,7 @@ struct GpuBackend {
             L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
             L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill)
-            L(KN_SORT_ROWS_REV, aasm_k6_sort_rows_rev) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
+            L(KN_SORT_ROWS_REV, aasm_k6_rev_place) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
             L(KN_CHILD_COUNT, aasm_k7_child_count) L(KN_CHILD_FILL, aasm_k7_child_fill) L(KN_SORT_ROWS_CHILD, aasm_k7_sort_rows_child)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_ENUM, aasm_k8_enum) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)

@@ -50,7 +50,7 @@ struct WS {
     int64_t *voff, *v_slot;
     // ---- forward CSR + reversed CSR
     int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e, *tmp_a;
-    I4 *tmp_pk;                          // rank-sort scratch of the packed in-edge records (rows longer than 32)
+    I4 *tmp_pk;                          // the packed in-edge records as kb_rev_fill's atomics placed them (r_pk: in list order)
     int64_t *rowptr, *e_wq, *rptr;
     uint8_t *e_fl;
     // ---- sweeps
@@ -970,7 +970,7 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
         const int64_t tv = vb + w.e_col[e];
         const int64_t pos = w.rptr[tv] + atomic_add(&w.rcur[tv], (int32_t)1);
         w.r_e[pos] = (int32_t)(e - e_base);
-        w.r_pk[pos] = pack_in_edge(u, w.e_wq[e], w.e_wr[e], w.e_fl[e]);
+        w.tmp_pk[pos] = pack_in_edge(u, w.e_wq[e], w.e_wr[e], w.e_fl[e]);   // in the order the atomics landed; kb_rev_place / kb_rev_hdr move it to its place in r_pk
     }
 }
 
@@ -1013,6 +1013,45 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
     }
 }
 
+// In-lists longer than REV_REG_SORT entries (dense graphs: ~25 on average) go from the order the atomics of
+// kb_rev_fill landed in (r_e = edge id, tmp_pk = record) to list order in r_pk: an entry's place is the number of
+// smaller edge ids in its list (they are distinct).  A wave owns the in-lists of AASM_WAVE consecutive vertices - one
+// contiguous run of slots - and its lanes stride over the ENTRIES of that run, whatever list they are in (the list
+// of an entry: binary search over the run's 65 row pointers in LDS; the run's keys are staged in LDS when they fit),
+// so the work is balanced and every entry is one coalesced 16-byte read and one write.  Short lists: kb_rev_hdr.
+#define REV_REG_SORT 8
+#define REVP_KEYS 2048
+struct RevPlaceLds { int64_t ptr[AASM_WAVE_MAX + 1]; int32_t key[REVP_KEYS]; };
+#define AASM_REVP_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REVP_KEYS * 4)
+static_assert(sizeof(RevPlaceLds) <= AASM_REVP_LDS_BYTES, "LDS budget");
+AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per AASM_WAVE vertices
+    RevPlaceLds *L = (RevPlaceLds *)k.lds;
+    const int64_t row0 = k.bid * AASM_WAVE;
+    if (row0 >= w.VT) return;
+    const int32_t nrows = (int32_t)((w.VT - row0 < AASM_WAVE) ? (w.VT - row0) : AASM_WAVE);
+    for (int32_t t = k.lane; t <= nrows; t += AASM_WAVE) L->ptr[t] = w.rptr[row0 + t];
+    wave_lds_sync();
+    bool any_long = false;
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) any_long |= L->ptr[t + 1] - L->ptr[t] > REV_REG_SORT;
+    if (!wave_any(any_long)) return;
+    const int64_t seg0 = L->ptr[0], seg1 = L->ptr[nrows];
+    const bool staged = seg1 - seg0 <= REVP_KEYS;
+    if (staged) {
+        for (int64_t i = seg0 + k.lane; i < seg1; i += AASM_WAVE) L->key[i - seg0] = w.r_e[i];
+        wave_lds_sync();
+    }
+    for (int64_t i = seg0 + k.lane; i < seg1; i += AASM_WAVE) {
+        int32_t lo = 0, hi = nrows;                                  // ptr[lo] <= i < ptr[hi]
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L->ptr[mid] <= i) lo = mid; else hi = mid; }
+        const int64_t p0 = L->ptr[lo], p1 = L->ptr[lo + 1];
+        if (p1 - p0 <= REV_REG_SORT) continue;
+        int32_t rank = 0;
+        if (staged) { const int32_t kx = L->key[i - seg0]; for (int64_t j = p0; j < p1; j++) rank += L->key[j - seg0] < kx ? 1 : 0; }
+        else { const int32_t kx = w.r_e[i]; for (int64_t j = p0; j < p1; j++) rank += w.r_e[j] < kx ? 1 : 0; }
+        w.r_pk[p0 + rank] = w.tmp_pk[i];
+    }
+}
+
 // ====================================================================================
 // K6  Kahn FIFO order of the reversed graph + DAG shortest-path tree in ONE sweep
 //     (k_shortest_walks.hpp:132-175,184).  One wave per contig.
@@ -1038,7 +1077,6 @@ struct RevEnt { I4 hdr; Dist d; I4 rec[2]; };                        // hdr = {i
 struct RevQ { RevEnt e[REVQ_N]; };
 #define AASM_REV_LDS_BYTES (REVQ_N * 80)
 static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
-#define REV_REG_SORT 8
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
@@ -1055,7 +1093,7 @@ AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread pe
 AASM_UNROLL
         for (int i = 0; i < REV_REG_SORT; i++) {
             key[i] = INT32_MAX;
-            if (i < ideg) { key[i] = w.r_e[r0 + i]; rec[i] = w.r_pk[r0 + i]; } else rec[i] = h[0];
+            if (i < ideg) { key[i] = w.r_e[r0 + i]; rec[i] = w.tmp_pk[r0 + i]; } else rec[i] = h[0];
         }
 AASM_UNROLL
         for (int i = 0; i < REV_REG_SORT; i++) {
@@ -1063,14 +1101,17 @@ AASM_UNROLL
 AASM_UNROLL
             for (int j = 0; j < REV_REG_SORT; j++) rank += (key[j] < key[i]) ? 1 : 0;
             if (i < ideg) {
-                if (rank != i) w.r_pk[r0 + rank] = rec[i];
+                w.r_pk[r0 + rank] = rec[i];
                 if (rank == 0) h[1] = rec[i];
                 if (rank == 1) h[2] = rec[i];
             }
         }
-    } else {
-        if (r1 > r0) h[1] = w.r_pk[r0];                               // (longer rows: kb_sort_rows put them in list order)
-        if (r1 > r0 + 1) h[2] = w.r_pk[r0 + 1];
+    } else if (ideg == 1) {
+        h[1] = w.tmp_pk[r0];
+        w.r_pk[r0] = h[1];
+    } else if (ideg > REV_REG_SORT) {                                 // (kb_rev_place put the longer lists in order)
+        h[1] = w.r_pk[r0];
+        h[2] = w.r_pk[r0 + 1];
     }
     for (int t = 0; t < 3; t++) w.rvh[3 * gv + t] = h[t];
     // the same for the forward sweep: {row start (2 words), out-degree, -} {-, head 0, head 1, anomaly weight 0 | weight 1 << 8}
@@ -1601,7 +1642,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
     return sp.root;
 }
 
-struct KProfNone {};
+struct KProfNone { int64_t acc[8]; };   // (acc: only touched by the -DAASM_KPROF diagnostic build)
 AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];

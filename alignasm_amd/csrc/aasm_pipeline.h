@@ -42,7 +42,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_COUNT: kb_row_count(k, w); break;
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
-        case KN_SORT_ROWS_REV: kb_sort_rows<I4>(k, w, w.rptr, w.r_e, w.r_pk, w.tmp_pk, w.VT, REV_REG_SORT, REV_REG_SORT); break;   // (kb_rev_hdr sorts the short rows)
+        case KN_SORT_ROWS_REV: kb_rev_place(k, w); break;
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep<AASM_WAVE>(k, w); break;
         case KN_FWD_SWEEP: kb_fwd_sweep<AASM_WAVE>(k, w); break;
