@@ -1024,6 +1024,17 @@ AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32
 struct RevPlaceLds { int64_t ptr[AASM_WAVE_MAX + 1]; int32_t key[REVP_KEYS]; };
 #define AASM_REVP_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REVP_KEYS * 4)
 static_assert(sizeof(RevPlaceLds) <= AASM_REVP_LDS_BYTES, "LDS budget");
+// #{j in [a, b) : key[j] < kx}; eight independent reads per wait (a lane's rank loop over a list of a few hundred keys
+// is otherwise one LDS round trip per key)
+AASM_DEV int32_t rank_below(const int32_t *key, int32_t a, int32_t b, int32_t kx) {
+    int32_t rank = 0, j = a;
+    for (; j + 8 <= b; j += 8) {
+        const int32_t k0 = key[j], k1 = key[j + 1], k2 = key[j + 2], k3 = key[j + 3], k4 = key[j + 4], k5 = key[j + 5], k6 = key[j + 6], k7 = key[j + 7];
+        rank += (k0 < kx) + (k1 < kx) + (k2 < kx) + (k3 < kx) + (k4 < kx) + (k5 < kx) + (k6 < kx) + (k7 < kx);
+    }
+    for (; j < b; j++) rank += key[j] < kx ? 1 : 0;
+    return rank;
+}
 AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per AASM_WAVE vertices
     RevPlaceLds *L = (RevPlaceLds *)k.lds;
     const int64_t row0 = k.bid * AASM_WAVE;
@@ -1040,14 +1051,27 @@ AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per 
         for (int64_t i = seg0 + k.lane; i < seg1; i += AASM_WAVE) L->key[i - seg0] = w.r_e[i];
         wave_lds_sync();
     }
+    if (!staged) {
+        // a run that does not fit holds lists of hundreds of entries: those one at a time, all lanes on one list, so
+        // that the key every lane compares with is ONE address (a broadcast read)
+        for (int32_t r = 0; r < nrows; r++) {
+            const int64_t p0 = L->ptr[r], len = L->ptr[r + 1] - p0;
+            if (len <= REV_REG_SORT) continue;
+            for (int64_t a = k.lane; a < len; a += AASM_WAVE) {
+                const int32_t kx = w.r_e[p0 + a];
+                const int32_t rank = rank_below(w.r_e + p0, 0, (int32_t)len, kx);
+                w.r_pk[p0 + rank] = w.tmp_pk[p0 + a];
+            }
+        }
+        return;
+    }
     for (int64_t i = seg0 + k.lane; i < seg1; i += AASM_WAVE) {
         int32_t lo = 0, hi = nrows;                                  // ptr[lo] <= i < ptr[hi]
         while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L->ptr[mid] <= i) lo = mid; else hi = mid; }
         const int64_t p0 = L->ptr[lo], p1 = L->ptr[lo + 1];
         if (p1 - p0 <= REV_REG_SORT) continue;
-        int32_t rank = 0;
-        if (staged) { const int32_t kx = L->key[i - seg0]; for (int64_t j = p0; j < p1; j++) rank += L->key[j - seg0] < kx ? 1 : 0; }
-        else { const int32_t kx = w.r_e[i]; for (int64_t j = p0; j < p1; j++) rank += w.r_e[j] < kx ? 1 : 0; }
+        const int32_t kx = L->key[i - seg0];
+        const int32_t rank = rank_below(L->key, (int32_t)(p0 - seg0), (int32_t)(p1 - seg0), kx);
         w.r_pk[p0 + rank] = w.tmp_pk[i];
     }
 }
