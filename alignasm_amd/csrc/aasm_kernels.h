@@ -61,8 +61,7 @@ struct WS {
     int64_t *tp_ptr, *te_wq;
     uint8_t *te_fl;
     // ---- SP-tree children CSR
-    int32_t *ccnt, *ccur, *cval;
-    int64_t *cptr;
+    int32_t *ccnt, *cval;                // SP-tree children: count per vertex, ids at cval[rptr[u] ..] (kb_children)
     // ---- heaps
     int64_t *hoff;
     int32_t *hcap_cnt;                   // per contig: capacity request (for the scan)
@@ -974,45 +973,6 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
     }
 }
 
-// sort every row of (key, payload) ascending by key; keys inside a row are distinct.
-// Lanes insertion-sort their own short rows; long rows are rank-sorted by the whole wave
-// through the tmp arrays (rows longer than `coop_len`: with a 16-byte payload a lane's insertion sort of a dozen
-// entries is dozens of dependent memory round trips the other 63 lanes wait for).  Rows of at most `skip_len`
-// entries are left alone (their reader sorts them in registers).
-template <class P>
-AASM_DEV void kb_sort_rows(const KCtx &k, const WS &w, const int64_t *ptr, int32_t *key, P *pay, P *tmp_pay, int64_t nrows, int64_t skip_len, int64_t coop_len) {
-    const int64_t row = k.bid * AASM_WAVE + k.lane;
-    const bool act = row < nrows;
-    const int64_t p0 = act ? ptr[row] : 0, L = act ? ptr[row + 1] - p0 : 0;
-    const bool big = L > coop_len;
-    if (act && !big && L > skip_len) {
-        for (int64_t a = 1; a < L; a++) {
-            const int32_t kx = key[p0 + a];
-            P px = P();
-            if (pay) px = pay[p0 + a];
-            int64_t t = a - 1;
-            while (t >= 0 && key[p0 + t] > kx) { key[p0 + t + 1] = key[p0 + t]; if (pay) pay[p0 + t + 1] = pay[p0 + t]; t--; }
-            key[p0 + t + 1] = kx; if (pay) pay[p0 + t + 1] = px;
-        }
-    }
-    uint64_t bigmask = wave_ballot(big);
-    while (bigmask) {
-        const int src = ffs64(bigmask) - 1;
-        bigmask &= bigmask - 1;
-        const int64_t q0 = wave_bcast(p0, src), QL = wave_bcast(L, src);
-        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) {
-            const int32_t kx = key[q0 + a];
-            int64_t rank = 0;
-            for (int64_t t = 0; t < QL; t++) rank += key[q0 + t] < kx ? 1 : 0;
-            w.tmp_a[q0 + rank] = kx;
-            if (pay) tmp_pay[q0 + rank] = pay[q0 + a];
-        }
-        wave_fence();
-        for (int64_t a = k.lane; a < QL; a += AASM_WAVE) { key[q0 + a] = w.tmp_a[q0 + a]; if (pay) pay[q0 + a] = tmp_pay[q0 + a]; }
-        wave_fence();
-    }
-}
-
 // In-lists longer than REV_REG_SORT entries (dense graphs: ~25 on average) go from the order the atomics of
 // kb_rev_fill landed in (r_e = edge id, tmp_pk = record) to list order in r_pk: an entry's place is the number of
 // smaller edge ids in its list (they are distinct).  A wave owns the in-lists of AASM_WAVE consecutive vertices - one
@@ -1381,22 +1341,23 @@ AASM_DEV void kb_topo_fill(const KCtx &k, const WS &w) {            // wave per 
 // ====================================================================================
 // K7  sidetrack heaps (k_shortest_walks.hpp:191-215; leftist_heap.hpp:29-40)
 // ====================================================================================
-AASM_DEV void kb_child_count(const KCtx &k, const WS &w) {          // thread per vertex
+// children of u in the SP tree (:191-194), ascending id: the vertices v with best[v] == u.  Such a v has an edge
+// v -> u, so it is a source in u's in-list - which is in ascending (source, position) order already; parallel edges of
+// one source are neighbours there.  The list is written over the front of u's OWN in-list slots (cval is indexed
+// like r_pk): no counting pass, no scan, no atomics, nothing to sort.
+AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
     const int64_t vb = w.voff[w.v_ctg[gv]];
-    const int32_t p = w.sp_best[gv];
-    if (p >= 0) atomic_add(&w.ccnt[vb + p], (int32_t)1);
-}
-AASM_DEV void kb_child_fill(const KCtx &k, const WS &w) {           // thread per vertex
-    const int64_t gv = k.bid * k.nthreads + k.tid;
-    if (gv >= w.VT) return;
-    const int64_t vb = w.voff[w.v_ctg[gv]];
-    const int32_t p = w.sp_best[gv];
-    if (p >= 0) {
-        const int64_t pos = w.cptr[vb + p] + atomic_add(&w.ccur[vb + p], (int32_t)1);
-        w.cval[pos] = (int32_t)(gv - vb);
+    const int32_t u = (int32_t)(gv - vb);
+    const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
+    int32_t n = 0, prev = -1;
+    for (int64_t t = r0; t < r1; t++) {
+        const int32_t src = w.r_pk[t].x;
+        if (src != prev && w.sp_best[vb + src] == u) w.cval[r0 + n++] = src;
+        prev = src;
     }
+    w.ccnt[gv] = n;
 }
 // K7 pre-pass 1, thread per vertex u (k_shortest_walks.hpp:204-210 without the insert): the sidetrack cost
 // c = w + d[v] - d[u] of every out-edge that goes into u's heap - not when d[v] is max() (:204-205), and not
@@ -1444,7 +1405,7 @@ AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
     const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
-    const int64_t c0 = w.cptr[gv], c1 = w.cptr[gv + 1];
+    const int64_t c0 = w.rptr[gv], c1 = c0 + w.ccnt[gv];          // (kb_children: the list sits at the front of the in-list slots)
     const int32_t fc = (c1 > c0) ? w.cval[c0] : -1;
     I4 a, b;
     a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;

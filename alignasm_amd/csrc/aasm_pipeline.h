@@ -22,7 +22,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILD_COUNT, KN_CHILD_FILL, KN_SORT_ROWS_CHILD, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -48,9 +48,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_FWD_SWEEP: kb_fwd_sweep<AASM_WAVE>(k, w); break;
         case KN_REV_SWEEP_G: kb_rev_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_FWD_SWEEP_G: kb_fwd_sweep<AASM_SWEEP_G>(k, w); break;
-        case KN_CHILD_COUNT: kb_child_count(k, w); break;
-        case KN_CHILD_FILL: kb_child_fill(k, w); break;
-        case KN_SORT_ROWS_CHILD: kb_sort_rows<int32_t>(k, w, w.cptr, w.cval, (int32_t *)nullptr, (int32_t *)nullptr, w.VT, 1, 32); break;
+        case KN_CHILDREN: kb_children(k, w); break;
         case KN_HEAP_CAP: kb_heap_cap(k, w); break;
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
@@ -234,16 +232,13 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
         // ---- K7 heaps
         be.phase_begin(AASM_PH_HEAP_PREP);
-        AZ(ccnt, int32_t, VT, "ccnt"); AZ(ccur, int32_t, VT, "ccur"); A(cptr, int64_t, VT + 1, "cptr"); A(cval, int32_t, VT, "cval");
+        A(ccnt, int32_t, VT, "ccnt"); A(cval, int32_t, ET, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
         A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off");
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
-        A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, VT, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
+        A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
         CHECK_ALLOC();
-        be.launch(KN_CHILD_COUNT, cdiv(VT, 256), 256, w);
-        be.scan_i32(w.ccnt, VT, w.cptr);
-        be.launch(KN_CHILD_FILL, cdiv(VT, 256), 256, w);
-        be.launch(KN_SORT_ROWS_CHILD, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
         be.launch(KN_SIDETRACK, cdiv(VT, 256), 256, w);
         be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
