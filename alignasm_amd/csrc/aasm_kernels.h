@@ -4,10 +4,10 @@
 //   K1  sort + parts ............. paf_data.cpp:241-261 ........ kb_sort, kb_sort_fix, kb_gather_parts
 //   K2  overlap pairs + cut ...... paf_data.cpp:294-378 ........ kb_ov_count, kb_ov_merge, kb_vcount, kb_vfill_*
 //   K3/4 linkable/get_score/make_Graph paf_data.cpp:422-696 .... kb_nsl, kb_row_count, kb_row_fill
-//   --  reversed CSR ............. k_shortest_walks.hpp:180-183 . kb_rev_fill, kb_sort_rows
+//   --  reversed CSR ............. k_shortest_walks.hpp:180-183 . kb_rev_fill, kb_rev_place, kb_rev_hdr
 //   K6  Kahn(rev)+DAG-SP ......... k_shortest_walks.hpp:132-175 . kb_rev_sweep
 //   K5/6 Kahn(fwd)+anomaly ....... paf_data.cpp:704-713,742-746 . kb_fwd_sweep
-//   K7  sidetrack heaps .......... k_shortest_walks.hpp:191-215, leftist_heap.hpp:29-40 .. kb_child_*, kb_heap
+//   K7  sidetrack heaps .......... k_shortest_walks.hpp:191-215, leftist_heap.hpp:29-40 .. kb_children, kb_sidetrack, kb_heap_hdr, kb_heap, kb_heap_mw
 //   K8  enumeration .............. k_shortest_walks.hpp:217-249 . kb_enum
 //   K9  recover/upgrade/select ... k_shortest_walks.hpp:254-290, paf_data.cpp:750-921,1489-1649 .. kb_select
 //
@@ -49,7 +49,7 @@ struct WS {
     int32_t *ctgV, *v_i, *v_j, *v_ctg;
     int64_t *voff, *v_slot;
     // ---- forward CSR + reversed CSR
-    int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e, *tmp_a;
+    int32_t *deg, *e_col, *e_wr, *indeg, *rcur, *r_e;
     I4 *tmp_pk;                          // the packed in-edge records as kb_rev_fill's atomics placed them (r_pk: in list order)
     int64_t *rowptr, *e_wq, *rptr;
     uint8_t *e_fl;
@@ -1049,7 +1049,7 @@ AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per 
 // instruction issue (profiles/r02_c3_pmc_sq.json), so a pop is written to cost few instructions and one memory
 // round trip:
 //  * every in-edge is ONE 16-byte record {source, qry weight (2 words), ref weight | flags << 24} (r_pk: written by
-//    kb_rev_fill, put in in-list order by kb_sort_rows), and kb_rev_hdr packs per vertex {in-list start,
+//    kb_rev_fill, put in in-list order by kb_rev_place / kb_rev_hdr), and kb_rev_hdr packs per vertex {in-list start,
 //    in-degree} plus its first two records (the mean in-degree is ~2) into 48 bytes (rvh);
 //  * the queue's front window lives in LDS, and an entry carries the vertex's 48-byte header and its final
 //    distance - both are known to the lane that appends the vertex (it fetched the header together with its

@@ -193,7 +193,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // ---- reversed CSR
         be.phase_begin(AASM_PH_REVCSR);
         A(rptr, int64_t, VT + 1, "rptr"); AZ(rcur, int32_t, VT, "rcur");
-        A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_a, int32_t, ET > VT ? ET : VT, "tmp_a"); A(tmp_pk, I4, ET, "tmp_pk");
+        A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
         be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
