@@ -1481,12 +1481,11 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 #define HEAP_QN 128
 #define HEAP_KMAX 16                      // sidetrack keys of a vertex that travel through the staging slot
 #define AASM_HEAP_LDS_BYTES 5696
-struct HeapStage { I4 a, b; Dist key[HEAP_KMAX]; };   // kb_heap_hdr's two header words + the first keys of one vertex
+struct HeapStage { Dist key[HEAP_KMAX]; };   // the first keys of one vertex
 struct HeapLds {
     HNode ring[HEAP_RING];
     I4 bq[HEAP_QN];
-    HeapStage stage;                      // context of the vertex popped next, parked here at the end of a step
-    int32_t tag;                          // ... and whose it is (-1: none)
+    HeapStage stage;                      // keys of the vertex popped next, parked here at the end of a step
 };
 static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
 struct Spine {
@@ -1658,30 +1657,31 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     {
         const I4 a0 = vh[dest];
         so = uni(a0.x); n = uni(a0.y);
-        if (k.lane == 0) L->tag = -1;
     }
     wave_lds_sync();
     int32_t pend_u = -1, pend_root = -1;                             // finished root of the previous vertex (lane 0), stored at the start of the next step
+    int32_t staged = -1;                                             // the vertex whose keys are parked in L->stage and whose header words are in c_* (-1: none)
+    int32_t c_nch = 0, c_fc = -1, c_sofc = 0, c_nfc = 0, c_c0lo = 0, c_c0hi = 0;   // {#children, first child, its key offset / #keys, child-list start}
     while (!hs.ovf) {
         HeapStage *S = &L->stage;
-        if (uni(L->tag) != u) {                                      // not staged (the root, a spilled queue entry): fetch now
+        if (staged != u) {                                           // not staged (the root, a spilled queue entry): fetch now
             const I4 ha = vh[u], hb = vh2[u];
             LaneArr<Dist> kk;
             FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) kk.at(t) = sk[(int64_t)so + t];
-            if (k.lane == 0) { S->a = ha; S->b = hb; }
+            c_nch = uni(ha.z); c_fc = uni(ha.w); c_sofc = uni(hb.z); c_nfc = uni(hb.w); c_c0lo = uni(hb.x); c_c0hi = uni(hb.y);
             FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) S->key[t] = kk.at(t);
             wave_lds_sync();
         }
-        const I4 ca = S->a, cb = S->b;
-        const int32_t nch = uni(ca.z), fc = uni(ca.w), so_fc = uni(cb.z), n_fc = uni(cb.w);
+        const int32_t nch = c_nch, fc = c_fc, so_fc = c_sofc, n_fc = c_nfc, c0lo = c_c0lo, c0hi = c_c0hi;
         KPROF_STAMP(0);                                              // context of this vertex
         // ---- every global store of this step, ahead of its loads: the root of the vertex before, the staged nodes
         if (pend_u >= 0) h[pend_u] = pend_root;                      // (lane 0 only: the pair lives in its vector registers)
         if (hs.alloc - hs.flushed >= HEAP_RING / 2) heap_flush(hs, k.lane);
         KPROF_STAMP(1);                                              // stores
         // ---- the vertex after this one: the queue front, or - the queue is empty, the tree path-like - the first child
-        int32_t v2 = -1, so2 = 0, n2 = 0;
-        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; v2 = uni(e.x); so2 = uni(e.z); n2 = uni(e.w); } }
+        int32_t v2 = -1, so2 = 0, n2 = 0, hu2 = -1;
+        bool peeked = false;                                         // the queue front has been read (the pop below takes it from here)
+        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; v2 = uni(e.x); hu2 = uni(e.y); so2 = uni(e.z); n2 = uni(e.w); peeked = true; } }
         else if (nch > 0) { v2 = fc; so2 = so_fc; n2 = n_fc; }
         I4 pa, pb;
         LaneArr<Dist> pk;
@@ -1704,11 +1704,11 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         KPROF_STAMP(3);                                              // inserts
         pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
         // ---- park the prefetched context (its loads had the whole step; this vertex's keys are used up)
-        if (v2 >= 0) {
-            if (k.lane == 0) { S->a = pa; S->b = pb; }
+        if (v2 >= 0) {                                               // (header words: straight into scalars - the loads are back by now)
+            c_nch = uni(pa.z); c_fc = uni(pa.w); c_sofc = uni(pb.z); c_nfc = uni(pb.w); c_c0lo = uni(pb.x); c_c0hi = uni(pb.y);
             FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) S->key[t] = pk.at(t);
         }
-        if (k.lane == 0) L->tag = v2;
+        staged = v2;
         // ---- children adopt the heap (:213)
         if (nch == 1 && head == tail) {                              // path-like tree: the only child is next, no queue traffic
             u = fc; so = so_fc; n = n_fc;
@@ -1718,7 +1718,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         if (nch > 0) {                                               // they enter the LDS queue window while it has room
             int32_t ncache = 0;
             if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
-            const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)uni(cb.y) << 32) | (uint32_t)uni(cb.x));
+            const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)c0hi << 32) | (uint32_t)c0lo);
             for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
                 const I4 ci = w.cinfo[c0 + t];
                 if (t < ncache) { I4 e; e.x = ci.x; e.y = hu; e.z = ci.y; e.w = ci.z; L->bq[(tail + t) & (HEAP_QN - 1)] = e; }
@@ -1731,7 +1731,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         KPROF_STAMP(4);                                              // children
         // ---- pop
         if (head >= tail) break;
-        if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
+        if (peeked) { u = v2; hu = hu2; so = so2; n = n2; }
+        else if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
         else {                                                       // spilled entry (the window was full when it was pushed)
             wave_fence();
             u = uni(q[head]); hu = uni(h[u]);
