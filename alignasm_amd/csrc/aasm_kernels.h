@@ -1120,12 +1120,12 @@ AASM_UNROLL
 // batches, 64 for dense ones: aasm_pipeline.h picks by mean degree): what used to be wave-uniform (queue head
 // and tail, the popped vertex) is uniform per lane group and lives in vector registers; ballots are cut to the
 // group's bits.
-#define AASM_SWEEP_G (AASM_WAVE >= 16 ? 16 : 1)
+#define AASM_SWEEP_G (AASM_WAVE >= 32 ? 32 : 1)
 template <int G> struct SweepGrp {
     static constexpr int N = AASM_WAVE / G;                          // contigs per wave
     int g, gl;
     AASM_MEM explicit SweepGrp(int lane) : g(lane / G), gl(lane % G) {}
-    AASM_MEM uint32_t bits(uint64_t m) const { return G >= 64 ? 0u : (uint32_t)(m >> (g * (G & 63))) & ((1u << (G & 31)) - 1u); }
+    AASM_MEM uint32_t bits(uint64_t m) const { return G >= 64 ? 0u : (uint32_t)((m >> (g * (G & 63))) & ((1ull << (G & 63)) - 1ull)); }
     AASM_MEM int32_t below(uint64_t m) const {                       // set bits of my group below my lane
         if (G >= 64) return popc64(m & lanemask_lt(gl));
         return __builtin_popcount(bits(m) & ((1u << gl) - 1u));

@@ -213,8 +213,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.fork();                                                   // side stream waits for everything enqueued so far
         be.use_side(true);
         be.phase_begin(AASM_PH_FWD);
-        // sparse batches (mean degree <= 6): several contigs per wave, AASM_SWEEP_G lanes each; dense ones: a wave per contig
-        const bool grouped = ET <= 6 * VT;
+        // big sparse batches (mean degree <= 6, thousands of contigs: bound by instruction issue): two contigs per wave,
+        // AASM_SWEEP_G lanes each; dense ones and small batches (bound by the chain per contig): a wave per contig
+        const bool grouped = ET <= 6 * VT && C >= 2560;            // (few contigs: a wave each - the scalar-uniform variant has the shorter chain per pop)
         const int64_t sweep_n = AASM_WAVE / AASM_SWEEP_G;
         if (grouped) be.launch(KN_FWD_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
         else be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
