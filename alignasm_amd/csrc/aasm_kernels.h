@@ -1116,8 +1116,9 @@ AASM_UNROLL
 
 // Contigs per wave: the graphs are long chains (~1.4 vertices per Kahn level, in-degree ~2), so a wave that
 // holds ONE contig issues every instruction of a pop for two busy lanes, and at 5 000 contigs the sweeps were
-// bound by instruction issue.  A wave therefore carries AASM_WAVE / G contigs, G lanes each (G = 16 for sparse
-// batches, 64 for dense ones: aasm_pipeline.h picks by mean degree): what used to be wave-uniform (queue head
+// bound by instruction issue.  A wave therefore carries AASM_WAVE / G contigs, G lanes each (G = 32 on big sparse
+// batches - 16 measured the same on 5 000 contigs and slower below -, 64 on dense or small ones, which are bound by
+// the chain per contig: aasm_pipeline.h picks): what used to be wave-uniform (queue head
 // and tail, the popped vertex) is uniform per lane group and lives in vector registers; ballots are cut to the
 // group's bits.
 #define AASM_SWEEP_G (AASM_WAVE >= 32 ? 32 : 1)
