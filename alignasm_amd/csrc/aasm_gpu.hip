@@ -376,10 +376,29 @@ struct GpuBackend {
     }
     bool failed() const { return fail; }
     bool oom() const { return out_of_memory; }
-    void zero(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
-    void fill_byte(void *p, int v, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, v, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
-    void fill_ff(void *p, size_t n) { if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    // zero fills of arrays that sit back to back in the arena (the AZ(...) runs of the pipeline) are merged into one
+    // memset: a request only extends the pending span; whatever touches the stream next issues it first
+    char *z_lo = nullptr, *z_hi = nullptr;
+    void flush_zero() {
+        if (!z_lo) return;
+        char *lo = z_lo; size_t n = (size_t)(z_hi - z_lo);
+        z_lo = z_hi = nullptr;
+        if (fail) return;
+        hipError_t e = hipMemsetAsync(lo, 0, n, stream);
+        if (e != hipSuccess) hip_fail("hipMemsetAsync", e);
+    }
+    void zero_alloc(void *p, size_t n) {                             // a WHOLE fresh allocation
+        if (!p || fail) return;
+        char *c = (char *)p;
+        if (z_lo && c >= z_hi && (size_t)(c - z_hi) <= 256) { z_hi = c + n; return; }   // (the gap is the allocator's alignment padding: nobody's data)
+        flush_zero();
+        z_lo = c; z_hi = c + n;
+    }
+    void zero(void *p, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void fill_byte(void *p, int v, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, v, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void fill_ff(void *p, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
+        flush_zero();
         if (fail || nblocks <= 0) return;
         dim3 g((unsigned)nblocks), b((unsigned)nthreads);
         switch (kn) {
@@ -400,6 +419,7 @@ struct GpuBackend {
         if (e != hipSuccess) hip_fail("kernel launch", e);
     }
     template <class T> void scan_t(const T *in, int64_t n, int64_t *out) {
+        flush_zero();
         if (fail) return;
         if (n <= 0) { zero(out, 8); return; }
         const int64_t nt = cdiv(n, SCAN_TILE);
@@ -420,6 +440,7 @@ struct GpuBackend {
     void scan_i32(const int32_t *in, int64_t n, int64_t *out) { scan_t<int32_t>(in, n, out); }
     void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { scan_t<uint8_t>(in, n, out); }
     int64_t read_i64(const int64_t *p) {
+        flush_zero();
         if (fail) return 0;
         hipError_t e = hipMemcpyAsync(cx.pinned, p, 8, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -431,6 +452,7 @@ struct GpuBackend {
     void read_i64s(std::initializer_list<const int64_t *> ps, int64_t *out) {
         int n = 0;
         for (auto p : ps) { (void)p; out[n++] = 0; }
+        flush_zero();
         if (fail) return;
         hipError_t e = hipSuccess;
         int i = 0;
@@ -441,22 +463,24 @@ struct GpuBackend {
         for (i = 0; i < n; i++) out[i] = cx.pinned[i];
     }
     void d2h(void *dst, const void *src, size_t n) {
+        flush_zero();
         if (fail || n == 0) return;
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) hip_fail("hipMemcpy D2H", e);
     }
     void h2d(void *dst, const void *src, size_t n) {
+        flush_zero();
         if (fail || n == 0) return;
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) hip_fail("hipMemcpy H2D", e);
     }
     // second stream: fork = side waits for the main stream's work so far; join = main waits for side
-    void fork() { if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
-    void use_side(bool on) { on_side = on; stream = on ? cx.side : main_stream; }
-    void join() { if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
-    void phase_begin(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_b[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); phase_used[ph] = true; } }
-    void phase_end(int ph) { if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_e[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); } }
+    void fork() { flush_zero(); if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
+    void use_side(bool on) { flush_zero(); on_side = on; stream = on ? cx.side : main_stream; }
+    void join() { flush_zero(); if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
+    void phase_begin(int ph) { flush_zero(); if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_b[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); phase_used[ph] = true; } }
+    void phase_end(int ph) { flush_zero(); if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_e[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); } }
 };
 
 }  // namespace aasm
@@ -486,6 +510,7 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     std::memset(&res->stats, 0, sizeof(res->stats));
     if (timing) hipEventRecord(cx.ev_t0, stream);
     int rc = run_pipeline(*be, dev_in, opts, res->w, res->sz);
+    be->flush_zero();
     if (timing) hipEventRecord(cx.ev_t1, stream);
     be->join();
     hipError_t e = hipStreamSynchronize(stream);

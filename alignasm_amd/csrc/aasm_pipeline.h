@@ -92,7 +92,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     if (C <= 0 || R <= 0) return AASM_E_INVAL;
 
 #define A(field, type, n, name) w.field = (type *)be.alloc(name, sizeof(type) * (size_t)((n) > 0 ? (n) : 1))
-#define AZ(field, type, n, name) do { A(field, type, n, name); be.zero(w.field, sizeof(type) * (size_t)((n) > 0 ? (n) : 1)); } while (0)
+#define AZ(field, type, n, name) do { A(field, type, n, name); be.zero_alloc(w.field, sizeof(type) * (size_t)((n) > 0 ? (n) : 1)); } while (0)
 // out of device memory -> AASM_E_NOMEM (the caller may split the contig range); any other HIP failure (launch,
 // memset, scan, read-back) -> AASM_E_HIP with the original error text, never retried
 #define CHECK_ALLOC() do { if (be.oom()) return AASM_E_NOMEM; if (be.failed()) return AASM_E_HIP; } while (0)

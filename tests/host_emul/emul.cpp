@@ -32,6 +32,7 @@ struct EmuBackend {
     bool failed() const { return fail; }
     bool oom() const { return fail; }
     void zero(void *p, size_t n) { memset(p, 0, n); }
+    void zero_alloc(void *p, size_t n) { memset(p, 0, n); }
     void fill_ff(void *p, size_t n) { memset(p, 0xFF, n); }
     void fill_byte(void *p, int v, size_t n) { memset(p, v, n); }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
