@@ -1467,9 +1467,9 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 //    loads one vertex later costs nothing extra;
 //  * fetches the next vertex's header and sidetrack keys one vertex ahead (kb_heap_hdr makes it predictable):
 //    the loads are issued right after the step's stores and their registers are only touched again at the END
-//    of the step, where they are parked in an LDS slot.  (Loads whose results are carried to
-//    the next loop iteration in registers do not survive the compiler: it copies them at the loop edge and
-//    waits for them on the spot - measured: 1 500-2 000 of 4 100 cycles per vertex.)
+//    of the step, where the keys are parked in an LDS slot and the header words become scalars (readfirstlane).
+//    (VECTOR load results carried to the next loop iteration in registers do not survive the compiler: it copies
+//    them at the loop edge and waits for them on the spot - measured: 1 500-2 000 of 4 100 cycles per vertex.)
 //   spine (registers)  80-96 % of the inserts continue from exactly the heap the last insert made, and an
 //                 insert's descent path is a prefix of its right spine.  A rank swap at position t sends the
 //                 new spine into an old left subtree: the cache then holds positions 0..t plus the node where
