@@ -70,3 +70,17 @@ def test_fuzz_emulation_vs_oracle_longer_contigs(T):
 def test_fuzz_hip_vs_oracle(T):
     api = T.api()
     _run(T, lambda hb, K, nsl: api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl), range(100, 130), 30)
+
+
+@pytest.mark.gpu
+def test_fuzz_hip_vs_oracle_many_contigs(T):
+    """Thousands of small adversarial contigs per batch: above 2 560 contigs the sweeps run two contigs per wave
+    (32 lanes each), which the six-contig batches above never reach."""
+    api = T.api()
+    for seed in (7, 8):
+        for style in (0, 1, 2):
+            hb = make_batch(seed, 2700, 14, 300, style)
+            for K, nsl in ((10000, False), (3, True)):
+                want = T.oracle_solve(hb, K, nsl)
+                got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl)
+                assert T.diff_outputs(want, got) == [], (seed, style, K, nsl)
