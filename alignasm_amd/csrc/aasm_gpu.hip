@@ -900,6 +900,30 @@ static int validate_batch(const aasm_batch_in *in) {
 
 
 
+// Make the device context and `bytes` of workspace arena ahead of the first solve (a fresh process pays the HIP start-up
+// and ~25 ms per GB of hipMalloc otherwise inside its first solve): callers run it on a thread of its own while they still
+// read their input.  Not finding the memory is not an error here - the solve allocates what it needs (and reports).
+int aasm_reserve_workspace(int device, int64_t bytes) {
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    DevCtx &cx = g_ctx[device];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    hipSetDevice(device);
+    size_t have = 0;
+    for (auto &b : cx.blocks) have += b.cap;
+    if (bytes <= 0 || have >= (size_t)bytes) return AASM_OK;
+    size_t want = (size_t)bytes - have, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;   // leave room for the input and the results
+    want &= ~(size_t)255;
+    if (want < ((size_t)64 << 20)) return AASM_OK;
+    char *p = nullptr;
+    hipError_t e = hipMalloc((void **)&p, want);
+    g_n_device_mallocs++;
+    if (e != hipSuccess) { (void)hipGetLastError(); return AASM_E_NOMEM; }
+    cx.blocks.push_back(ArenaBlock{p, want, 0});
+    return AASM_OK;
+}
+
 static void ctx_release_arena(int device) {
     DevCtx &cx = g_ctx[device];
     std::lock_guard<std::mutex> lk(cx.mu);

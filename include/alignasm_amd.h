@@ -212,6 +212,12 @@ typedef struct aasm_upload aasm_upload;
 int  aasm_upload_batch(const aasm_batch_in *host_in, int device, aasm_upload **up, aasm_batch_in *dev_view);
 void aasm_upload_free(aasm_upload *up);
 
+/* Start-up helper for a fresh process (no counterpart in the reference: its state is the CPU heap): creates the device
+ * context and grows the workspace arena to `bytes` (capped at half of the free device memory) so that the first solve
+ * does not pay HIP's start-up and the arena's hipMalloc calls.  Meant to run on a thread of its own while the caller
+ * still reads its input (the CLI does: ~3.7 bytes of arena per byte of PAF text).  AASM_E_NOMEM is harmless here. */
+int  aasm_reserve_workspace(int device, int64_t bytes);
+
 /* Debug/parity hook: copy a named device intermediate of a result solved with
  * opts.keep_debug=1 (names listed in DESIGN.md; e.g. "perm", "csr_col", "sp_d").
  * Call with dst==NULL to get the byte size.                                           */
