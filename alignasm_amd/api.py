@@ -85,6 +85,13 @@ def debug_counter(name):
     return int(LIB.aasm_debug_counter(name.encode()))
 
 
+def reserve_workspace(device=0, nbytes=0):
+    """Create the device context and grow its workspace arena to `nbytes` ahead of the first solve (a fresh process
+    otherwise pays HIP's start-up and the arena's hipMalloc calls inside it).  Returns the C-ABI code (0 = ok;
+    AASM_E_NOMEM only means the solve will allocate for itself)."""
+    return int(LIB.aasm_reserve_workspace(C.c_int(int(device)), C.c_int64(int(nbytes))))
+
+
 def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False,
               test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto"):
     o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)

@@ -255,3 +255,19 @@ def test_one_wave_heap_kernel_arena_is_bit_identical(T, case):
     res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves="none")
     assert T.diff_intermediates(hb, res.debug, K, nsl) == []
     res.close(); db.close()
+
+
+def test_reserved_workspace_serves_the_next_solve(T):
+    """aasm_reserve_workspace (what the CLI runs beside its reader): after it, a solve that fits the reservation
+    makes no device allocation of its own."""
+    api = T.api()
+    assert api.reserve_workspace(0, 3 << 30) == 0
+    hb = T.synth(300, 400, 19)
+    db = api.DeviceBatch(hb)
+    n0 = api.debug_counter("device_mallocs")
+    want = T.oracle_solve(hb, 4)
+    res = db.solve(max_paths=4)
+    assert api.debug_counter("device_mallocs") == n0
+    assert T.diff_outputs(want, res.fetch()) == []
+    res.close(); db.close()
+    assert api.reserve_workspace(99, 1 << 20) != 0          # no such device: an error code, not a crash
