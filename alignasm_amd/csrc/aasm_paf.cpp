@@ -696,35 +696,82 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
     return rc;
 }
 
-// One output file: contigs are cut into one contiguous share per host thread (balanced by
-// estimated output bytes), every thread formats its share into its own buffer, and the buffers are
-// written in contig order.
+// One output file, written in ROUNDS: a round is a contiguous run of contigs (a few MB of output per host thread),
+// cut into one share per thread; while the threads format round r + 1 into one set of buffers, a second set of
+// threads writes round r from the other set at offsets that are known by then (sizes of everything before it).
+// So the formatting runs beside the page-cache copy, and the buffers are a few MB each, reused, instead of one
+// fresh allocation the size of the file.  Rows leave in contig order, as process_output writes them.
 template <class EMIT>   // EMIT(contig, buf, err) -> rc : appends every line of one contig
 static int write_file_mt(const aasm_paf &paf, const char *path, const std::vector<int64_t> &weight_prefix, EMIT emit) {
     const int64_t C = paf.n_contigs();
+    const int64_t W = weight_prefix[C];
     int T = host_threads();
-    if (weight_prefix[C] < (1 << 20)) T = 1;
+    if (W < (1 << 20)) T = 1;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::string> bufs((size_t)T), errs((size_t)T);
+    int64_t R = W / ((int64_t)T * ((int64_t)4 << 20)) + 1;              // ~4 MB per thread and round
+    if (R > 256) R = 256;
+    auto cut_at = [&](int64_t w) {
+        int64_t c = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), w) - weight_prefix.begin();
+        return c > C ? C : c;
+    };
+    std::vector<int64_t> rcut((size_t)R + 1, C);
+    rcut[0] = 0;
+    for (int64_t r = 1; r < R; r++) { rcut[r] = cut_at(W * r / R); if (rcut[r] < rcut[r - 1]) rcut[r] = rcut[r - 1]; }
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
+    std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
+    std::vector<std::string> errs((size_t)T);
     std::vector<int> rcs((size_t)T, AASM_OK);
-    std::vector<int64_t> cut((size_t)T + 1, C);
-    cut[0] = 0;
-    for (int t = 1; t < T; t++)
-        cut[t] = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), weight_prefix[C] * t / T) - weight_prefix.begin();
-    for (int t = 1; t <= T; t++) { if (cut[t] > C) cut[t] = C; if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1]; }
-    run_threads(T, [&](int t) {
-            bufs[t].reserve((size_t)(weight_prefix[cut[t + 1]] - weight_prefix[cut[t]]) + 4096);   // the weights are byte estimates: no regrowth copies
-        for (int64_t c = cut[t]; c < cut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, bufs[t], errs[t]);
-    });
-    for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { set_last_error(errs[t]); return rcs[t]; }   // first failing contig in file order
-    const auto t1 = std::chrono::steady_clock::now();
-    const int rc = write_buffers(path, bufs);
-    if (std::getenv("AASM_IO_TIMING")) {
-        size_t total = 0;
-        for (auto &b : bufs) total += b.size();
-        std::fprintf(stderr, "aasm io: %s format %.3f s write %.3f s (%.1f MB, %d threads)\n", path, std::chrono::duration<double>(t1 - t0).count(),
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), total / 1e6, T);
+    std::vector<int64_t> off((size_t)T + 1, 0);                          // file offsets of the round being written
+    std::atomic<int> wrc{AASM_OK};
+    int64_t base = 0, total = 0;
+    int fail_rc = AASM_OK;
+    std::string fail_msg;
+    for (int64_t r = 0; r <= R && fail_rc == AASM_OK; r++) {             // step r: format round r (r < R), write round r - 1 (r > 0)
+        const int fset = (int)(r & 1), wset = fset ^ 1;
+        const bool do_f = r < R, do_w = r > 0;
+        std::vector<int64_t> tcut((size_t)T + 1, 0);
+        if (do_f) {
+            const int64_t c0 = rcut[r], c1 = rcut[r + 1], w0 = weight_prefix[c0], w1 = weight_prefix[c1];
+            tcut[0] = c0; tcut[T] = c1;
+            for (int t = 1; t < T; t++) { int64_t c = cut_at(w0 + (w1 - w0) * t / T); if (c < tcut[t - 1]) c = tcut[t - 1]; if (c > c1) c = c1; tcut[t] = c; }
+        }
+        run_threads((do_f ? T : 0) + (do_w ? T : 0), [&](int id) {
+            if (do_f && id < T) {                                        // ---- format my share of round r
+                const int t = id;
+                std::string &b = bufs[fset][t];
+                b.clear();
+                const size_t want = (size_t)(weight_prefix[tcut[t + 1]] - weight_prefix[tcut[t]]) + 4096;   // the weights are byte estimates: no regrowth copies
+                if (b.capacity() < want) b.reserve(want);
+                for (int64_t c = tcut[t]; c < tcut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, b, errs[t]);
+            } else {                                                     // ---- write my share of round r - 1
+                const int t = do_f ? id - T : id;
+                const std::string &b = bufs[wset][t];
+                const char *q = b.data();
+                int64_t left = (int64_t)b.size(), o = off[t];
+                while (left > 0) {
+                    const ssize_t wr = ::pwrite(fd, q, (size_t)std::min<int64_t>(left, 1 << 30), (off_t)o);
+                    if (wr <= 0) { wrc = AASM_E_IO; return; }
+                    q += wr; o += wr; left -= wr;
+                }
+            }
+        });
+        if (do_f) {
+            for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { fail_rc = rcs[t]; fail_msg = errs[t]; break; }   // first failing contig in file order
+            off[0] = base;
+            for (int t = 0; t < T; t++) off[t + 1] = off[t] + (int64_t)bufs[fset][t].size();
+            base = off[T];
+            total = base;
+        }
     }
+    int rc = fail_rc;
+    if (::close(fd) != 0 && rc == AASM_OK) rc = AASM_E_IO;
+    if (rc == AASM_OK && wrc != AASM_OK) rc = wrc;
+    if (fail_rc != AASM_OK) set_last_error(fail_msg);
+    else if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
+    if (std::getenv("AASM_IO_TIMING"))
+        std::fprintf(stderr, "aasm io: %s format + write %.3f s (%.1f MB, %d threads x %lld rounds)\n", path,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), total / 1e6, T, (long long)R);
     return rc;
 }
 

@@ -190,3 +190,29 @@ def test_writers_match_io_oracle(T, tmp_path, case):
         assert b"xi:Z:A_" in want[0] + want[1] + want[2]
     cut = sum(1 for ln in want[0].decode().splitlines() if ln.split("\t")[14] not in text.decode())
     assert cut > 0
+
+
+def test_writer_in_several_rounds_matches_io_oracle(T, tmp_path):
+    """The writer formats and writes in rounds of ~4 MB per host thread (formatting of round r + 1 beside the write of
+    round r): tens of MB of output over 3 threads = several rounds and shares, byte-identical to the oracle-side renderer."""
+    api, io = T.api(), T.io_oracle()
+    text = api.Paf.synth(260, 150, 23, dup_every=5).to_text()
+    st = io.read_paf(text)
+    paf = api.Paf.parse(text)
+    hb = T.io_oracle_batch(st)
+    K = 6
+    sol = T.oracle_solve(hb, K)
+    want = io.render_outputs(st, sol)
+    from alignasm_amd._abi import BatchOut, Opts
+    out = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(hb.view), C.byref(Opts(K, 0, 0, 0, 0)), 2, C.byref(out)) == 0
+    paths = [str(tmp_path / n) for n in ("y.aln.paf", "y.aln.alt.paf", "y.aln.all.paf")]
+    prev = api.set_host_threads(3)
+    try:
+        paf.write_outputs(out, *paths)
+    finally:
+        api.set_host_threads(prev)
+    T.oracle().oracle_free_out(C.byref(out))
+    got = [open(p, "rb").read() for p in paths]
+    assert len(want[0]) > 3 * (4 << 20)                           # more than one round of three 4 MB shares
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
