@@ -26,6 +26,7 @@ struct WS {
     // ---- sizes / options
     int64_t C, R, R0, S, VT, ET;
     int32_t K, nsl;
+    int32_t avg_sidetracks;              // mean #sidetracks per contig of the batch (K7's wave priority)
     // ---- input batch (device), original record order; rec_off already points at the chunk
     const int64_t *rec_off, *in_qs, *in_qe, *in_rs, *in_re, *in_qt, *in_rng_off, *rql, *rqr, *rrl;
     const int32_t *in_chr;
@@ -1642,6 +1643,16 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (w.mw_flag[c]) return;                                        // wide trees: kb_heap_mw
+#if !defined(AASM_HOST_EMUL)
+    {   // The launch ends with its longest contig while thousands of waves share the issue slots: contigs with more
+        // inserts than the batch's mean get a higher wave priority, so the tail starts ahead instead of last.
+        const int64_t I = (w.rowptr[vb + V] - w.rowptr[vb]) - (V - 1);
+        const int64_t a = w.avg_sidetracks > 0 ? w.avg_sidetracks : 1;
+        if (8 * I > 9 * a) __builtin_amdgcn_s_setprio(3);
+        else if (I > a) __builtin_amdgcn_s_setprio(2);
+        else if (8 * I > 7 * a) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     if (k.lane == 0) w.h_cnt[c] = 0;
     if (w.status[c] != 0) return;
     if (dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)

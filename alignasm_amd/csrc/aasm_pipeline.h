@@ -249,6 +249,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW}, hh);
         const int64_t HT = hh[0], HTM = hh[1], NMW = HTM > 0 ? hh[2] : 0;
         sz.HT = HT;
+        w.avg_sidetracks = (int32_t)std::min<int64_t>((ET - VT + C) / (C > 0 ? C : 1), INT32_MAX);
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
         A(hprov, HNode, HTM, "hprov");
         A(mw_order, int32_t, VT, "mw_order"); A(mw_rs, int32_t, VT, "mw_rs"); A(mw_fb, int32_t, VT, "mw_fb"); A(mw_rsv, int32_t, VT, "mw_rsv"); A(mw_used, int32_t, VT, "mw_used");
