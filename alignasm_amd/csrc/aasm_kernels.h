@@ -148,7 +148,7 @@ struct CsScan {
 };
 AASM_DEV void cs_close_op(CsScan &s, const WS &w) {                  // the open operation is complete
     if (s.t == ':') {                                                // :42-49, then :101-107
-        if (s.plen < 1 || s.plen > 18 || s.val <= 0 || s.n >= s.cnt) { s.bad = true; return; }
+        if (s.plen < 1 || s.val <= 0 || s.n >= s.cnt) { s.bad = true; return; }   // (a length beyond int64 has set val = -1: from_chars' out_of_range)
         if (s.fwd) {
             const int64_t o = s.o0 + s.n;
             w.rql_w[o] = s.q; w.rqr_w[o] = s.q + s.val - 1; w.rrl_w[o] = s.rr;
@@ -197,7 +197,11 @@ AASM_DEV void kb_cs_ranges(const KCtx &k, const WS &w) {
             } else if (s.t == ':') {
                 const unsigned dg = (unsigned)(c - '0');
                 if (dg > 9u) s.bad = true;
-                else { if (s.plen < 18) s.val = s.val * 10 + dg; s.plen++; }
+                else {                                               // std::from_chars<int64_t>: any number of digits, leading zeros included, value <= INT64_MAX
+                    const uint64_t nv = (uint64_t)s.val * 10u + dg;
+                    s.val = (s.val < 0 || s.val > INT64_MAX / 10 || nv > (uint64_t)INT64_MAX) ? -1 : (int64_t)nv;
+                    s.plen = 1;
+                }
             } else if (s.t && (unsigned)((c | 32) - 'a') < 26u) s.plen++;
             else s.bad = true;                                       // not a cs character, or payload before any operation (:66-68)
         }

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos.so")
 REF_MONO_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos_mono.so")
+REF_CS_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_cs.so")
 EMUL_SO = os.path.join(ROOT, "tests", "host_emul", "libaasm_emul.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -68,6 +69,103 @@ def ref(mono=True):
             getattr(lib, fn).restype = C.c_int64
         _cache[key] = lib
     return _cache[key]
+
+
+def ref_cs():
+    """oracle/_ref/libaasm_ref_cs.so: the REAL get_overlap_range / get_edited_paf_data (paf_data.cpp:15-220), or None."""
+    if "rcs" not in _cache:
+        if not os.path.exists(REF_CS_SO):
+            return None
+        lib = C.CDLL(REF_CS_SO)
+        lib.ref_cs_overlap_range.restype = C.c_int64
+        lib.ref_cs_edit.restype = C.c_int64
+        _cache["rcs"] = lib
+    return _cache["rcs"]
+
+
+_cs_buf = {}
+
+
+def _cs_bufs(cap):
+    if _cs_buf.get("cap", 0) < cap:
+        _cs_buf.update(cap=cap, a=[np.zeros(cap, np.int64) for _ in range(4)], err=C.create_string_buffer(256), out=C.create_string_buffer(1 << 16))
+    return _cs_buf
+
+
+def ref_cs_ranges(row):
+    """Reference get_overlap_range on a tests/cs_cases.py row -> ("ok", [(ql, qr, rl, rr), ...]) or ("err", code, text)."""
+    cs = row["cs"].encode()
+    b = _cs_bufs(max(64, len(cs)))
+    n = ref_cs().ref_cs_overlap_range(cs, C.c_int64(len(cs)), 1 if row["fwd"] else 0, C.c_int64(row["qs"]), C.c_int64(row["qe"]), C.c_int64(row["rs"]),
+                                      C.c_int64(row["re"]), _P(b["a"][0]), _P(b["a"][1]), _P(b["a"][2]), _P(b["a"][3]), C.c_int64(b["cap"]), b["err"], C.c_int64(256))
+    if n < 0:
+        return ("err", int(n), b["err"].value.decode())
+    return ("ok", [tuple(int(b["a"][k][i]) for k in range(4)) for i in range(n)])
+
+
+def ref_cs_edit(row, clip, mat_num=7, aln_len=9):
+    """Reference get_edited_paf_data -> ("ok", cs, mat_num, aln_len, is_cut) or ("err", code, text)."""
+    cs = row["cs"].encode()
+    b = _cs_bufs(max(64, len(cs)))
+    m, al, cut = C.c_int32(mat_num), C.c_int32(aln_len), C.c_int32(-1)
+    n = ref_cs().ref_cs_edit(cs, C.c_int64(len(cs)), 1 if row["fwd"] else 0, C.c_int64(row["qs"]), C.c_int64(row["qe"]), C.c_int64(row["rs"]), C.c_int64(row["re"]),
+                             C.c_int64(clip[0]), C.c_int64(clip[1]), C.c_int64(clip[2]), C.c_int64(clip[3]),
+                             b["out"], C.c_int64(len(b["out"])), C.byref(m), C.byref(al), C.byref(cut), b["err"], C.c_int64(256))
+    if n < 0:
+        return ("err", int(n), b["err"].value.decode())
+    assert n < len(b["out"])
+    return ("ok", b["out"].value.decode(), m.value, al.value, bool(cut.value))
+
+
+def product_cs_ranges(row):
+    """Product host codec (aasm_cs_match_ranges) in the same shape; the product stores no ref_r (derivable)."""
+    a = api()
+    cs = row["cs"].encode()
+    b = _cs_bufs(max(64, len(cs)))
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    n = a.LIB.aasm_cs_match_ranges(cs, C.c_int64(len(cs)), 1 if row["fwd"] else 0, C.c_int64(row["qs"]), C.c_int64(row["qe"]), C.c_int64(row["rs"]),
+                                   C.c_int64(row["re"]), P(b["a"][0]), P(b["a"][1]), P(b["a"][2]), C.c_int64(b["cap"]))
+    if n < 0:
+        return ("err", int(n), a.LIB.aasm_last_error().decode())
+    step = 1 if row["fwd"] else -1
+    return ("ok", [(int(b["a"][0][i]), int(b["a"][1][i]), int(b["a"][2][i]), int(b["a"][2][i] + (b["a"][1][i] - b["a"][0][i]) * step)) for i in range(n)])
+
+
+def product_cs_edit(row, clip, mat_num=7, aln_len=9):
+    a = api()
+    cs = row["cs"].encode()
+    b = _cs_bufs(max(64, len(cs)))
+    m, al, cut = C.c_int32(mat_num), C.c_int32(aln_len), C.c_int32(-1)
+    n = a.LIB.aasm_cs_edit(cs, C.c_int64(len(cs)), 1 if row["fwd"] else 0, C.c_int64(row["qs"]), C.c_int64(row["qe"]), C.c_int64(clip[0]), C.c_int64(clip[1]),
+                           C.c_int64(clip[2]), C.c_int64(clip[3]), b["out"], C.c_int64(len(b["out"])), C.byref(m), C.byref(al), C.byref(cut))
+    if n < 0:
+        return ("err", int(n), a.LIB.aasm_last_error().decode())
+    return ("ok", b["out"].value.decode(), m.value, al.value, bool(cut.value))
+
+
+def io_cs_ranges(row):
+    """oracle/paf_io_oracle.py get_overlap_range in the same shape."""
+    io = io_oracle()
+    r = io.PafRow()
+    r.aln_fwd, r.qry_str, r.qry_end, r.ref_str, r.ref_end, r.cs_string = row["fwd"], row["qs"], row["qe"], row["rs"], row["re"], row["cs"]
+    try:
+        io.get_overlap_range(r, row["cs"])
+    except io.CsError as e:
+        return ("err", -1, str(e))
+    return ("ok", [(q[0], q[1], f[0], f[1]) for q, f in zip(r.qry_rng, r.ref_rng)])
+
+
+def io_cs_edit(row, clip, mat_num=7, aln_len=9):
+    io = io_oracle()
+    r = io.PafRow()
+    r.aln_fwd, r.qry_str, r.qry_end, r.ref_str, r.ref_end, r.cs_string = row["fwd"], row["qs"], row["qe"], row["rs"], row["re"], row["cs"]
+    r.mat_num, r.aln_len = mat_num, aln_len
+    try:
+        return ("ok",) + tuple(io.get_edited_paf_data(clip[0], clip[1], clip[2], clip[3], r))
+    except io.CsLogicError as e:
+        return ("err", -3, str(e))
+    except io.CsError as e:
+        return ("err", -1, str(e))
 
 
 def api():

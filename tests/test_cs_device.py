@@ -37,6 +37,7 @@ TAGS = [
     b":" + b"9" * 7 + b"+a",                              # 7-digit length
     (b":12*ac" * 30) + b":4",                             # many short operations: lengths straddle window ends
     b":3" + b"+a:1" * 70,
+    b":007*ac:00000000000000000000005+GG:0012",           # leading zeros, any digit count (std::from_chars), upper-case letters (isalpha)
 ]
 
 
@@ -107,7 +108,9 @@ BAD = [
     b":10?:5",                   # not a cs character
     b"10:5",                     # does not start with an operation
     b":5:-3",                    # negative length
-    b":1234567890123456789",     # 19 digits
+    b":1234567890123456789",     # 19 digits: a legal length that the coordinates do not consume
+    b":9223372036854775808",     # beyond int64: from_chars' out_of_range
+    b":99999999999999999999",
 ]
 
 
