@@ -20,7 +20,7 @@ def _row(cs, fwd=True, qs=100, ql=None, rl=None, name=b"ctg1"):
 def _consumed(cs):
     import re
     q = r = 0
-    for op in re.findall(rb":[0-9]+|\*[a-z][a-z]|[+-][a-z]+", cs):
+    for op in re.findall(rb":[0-9]+|\*[A-Za-z][A-Za-z]|[+-][A-Za-z]+", cs):
         if op[:1] == b":": q += int(op[1:]); r += int(op[1:])
         elif op[:1] == b"*": q += 1; r += 1
         elif op[:1] == b"+": q += len(op) - 1
