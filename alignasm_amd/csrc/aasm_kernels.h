@@ -71,7 +71,8 @@ struct WS {
     // ---- enumeration
     Dist *kd;
     int32_t *klast, *knodes, *kprev, *kfound;
-    PqK *pq;                             // K8: 8-ary heap of 32-byte keys, 3K + 1 per contig
+    PqK *pq;                             // K8: queue storage, pq_stride entries per contig (heap form: 3K + 1; run form: enum_stride(K), aasm_enum.h)
+    int64_t pq_stride;
     int64_t *kcq;                        // K8: qry_score of every candidate, by insertion index
     // ---- selection / outputs
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;    // (u,v) pairs, 2*(N+2) ints per contig
@@ -2062,7 +2063,7 @@ AASM_DEV void pq8_drop_top(Pq8 &q, int lane) {                      // the last 
     if (q.n > 0) pq8_sink_from_root(q, x, lane);
 }
 
-AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave per contig
+AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave per contig (the d-ary heap form: host emulation, and the device cross-check of kb_enum_lsm)
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (k.lane == 0) w.kfound[c] = 0;
@@ -2072,7 +2073,7 @@ AASM_DEV void kb_enum(const KCtx &k, const WS &w) {                 // one wave 
     Dist *kd = w.kd + c * K;
     int32_t *klast = w.klast + c * K, *knodes = w.knodes + c * (3 * K + 1), *kprev = w.kprev + c * (3 * K + 1);
     int64_t *kcq = w.kcq + c * (3 * K + 1);                          // qry_score of candidate `cur` (the key carries the sum)
-    Pq8 q; q.g = w.pq + c * (3 * K + 1); q.l = (PqK *)k.lds; q.n = 0; q.pc_idx = -1;
+    Pq8 q; q.g = w.pq + c * w.pq_stride; q.l = (PqK *)k.lds; q.n = 0; q.pc_idx = -1;
     static_assert(PQ8_LDS_N * sizeof(PqK) <= AASM_ENUM_LDS_BYTES, "LDS budget");
     const HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t *h = w.h_root + vb;

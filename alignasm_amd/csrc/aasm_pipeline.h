@@ -16,13 +16,14 @@
 
 #include "../../include/alignasm_amd.h"
 #include "aasm_kernels.h"
+#include "aasm_enum.h"
 
 namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -54,7 +55,12 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
         case KN_HEAP: kb_heap(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
-        case KN_ENUM: kb_enum(k, w); break;
+#if defined(AASM_HOST_EMUL)
+        case KN_ENUM: case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
+#else
+        case KN_ENUM: kb_enum_lsm(k, w); break;
+        case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
+#endif
         case KN_SELECT: kb_select(k, w); break;
         case KN_GATHER_OUT: kb_gather_out(k, w); break;
         case KN_TOPO_COUNT: kb_topo_count(k, w); break;
@@ -266,10 +272,12 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // ---- K8 enumeration
         const int64_t K = w.K;
         A(kd, Dist, C * K, "kd"); A(klast, int32_t, C * K, "klast");
-        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PqK, C * (3 * K + 1), "pq"); A(kcq, int64_t, C * (3 * K + 1), "kcq");
+        const bool enum_heap = B::host_emulation || (opts.reserved[0] & 8) != 0;   // reserved[0] bit 3 (tests): the d-ary heap form on the device too
+        w.pq_stride = enum_heap ? 3 * K + 1 : enum_stride(K);
+        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PqK, C * w.pq_stride, "pq"); A(kcq, int64_t, C * (3 * K + 1), "kcq");
         CHECK_ALLOC();
         be.phase_begin(AASM_PH_ENUM);
-        be.launch(KN_ENUM, C, AASM_WAVE, w);
+        be.launch(enum_heap ? KN_ENUM_HEAP : KN_ENUM, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_ENUM);
     }
 

@@ -17,6 +17,7 @@ using namespace aasm;
 
 namespace {
 struct EmuBackend {
+    static constexpr bool host_emulation = true;
     std::vector<void *> blocks;
     std::map<std::string, std::pair<void *, size_t>> named;
     bool fail = false;
