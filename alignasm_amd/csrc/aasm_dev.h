@@ -51,6 +51,7 @@ AASM_DEV void store_drain() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
 AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { int32_t o = *p; if (v < o) *p = v; return o; }
+AASM_DEV void atomic_max_i64(int64_t *p, int64_t v) { if (v > *p) *p = v; }
 AASM_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __builtin_ffsll((long long)m); }
 #else
@@ -93,6 +94,7 @@ AASM_DEV unsigned long long atomic_add(int64_t *p, int64_t v) {
     return atomicAdd((unsigned long long *)p, (unsigned long long)v);
 }
 AASM_DEV int32_t atomic_min_i32(int32_t *p, int32_t v) { return atomicMin(p, v); }
+AASM_DEV void atomic_max_i64(int64_t *p, int64_t v) { atomicMax((long long *)p, (long long)v); }   // (non-negative values)
 AASM_DEV int popc64(uint64_t m) { return __popcll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __ffsll((long long)m); }
 #endif

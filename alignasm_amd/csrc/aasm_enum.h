@@ -10,21 +10,34 @@
 //
 //  F   the |F| <= 64 smallest entries of the whole queue, SORTED, one per lane, in registers.
 //      pop = the front lane (a head index moves; nothing shifts).  A push smaller than max(F) is
-//      placed with one compare + ballot + one DPP wave shift of the 11 registers of an entry.
+//      placed with one compare + ballot + one DPP wave shift of the 7 registers of an entry.
 //  I   insertion buffer (LDS, 64 entries, unsorted): every other push, three lanes at a time.
 //  R   sorted runs in global memory, one per level of a binary LSM tree (run of level l: <= 64 << l
 //      entries).  A full I is sorted by a 21-stage bitonic network across the lanes and merged down
 //      the levels: two sorted runs are merged 64 entries per step (the upper half of a 128-entry
 //      bitonic merge is carried, the next 2 KB block comes from the run whose last loaded entry is
-//      smaller), all loads and stores whole coalesced blocks.  An entry at position p of a sorted run
-//      has p smaller entries in front of it, so a merged run is CUT at K - found entries: what lies
-//      behind can never be popped.
+//      smaller; the next block of either run is already in flight), all loads and stores whole
+//      coalesced blocks.  An entry at position p of a sorted run has p smaller entries in front of
+//      it, so a merged run is CUT at K - found entries: what lies behind can never be popped.  The
+//      cut also yields a bound: once a run holds K - found entries, a push that is not smaller than
+//      its last one can never be popped either and is dropped at once (it still gets its insertion
+//      index and its candidate record, as every push of the reference does).
 //  refill (F ran empty): the 64 smallest of the run heads (one block per level, merged keeping the
 //      lower half, each entry tagged with its level so the heads can be advanced).
 //
+// Order key.  (Distance, node, index) compares the score sum, then anom, then the ratio
+// qul_nonzero / qul_total (higher first, by cross-multiplication: paf_data.hpp:142-159), then node and
+// index.  Cross-multiplying in every compare-exchange of the networks would cost four quarter-rate
+// multiplies per stage, so a push computes ONE 64-bit key2 = anom << 42 | (2^42 - 1 - r) with
+// r = trunc(RN_double(qnz * 2^41 / max(qtot, 1))): qtot <= path edges <= N + 1 < 2^20 (the host picks the
+// heap form for a batch with a longer contig), so two different ratios differ by more than 2^-40, their
+// correctly rounded quotients by more than 1, and equal ratios give the same quotient: r orders exactly
+// as the cross-multiplication does.  An entry is then three unsigned 64-bit words (sum, key2, node:index),
+// compared lexicographically.
+//
 // The memory latency of a pop (heap node of the popped entry -> root of the cross heap -> keys of the
 // <= 3 successors: three dependent round trips) is paid once per REFILL for 64 entries at a time:
-// every lane of F fetches the successor keys of its own entry and parks them in LDS (96 B per entry);
+// every lane of F fetches the successor keys of its own entry and parks them in LDS (128 B per entry);
 // an entry pushed straight into F is fetched the first time an unfetched entry reaches the front,
 // together with every other unfetched one.  A pop then touches registers and LDS only.
 #pragma once
@@ -39,43 +52,41 @@ namespace aasm {
 AASM_HD int64_t enum_k64(int64_t K) { return (K + 63) / 64 * 64; }
 AASM_HD int32_t enum_lmax(int64_t K) { int32_t l = 0; while (((int64_t)64 << l) < enum_k64(K)) l++; return l; }
 AASM_HD int64_t enum_stride(int64_t K) { return 128 * (((int64_t)1 << enum_lmax(K)) - 1) + 3 * enum_k64(K); }
+#define AASM_ENUM_MAX_N (((int64_t)1 << 20) - 2)     // longest contig (records) the key2 form is exact for
 }  // namespace aasm
 
 #if !defined(AASM_HOST_EMUL)
 
 namespace aasm {
 
+struct __attribute__((aligned(8))) I2 { int32_t x, y; };
 #define EQ_ILEN 64
 #define EQ_IFLUSH 58                     // flush I when it holds more than this (a pop adds <= 3 entries)
 #define EQ_MAXLEV 28
 struct EnumLds {
-    I4 succ[64][3][2];                   // per F slot: successor j = {key delta: sum (2 words), qry (2 words)}, {anom, qnz, qtot, heap node | -1}
-    I4 ibuf[EQ_ILEN][2];                 // I: {sum (2), anom, qnz}, {qtot, node, cur, prev}
+    // per F slot, nine quads.  The entry itself: [0] {qry (2 words), anom, qnz}, [1].xy {qtot, prev}.  Its successors (cross heap
+    // root, left, right), COMPLETE but for the insertion index: j at [2 + 2j] {sum (2), key2 (2)}, [3 + 2j] {qry (2), heap node | -1, anom},
+    // and their {qnz, qtot} pairs at [1].zw, [8].xy, [8].zw
+    I4 slot[64][9];
+    I2 ibuf[EQ_ILEN][3];                 // I: {sum}, {key2}, {index, node}
     int32_t run_slot[EQ_MAXLEV], run_head[EQ_MAXLEV], run_end[EQ_MAXLEV];
 };
-#define AASM_ENUM2_LDS_BYTES (64 * 96 + EQ_ILEN * 32 + 3 * EQ_MAXLEV * 4)
+#define AASM_ENUM2_LDS_BYTES (64 * 144 + EQ_ILEN * 24 + 3 * EQ_MAXLEV * 4)
 static_assert(sizeof(EnumLds) <= AASM_ENUM2_LDS_BYTES, "LDS budget");
 
-struct QE { int64_t sum; int32_t anom, qnz, qtot, node, cur, prev, tag; };   // tag: refill only (source level)
-AASM_DEV QE qe_inf() { QE e; e.sum = INT64_MAX; e.anom = e.qnz = e.qtot = e.node = e.cur = e.prev = e.tag = 0; return e; }
-AASM_DEV bool qe_less_v(const QE &a, const QE &b) {                  // pq_full_less on entries, branch-free (one per lane)
-    const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
-    const int64_t l = (int64_t)a.qnz * (int64_t)tb, r = (int64_t)b.qnz * (int64_t)ta;
-    const int64_t ia = (int64_t)(((uint64_t)(uint32_t)a.node << 32) | (uint32_t)a.cur), ib = (int64_t)(((uint64_t)(uint32_t)b.node << 32) | (uint32_t)b.cur);
-    return (a.sum < b.sum) | ((a.sum == b.sum) & ((a.anom < b.anom) | ((a.anom == b.anom) & ((l > r) | ((l == r) & (ia < ib))))));
+struct QE { uint64_t sum, key2, nc; int32_t tag; };                  // nc = node << 32 | insertion index; tag: refill only (source level)
+#define QE_INF_SUM 0x7fffffffffffffffull
+AASM_DEV QE qe_inf() { QE e; e.sum = QE_INF_SUM; e.key2 = 0; e.nc = 0; e.tag = 0; return e; }
+AASM_DEV bool qe_less(const QE &a, const QE &b) {                    // score sums are non-negative: unsigned order == signed order
+    return (a.sum < b.sum) | ((a.sum == b.sum) & ((a.key2 < b.key2) | ((a.key2 == b.key2) & (a.nc < b.nc))));
 }
-AASM_DEV bool qe_less_s(const QE &a, const QE &b) {                  // the same on wave-uniform values
-    if (a.sum != b.sum) return a.sum < b.sum;
-    if (a.anom != b.anom) return a.anom < b.anom;
-    const int32_t ta = a.qtot ? a.qtot : 1, tb = b.qtot ? b.qtot : 1;
-    const int64_t l = (int64_t)a.qnz * (int64_t)tb, r = (int64_t)b.qnz * (int64_t)ta;
-    if (l != r) return l > r;
-    if (a.node != b.node) return a.node < b.node;
-    return a.cur < b.cur;
+AASM_DEV uint64_t qe_key2(int32_t anom, int32_t qnz, int32_t qtot) {
+    const double r = (double)((uint64_t)(uint32_t)qnz << 41) / (double)(qtot ? qtot : 1);
+    return ((uint64_t)(uint32_t)anom << 42) | ((((uint64_t)1 << 42) - 1) - (uint64_t)r);
 }
-AASM_DEV int32_t hi32(int64_t x) { return (int32_t)((uint64_t)x >> 32); }
-AASM_DEV int32_t lo32(int64_t x) { return (int32_t)(uint32_t)(uint64_t)x; }
-AASM_DEV int64_t mk64(int32_t lo, int32_t hi) { return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); }
+AASM_DEV int32_t hi32(uint64_t x) { return (int32_t)(x >> 32); }
+AASM_DEV int32_t lo32(uint64_t x) { return (int32_t)(uint32_t)x; }
+AASM_DEV uint64_t mk64(int32_t lo, int32_t hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; }
 
 // value of lane (lane ^ M): DPP inside a row of 16, ds_swizzle inside 32 lanes, bpermute across the halves
 template <int M> AASM_DEV int32_t lane_xor(int32_t x, int lane) {
@@ -87,26 +98,24 @@ template <int M> AASM_DEV int32_t lane_xor(int32_t x, int lane) {
     else if (M == 4 || M == 8 || M == 16 || M == 31) return __builtin_amdgcn_ds_swizzle(x, (M << 10) | 0x1F);
     else return __builtin_amdgcn_ds_bpermute((lane ^ M) << 2, x);
 }
+template <int M> AASM_DEV uint64_t lane_xor64(uint64_t x, int lane) { return mk64(lane_xor<M>(lo32(x), lane), lane_xor<M>(hi32(x), lane)); }
 template <int M> AASM_DEV QE qe_xor(const QE &e, int lane) {
     QE p;
-    p.sum = mk64(lane_xor<M>(lo32(e.sum), lane), lane_xor<M>(hi32(e.sum), lane));
-    p.anom = lane_xor<M>(e.anom, lane); p.qnz = lane_xor<M>(e.qnz, lane); p.qtot = lane_xor<M>(e.qtot, lane);
-    p.node = lane_xor<M>(e.node, lane); p.cur = lane_xor<M>(e.cur, lane); p.prev = lane_xor<M>(e.prev, lane); p.tag = lane_xor<M>(e.tag, lane);
+    p.sum = lane_xor64<M>(e.sum, lane); p.key2 = lane_xor64<M>(e.key2, lane); p.nc = lane_xor64<M>(e.nc, lane); p.tag = lane_xor<M>(e.tag, lane);
     return p;
 }
 AASM_DEV QE qe_sel(bool take, const QE &p, const QE &e) {
     QE r;
-    r.sum = take ? p.sum : e.sum; r.anom = take ? p.anom : e.anom; r.qnz = take ? p.qnz : e.qnz; r.qtot = take ? p.qtot : e.qtot;
-    r.node = take ? p.node : e.node; r.cur = take ? p.cur : e.cur; r.prev = take ? p.prev : e.prev; r.tag = take ? p.tag : e.tag;
+    r.sum = take ? p.sum : e.sum; r.key2 = take ? p.key2 : e.key2; r.nc = take ? p.nc : e.nc; r.tag = take ? p.tag : e.tag;
     return r;
 }
-// compare-exchange with lane ^ M: the lower lane of a pair keeps the smaller entry
+// compare-exchange with lane ^ M: the lower lane of a pair keeps the smaller entry (entries are distinct, except
+// +inf padding, which may swap with itself)
 template <int M> AASM_DEV void qe_cx(QE &e, int lane) {
     constexpr int HB = M >= 32 ? 32 : M >= 16 ? 16 : M >= 8 ? 8 : M >= 4 ? 4 : M >= 2 ? 2 : 1;
     const QE p = qe_xor<M>(e, lane);
-    const bool lower = (lane & HB) == 0;
-    const bool pl = qe_less_v(p, e), el = qe_less_v(e, p);
-    e = qe_sel(lower ? pl : el, p, e);
+    const bool upper = (lane & HB) != 0;
+    e = qe_sel(qe_less(p, e) != upper, p, e);
 }
 AASM_DEV void qe_sort64(QE &e, int lane) {                          // bitonic sort, flip formulation: 21 stages
     qe_cx<1>(e, lane);
@@ -116,40 +125,45 @@ AASM_DEV void qe_sort64(QE &e, int lane) {                          // bitonic s
     qe_cx<31>(e, lane); qe_cx<8>(e, lane); qe_cx<4>(e, lane); qe_cx<2>(e, lane); qe_cx<1>(e, lane);
     qe_cx<63>(e, lane); qe_cx<16>(e, lane); qe_cx<8>(e, lane); qe_cx<4>(e, lane); qe_cx<2>(e, lane); qe_cx<1>(e, lane);
 }
-AASM_DEV void qe_clean64(QE &e, int lane) {                         // a bitonic sequence of 64 -> sorted
-    qe_cx<32>(e, lane); qe_cx<16>(e, lane); qe_cx<8>(e, lane); qe_cx<4>(e, lane); qe_cx<2>(e, lane); qe_cx<1>(e, lane);
-}
-// x, y sorted ascending (one entry per lane) -> x = the 64 smallest of both, y = the 64 largest, both sorted
+// x, y sorted ascending (one entry per lane) -> x = the 64 smallest of both, y = the 64 largest, both sorted: the flip
+// stage leaves two bitonic sequences, six half-cleaners each sort them (interleaved: two independent chains)
 AASM_DEV void qe_merge(QE &x, QE &y, int lane, bool want_hi) {
     const QE yr = qe_xor<63>(y, lane);
-    const bool sw = qe_less_v(yr, x);
+    const bool sw = qe_less(yr, x);
     const QE lo = qe_sel(sw, yr, x), hi = qe_sel(sw, x, yr);
     x = lo; y = hi;
-    qe_clean64(x, lane);
-    if (want_hi) qe_clean64(y, lane);
+    if (want_hi) {
+        qe_cx<32>(x, lane); qe_cx<32>(y, lane); qe_cx<16>(x, lane); qe_cx<16>(y, lane); qe_cx<8>(x, lane); qe_cx<8>(y, lane);
+        qe_cx<4>(x, lane); qe_cx<4>(y, lane); qe_cx<2>(x, lane); qe_cx<2>(y, lane); qe_cx<1>(x, lane); qe_cx<1>(y, lane);
+    } else {
+        qe_cx<32>(x, lane); qe_cx<16>(x, lane); qe_cx<8>(x, lane); qe_cx<4>(x, lane); qe_cx<2>(x, lane); qe_cx<1>(x, lane);
+    }
 }
+AASM_DEV uint64_t uni_u64(uint64_t x, int j) { return mk64(__builtin_amdgcn_readlane(lo32(x), j), __builtin_amdgcn_readlane(hi32(x), j)); }
 AASM_DEV QE qe_uni(const QE &e, int j) {                            // the entry lane j holds (wave-uniform j)
-    QE r;
-    r.sum = mk64(__builtin_amdgcn_readlane(lo32(e.sum), j), __builtin_amdgcn_readlane(hi32(e.sum), j));
-    r.anom = __builtin_amdgcn_readlane(e.anom, j); r.qnz = __builtin_amdgcn_readlane(e.qnz, j); r.qtot = __builtin_amdgcn_readlane(e.qtot, j);
-    r.node = __builtin_amdgcn_readlane(e.node, j); r.cur = __builtin_amdgcn_readlane(e.cur, j); r.prev = __builtin_amdgcn_readlane(e.prev, j); r.tag = 0;
-    return r;
+    QE r; r.sum = uni_u64(e.sum, j); r.key2 = uni_u64(e.key2, j); r.nc = uni_u64(e.nc, j); r.tag = 0; return r;
 }
-// a 64-entry block of a run: entry (at + lane), or +inf behind the end
+// a 64-entry block of a run: entry (at + lane), or +inf behind the end.  32 bytes per entry: {sum, key2}, {node:index, -}
 AASM_DEV QE qe_load(const PqK *g, int32_t at, int32_t end, int lane) {
     QE e = qe_inf();
     if (at + lane < end) {
         const I4 *p = (const I4 *)(g + at + lane);
-        const I4 a = p[0], b = p[1];
-        e.sum = mk64(a.x, a.y); e.anom = a.z; e.qnz = a.w; e.qtot = b.x; e.node = b.y; e.cur = b.z; e.prev = b.w;
+        const I4 a = p[0];
+        const I2 b = *(const I2 *)(p + 1);
+        e.sum = mk64(a.x, a.y); e.key2 = mk64(a.z, a.w); e.nc = mk64(b.x, b.y);
     }
     return e;
 }
 AASM_DEV void qe_store(PqK *g, int32_t at, const QE &e) {
     I4 *p = (I4 *)(g + at);
-    I4 a, b;
-    a.x = lo32(e.sum); a.y = hi32(e.sum); a.z = e.anom; a.w = e.qnz; b.x = e.qtot; b.y = e.node; b.z = e.cur; b.w = e.prev;
-    p[0] = a; p[1] = b;
+    I4 a; I2 b;
+    a.x = lo32(e.sum); a.y = hi32(e.sum); a.z = lo32(e.key2); a.w = hi32(e.key2); b.x = lo32(e.nc); b.y = hi32(e.nc);
+    p[0] = a; *(I2 *)(p + 1) = b;
+}
+AASM_DEV void qe_to_lds(I2 *dst, const QE &e) {
+    I2 a, b, c;
+    a.x = lo32(e.sum); a.y = hi32(e.sum); b.x = lo32(e.key2); b.y = hi32(e.key2); c.x = lo32(e.nc); c.y = hi32(e.nc);
+    dst[0] = a; dst[1] = b; dst[2] = c;
 }
 
 struct EnumQ {
@@ -158,6 +172,7 @@ struct EnumQ {
     int32_t lmax, k64;
     int32_t in;                          // entries in I
     int32_t nruns;                       // non-empty levels
+    QE bound;                            // nothing >= bound can still be popped (+inf: no bound yet)
 };
 AASM_DEV int32_t eq_cap(const EnumQ &q, int32_t l) { const int64_t c = (int64_t)64 << l; return l < q.lmax && c < q.k64 ? (int32_t)c : q.k64; }
 AASM_DEV PqK *eq_slot(const EnumQ &q, int32_t l, int32_t s) {
@@ -166,28 +181,35 @@ AASM_DEV PqK *eq_slot(const EnumQ &q, int32_t l, int32_t s) {
 }
 
 // out[0 .. out_len) <- the out_len smallest of (carry, if has_carry) + A[0 .. a_len) + B[0 .. b_len); the inputs are sorted.
-// With has_carry the A run is not read (a_len = 0): the carry is the sorted block in registers.
-AASM_DEV void eq_merge(const PqK *A, int32_t a_len, const PqK *B, int32_t b_len, PqK *out, int32_t out_len, QE carry, bool has_carry, int lane) {
+// With has_carry the A run is not read (a_len = 0): the carry is the sorted block in registers.  Returns the last
+// entry written when the output was cut short of the input (the queue's bound), +inf otherwise.
+AASM_DEV QE eq_merge(const PqK *A, int32_t a_len, const PqK *B, int32_t b_len, PqK *out, int32_t out_len, QE carry, int32_t c_len, bool has_carry, int lane) {
+    const bool cut = out_len < (has_carry ? c_len : a_len) + b_len;
     int32_t ia = 0, ib = 0, o = 0;
     QE lastA = qe_inf(), lastB = qe_inf();
-    lastB.sum = INT64_MIN;                                           // "nothing loaded yet": the first block comes from B
+    lastB.sum = 0; lastB.key2 = 0;                                   // "nothing loaded yet": the first block comes from B
     if (!has_carry) { carry = qe_load(A, 0, a_len, lane); ia = 64; lastA = qe_uni(carry, 63); } else a_len = 0;
+    QE nA = qe_load(A, ia, a_len, lane), nB = qe_load(B, 0, b_len, lane);   // the next block of either run, in flight
+    QE last = qe_inf();
     while (o < out_len) {
         const bool availA = ia < a_len, availB = ib < b_len;
         if (!availA && !availB) break;
         // next block: from the run whose last loaded entry is smaller (all entries not loaded yet are then >= every
         // entry this step emits); an exhausted run leaves the choice to the other one
-        const bool takeA = availA && (!availB || qe_less_s(lastA, lastB));
+        const bool takeA = availA && (!availB || qe_less(lastA, lastB));
         QE blk;
-        if (takeA) { blk = qe_load(A, ia, a_len, lane); ia += 64; lastA = qe_uni(blk, 63); }
-        else { blk = qe_load(B, ib, b_len, lane); ib += 64; lastB = qe_uni(blk, 63); }
+        if (takeA) { blk = nA; ia += 64; lastA = qe_uni(blk, 63); nA = qe_load(A, ia, a_len, lane); }
+        else { blk = nB; ib += 64; lastB = qe_uni(blk, 63); nB = qe_load(B, ib, b_len, lane); }
         qe_merge(carry, blk, lane, true);
         if (o + lane < out_len) qe_store(out, o + lane, carry);
+        if (cut && out_len - o <= 64) last = qe_uni(carry, out_len - o - 1);
         o += 64;
         carry = blk;
     }
     if (o + lane < out_len) qe_store(out, o + lane, carry);          // (out_len never exceeds the number of real entries)
+    if (cut && o < out_len) last = qe_uni(carry, out_len - o - 1);
     wave_fence();                                                    // later block loads of this wave see the run
+    return last;
 }
 
 // I -> a sorted block, merged down the levels of the LSM tree (one run per level at rest; level l < lmax has two
@@ -195,8 +217,8 @@ AASM_DEV void eq_merge(const PqK *A, int32_t a_len, const PqK *B, int32_t b_len,
 AASM_DEV void eq_flush(EnumQ &q, int32_t keep, int lane) {
     QE s = qe_inf();
     if (lane < q.in) {
-        const I4 a = q.L->ibuf[lane][0], b = q.L->ibuf[lane][1];
-        s.sum = mk64(a.x, a.y); s.anom = a.z; s.qnz = a.w; s.qtot = b.x; s.node = b.y; s.cur = b.z; s.prev = b.w;
+        const I2 a = q.L->ibuf[lane][0], b = q.L->ibuf[lane][1], c = q.L->ibuf[lane][2];
+        s.sum = mk64(a.x, a.y); s.key2 = mk64(b.x, b.y); s.nc = mk64(c.x, c.y);
     }
     const int32_t n = q.in;
     q.in = 0;
@@ -221,7 +243,8 @@ AASM_DEV void eq_flush(EnumQ &q, int32_t keep, int lane) {
             const bool occ2 = uni(q.L->run_head[nl]) < uni(q.L->run_end[nl]);
             ns = occ2 ? (nl == top ? (s2 + 1) % 3 : 1 - s2) : 0;
         }
-        eq_merge(eq_slot(q, l, cslot), in_regs ? 0 : len, eq_slot(q, l, os) + oh, oe - oh, eq_slot(q, nl, ns), tot, s, in_regs, lane);
+        const QE last = eq_merge(eq_slot(q, l, cslot), in_regs ? 0 : len, eq_slot(q, l, os) + oh, oe - oh, eq_slot(q, nl, ns), tot, s, len, in_regs, lane);
+        if (last.sum != QE_INF_SUM && qe_less(last, q.bound)) q.bound = last;   // the run was cut at K - found entries: its last entry bounds the queue
         if (lane == 0) { q.L->run_head[l] = 0; q.L->run_end[l] = 0; }
         wave_lds_sync();
         q.nruns--;
@@ -243,13 +266,13 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     const int64_t vb = w.voff[c];
     const int32_t K = w.K;
     Dist *kd = w.kd + c * (int64_t)K;
-    int32_t *klast = w.klast + c * (int64_t)K, *knodes = w.knodes + c * (3 * (int64_t)K + 1), *kprev = w.kprev + c * (3 * (int64_t)K + 1);
-    int64_t *kcq = w.kcq + c * (3 * (int64_t)K + 1);
+    int32_t *klast = w.klast + c * (int64_t)K;
+    I4 *kcand = w.kcand + 2 * c * (3 * (int64_t)K + 1);
     const HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
     EnumQ q;
-    q.L = (EnumLds *)k.lds; q.g = w.pq + c * w.pq_stride; q.lmax = enum_lmax(K); q.k64 = (int32_t)enum_k64(K); q.in = 0; q.nruns = 0;
+    q.L = (EnumLds *)k.lds; q.g = w.pq + c * w.pq_stride; q.lmax = enum_lmax(K); q.k64 = (int32_t)enum_k64(K); q.in = 0; q.nruns = 0; q.bound = qe_inf();
     if (lane < EQ_MAXLEV) { q.L->run_slot[lane] = 0; q.L->run_head[lane] = 0; q.L->run_end[lane] = 0; }
     wave_lds_sync();
 
@@ -259,37 +282,30 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     const int32_t hs = uni(h[src]);
     if (hs < 0) { if (lane == 0) { w.kfound[c] = 1; atomic_add(&w.counters[CNT_PATHS], (int64_t)1); } return; }   // :227-228
 
-    // ---- F: sorted entries in lanes [hd, nf); f_slot = LDS successor slot | 0x100 while the successors are not fetched yet
+    // ---- F: sorted entries in lanes [hd, nf); f_slot = LDS slot of the entry | 0x100 while its successors are not fetched yet
     QE f = qe_inf();
-    int64_t f_qry = 0;
     int32_t f_slot = 0;
     int32_t hd = 0, nf = 0;
     uint64_t freemask = ~0ull;
     QE maxF = qe_inf();
 
-    auto f_insert = [&](const QE &x, int64_t xq) {                  // x (wave-uniform) into F; the caller has decided that it belongs there
-        const int32_t below = popc64(wave_ballot(lane >= hd && lane < nf && qe_less_v(f, x)));
-        int32_t pos = hd + below;
+    // x (wave-uniform; own = its {qry, anom, qnz}, {qtot, prev} words) into F; the caller has decided that it belongs there
+    auto f_insert = [&](const QE &x, const I4 &own0, const I4 &own1) {
+        const int32_t below = popc64(wave_ballot(lane >= hd && lane < nf && qe_less(f, x)));
+        const int32_t pos = hd + below;
         if (nf == 64 && hd == 0) {                                   // full: the largest entry leaves for I
-            if (lane == 63) {
-                I4 a, b;
-                a.x = lo32(f.sum); a.y = hi32(f.sum); a.z = f.anom; a.w = f.qnz; b.x = f.qtot; b.y = f.node; b.z = f.cur; b.w = f.prev;
-                q.L->ibuf[q.in][0] = a; q.L->ibuf[q.in][1] = b;
-            }
+            if (lane == 63) qe_to_lds(q.L->ibuf[q.in], f);
             freemask |= 1ull << (__builtin_amdgcn_readlane(f_slot, 63) & 63);
             q.in++; nf = 63;
         }
         const int32_t sl = ffs64(freemask) - 1;
         freemask &= ~(1ull << sl);
         bool mv; int32_t at;
-        QE t; int64_t tq; int32_t ts;
+        QE t; int32_t ts;
+#define EQ_SH(CTRL, v) __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false)
 #define EQ_SHIFT(CTRL) do { \
-            t.sum = mk64(__builtin_amdgcn_update_dpp(0, lo32(f.sum), CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, hi32(f.sum), CTRL, 0xf, 0xf, false)); \
-            t.anom = __builtin_amdgcn_update_dpp(0, f.anom, CTRL, 0xf, 0xf, false); t.qnz = __builtin_amdgcn_update_dpp(0, f.qnz, CTRL, 0xf, 0xf, false); \
-            t.qtot = __builtin_amdgcn_update_dpp(0, f.qtot, CTRL, 0xf, 0xf, false); t.node = __builtin_amdgcn_update_dpp(0, f.node, CTRL, 0xf, 0xf, false); \
-            t.cur = __builtin_amdgcn_update_dpp(0, f.cur, CTRL, 0xf, 0xf, false); t.prev = __builtin_amdgcn_update_dpp(0, f.prev, CTRL, 0xf, 0xf, false); t.tag = 0; \
-            tq = mk64(__builtin_amdgcn_update_dpp(0, lo32(f_qry), CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, hi32(f_qry), CTRL, 0xf, 0xf, false)); \
-            ts = __builtin_amdgcn_update_dpp(0, f_slot, CTRL, 0xf, 0xf, false); } while (0)
+            t.sum = mk64(EQ_SH(CTRL, lo32(f.sum)), EQ_SH(CTRL, hi32(f.sum))); t.key2 = mk64(EQ_SH(CTRL, lo32(f.key2)), EQ_SH(CTRL, hi32(f.key2))); \
+            t.nc = mk64(EQ_SH(CTRL, lo32(f.nc)), EQ_SH(CTRL, hi32(f.nc))); t.tag = 0; ts = EQ_SH(CTRL, f_slot); } while (0)
         if (nf < 64) {                                               // lanes [pos, nf) move up by one
             EQ_SHIFT(0x138);                                         // wave_shr:1: the value of lane - 1
             mv = lane > pos && lane <= nf; at = pos; nf++;
@@ -298,8 +314,9 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
             mv = lane >= hd - 1 && lane < pos - 1; at = pos - 1; hd--;
         }
 #undef EQ_SHIFT
-        f = qe_sel(mv, t, f); f_qry = mv ? tq : f_qry; f_slot = mv ? ts : f_slot;
-        if (lane == at) { f = x; f_qry = xq; f_slot = sl | 0x100; }
+#undef EQ_SH
+        f = qe_sel(mv, t, f); f_slot = mv ? ts : f_slot;
+        if (lane == at) { f = x; f_slot = sl | 0x100; q.L->slot[sl][0] = own0; q.L->slot[sl][1] = own1; }
         maxF = qe_uni(f, nf - 1);
     };
 
@@ -307,16 +324,21 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     {
         const HNode r0 = nodes[hs];
         const Dist d0 = dist_add(dsrc, hnode_key(r0));
-        QE x; x.sum = uni(d0.qry + d0.ref); x.anom = uni(d0.anom); x.qnz = uni(d0.qnz); x.qtot = uni(d0.qtot); x.node = hs; x.cur = 0; x.prev = -1; x.tag = 0;
-        if (lane == 0) { knodes[0] = hs; kprev[0] = -1; kcq[0] = d0.qry; }
+        QE x; x.sum = (uint64_t)uni(d0.qry + d0.ref); x.key2 = uni_u64(qe_key2(d0.anom, d0.qnz, d0.qtot), 0); x.nc = mk64(0, hs); x.tag = 0;
+        I4 o0, o1;
+        o0.x = uni(lo32((uint64_t)d0.qry)); o0.y = uni(hi32((uint64_t)d0.qry)); o0.z = uni(d0.anom); o0.w = uni(d0.qnz); o1.x = uni(d0.qtot); o1.y = -1; o1.z = 0; o1.w = 0;
+        if (lane == 0) { I4 cd; cd.x = hs; cd.y = -1; cd.z = o0.x; cd.w = o0.y; kcand[0] = cd; I4 ce; ce.x = o0.z; ce.y = o0.w; ce.z = o1.x; ce.w = 0; kcand[1] = ce; }
         nn = 1;
-        f_insert(x, uni(d0.qry));
+        f_insert(x, o0, o1);
     }
 
+    KPROF_DECL;
+    KPROF_START();
     while (found < K) {                                              // :240-248
+        KPROF_STAMP(0);                                              // pop + pushes
         const bool need_refill = hd == nf;
         if (need_refill && q.in == 0 && q.nruns == 0) break;         // queue empty
-        if (q.in > EQ_IFLUSH || (need_refill && q.in > 0)) { wave_lds_sync(); eq_flush(q, K - found, lane); }
+        if (q.in > EQ_IFLUSH || (need_refill && q.in > 0)) { wave_lds_sync(); eq_flush(q, K - found, lane); KPROF_STAMP(1); }
         if (need_refill) {
             // ---- the 64 smallest entries of the run heads
             QE cnd = qe_inf();
@@ -327,10 +349,10 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
                 blk.tag = l;
                 qe_merge(cnd, blk, lane, false);
             }
-            const uint64_t fin = wave_ballot(cnd.sum != INT64_MAX);
+            const uint64_t fin = wave_ballot(cnd.sum != QE_INF_SUM);
             nf = popc64(fin); hd = 0;
             for (int32_t l = 0; l <= q.lmax; l++) {
-                const int32_t took = popc64(wave_ballot(cnd.sum != INT64_MAX && cnd.tag == l));
+                const int32_t took = popc64(wave_ballot(cnd.sum != QE_INF_SUM && cnd.tag == l));
                 if (took) {
                     const int32_t rh = uni(q.L->run_head[l]) + took;
                     if (lane == 0) q.L->run_head[l] = rh;
@@ -339,92 +361,123 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
             }
             wave_lds_sync();
             f = cnd; f.tag = 0;
-            f_slot = lane | 0x100;
+            f_slot = lane | 0x200;                                   // 0x200: its own words are still in the candidate record
             freemask = nf >= 64 ? 0ull : ~((1ull << nf) - 1ull);
-            wave_fence();
-            f_qry = lane < nf ? kcq[f.cur] : 0;
             maxF = qe_uni(f, nf - 1);
+            wave_fence();                                            // candidate records written by lanes 0..2 of this wave
+            KPROF_STAMP(2);
         }
-        // ---- successors of every entry of F that has none yet: heap node -> cross root -> keys
-        if (__builtin_amdgcn_readlane(f_slot, hd) & 0x100) {
-            if (lane >= hd && lane < nf && (f_slot & 0x100)) {
-                const NodeQ ch = nodeq_load(nodes + f.node);
+        // ---- successors of every entry of F that has none yet: heap node -> cross root -> keys; each lane builds the complete
+        //      queue entries of its own entry's successors (their insertion index comes at the pop)
+        if (__builtin_amdgcn_readlane(f_slot, hd) & 0x300) {
+            if (lane >= hd && lane < nf && (f_slot & 0x300)) {
+                const int32_t sl = f_slot & 63;
+                const int32_t fnode = hi32(f.nc), fcur = lo32(f.nc);
+                I4 o0, o1;
+                if (f_slot & 0x200) {
+                    const I4 c0 = kcand[2 * (int64_t)fcur], c1 = kcand[2 * (int64_t)fcur + 1];
+                    o0.x = c0.z; o0.y = c0.w; o0.z = c1.x; o0.w = c1.y; o1.x = c1.z; o1.y = c0.y;
+                    q.L->slot[sl][0] = o0;
+                } else { o0 = q.L->slot[sl][0]; o1 = q.L->slot[sl][1]; }
+                const uint64_t oq = mk64(o0.x, o0.y);
+                const NodeQ ch = nodeq_load(nodes + fnode);
                 const int32_t cl = ch.q2.x, cr = ch.q2.y;
                 const int32_t hv = h[ch.q2.w];
                 const int32_t sid[3] = {hv, cl, cr};
-                const int64_t cq = mk64(ch.q0.x, ch.q0.y), cs = cq + mk64(ch.q0.z, ch.q0.w);
-                const int32_t sl = f_slot & 63;
+                const uint64_t cq = mk64(ch.q0.x, ch.q0.y), cs = cq + mk64(ch.q0.z, ch.q0.w);
+                int32_t pn[3], pt[3];
                 AASM_UNROLL
                 for (int j = 0; j < 3; j++) {
                     I4 a, b;
-                    a.x = a.y = a.z = a.w = 0; b.x = b.y = b.z = 0; b.w = -1;
+                    a.x = a.y = a.z = a.w = 0; b.x = b.y = b.w = 0; b.z = -1; pn[j] = 0; pt[j] = 0;
                     if (sid[j] >= 0) {
-                        const I4 *pn = (const I4 *)(nodes + sid[j]);
-                        const I4 n0 = pn[0], n1 = pn[1];
-                        int64_t dq = mk64(n0.x, n0.y), ds = dq + mk64(n0.z, n0.w);
+                        const I4 *np_ = (const I4 *)(nodes + sid[j]);
+                        const I4 n0 = np_[0], n1 = np_[1];
+                        uint64_t dq = mk64(n0.x, n0.y), ds = dq + mk64(n0.z, n0.w);
                         int32_t da = n1.x, dn = n1.y, dt = n1.z;
                         if (j > 0) { dq -= cq; ds -= cs; da -= ch.q1.x; dn -= ch.q1.y; dt -= ch.q1.z; }   // same heap: add the difference (:246-247)
-                        a.x = lo32(ds); a.y = hi32(ds); a.z = lo32(dq); a.w = hi32(dq); b.x = da; b.y = dn; b.z = dt; b.w = sid[j];
+                        const uint64_t ssum = f.sum + ds, sq = oq + dq;
+                        const int32_t sa = o0.z + da, sn = o0.w + dn, st = o1.x + dt;
+                        const uint64_t k2 = qe_key2(sa, sn, st);
+                        a.x = lo32(ssum); a.y = hi32(ssum); a.z = lo32(k2); a.w = hi32(k2);
+                        b.x = lo32(sq); b.y = hi32(sq); b.z = sid[j]; b.w = sa; pn[j] = sn; pt[j] = st;
                     }
-                    q.L->succ[sl][j][0] = a; q.L->succ[sl][j][1] = b;
+                    q.L->slot[sl][2 + 2 * j] = a; q.L->slot[sl][3 + 2 * j] = b;
                 }
+                o1.z = pn[0]; o1.w = pt[0];
+                I4 p8; p8.x = pn[1]; p8.y = pt[1]; p8.z = pn[2]; p8.w = pt[2];
+                q.L->slot[sl][1] = o1; q.L->slot[sl][8] = p8;
                 f_slot = sl;
             }
             wave_lds_sync();
+#if defined(AASM_KPROF)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            KPROF_STAMP(3);
         }
         // ---- pop (:241-244)
-        const QE top = qe_uni(f, hd);
-        const int64_t tq = mk64(__builtin_amdgcn_readlane(lo32(f_qry), hd), __builtin_amdgcn_readlane(hi32(f_qry), hd));
+        const uint64_t tsum = uni_u64(f.sum, hd);
+        const int32_t tcur = __builtin_amdgcn_readlane(lo32(f.nc), hd);
         const int32_t tslot = __builtin_amdgcn_readlane(f_slot, hd) & 63;
         hd++;
         freemask |= 1ull << tslot;
-        if (lane == 0) {
-            Dist dtop; dtop.qry = tq; dtop.ref = top.sum - tq; dtop.anom = top.anom; dtop.qnz = top.qnz; dtop.qtot = top.qtot; dtop.pad = 0;
-            kd[found] = dtop; klast[found] = top.cur;
-        }
-        found++;
+        const I4 t0 = q.L->slot[tslot][0], t1 = q.L->slot[tslot][1], t8 = q.L->slot[tslot][8];   // {qry, anom, qnz}, {qtot, prev, ..}
         // ---- its successors, one per lane (:245-247): cross heap root, left, right
-        QE x = qe_inf(); int64_t xq = 0;
+        QE x = qe_inf();
+        I4 x0, x1;
+        x0.x = x0.y = x0.z = x0.w = 0; x1.x = x1.y = x1.z = x1.w = 0;
         bool valid = false;
         if (lane < 3) {
-            const I4 a = q.L->succ[tslot][lane][0], b = q.L->succ[tslot][lane][1];
-            valid = b.w >= 0;
-            x.sum = top.sum + mk64(a.x, a.y); xq = tq + mk64(a.z, a.w);
-            x.anom = top.anom + b.x; x.qnz = top.qnz + b.y; x.qtot = top.qtot + b.z; x.node = b.w; x.prev = lane == 0 ? top.cur : top.prev;
+            const I4 a = q.L->slot[tslot][2 + 2 * lane], b = q.L->slot[tslot][3 + 2 * lane];
+            valid = b.z >= 0;
+            x.sum = mk64(a.x, a.y); x.key2 = mk64(a.z, a.w); x.nc = (uint64_t)(uint32_t)b.z << 32;
+            x0.x = b.x; x0.y = b.y; x0.z = b.w; x0.w = lane == 0 ? t1.z : lane == 1 ? t8.x : t8.z;
+            x1.x = lane == 0 ? t1.w : lane == 1 ? t8.y : t8.w; x1.y = lane == 0 ? tcur : t1.y;
         }
+        if (lane == 0) {
+            const uint64_t tq = mk64(t0.x, t0.y);
+            Dist dtop; dtop.qry = (int64_t)tq; dtop.ref = (int64_t)(tsum - tq); dtop.anom = t0.z; dtop.qnz = t0.w; dtop.qtot = t1.x; dtop.pad = 0;
+            kd[found] = dtop; klast[found] = tcur;
+        }
+        found++;
         const uint64_t vm = wave_ballot(valid);
         if (vm == 0) continue;
-        x.cur = nn + popc64(vm & lanemask_lt(lane));
-        if (valid) { knodes[x.cur] = x.node; kprev[x.cur] = x.prev; kcq[x.cur] = xq; }
+        const int32_t xcur = nn + popc64(vm & lanemask_lt(lane));
+        x.nc |= (uint32_t)xcur;
+        if (valid) {
+            I4 cd; cd.x = hi32(x.nc); cd.y = x1.y; cd.z = x0.x; cd.w = x0.y;
+            I4 ce; ce.x = x0.z; ce.y = x0.w; ce.z = x1.x; ce.w = 0;
+            kcand[2 * (int64_t)xcur] = cd; kcand[2 * (int64_t)xcur + 1] = ce;
+        }
         nn += popc64(vm);
+        const bool live = valid && qe_less(x, q.bound);              // (the others can never be popped: dropped here)
+        const uint64_t lm = wave_ballot(live);
+        if (lm == 0) continue;
         const bool room = q.in == 0 && q.nruns == 0 && (nf - hd) < 64;       // nothing behind F: F may grow at its end
-        const uint64_t fm = wave_ballot(valid && hd < nf && qe_less_v(x, maxF));
+        const uint64_t fm = wave_ballot(live && hd < nf && qe_less(x, maxF));
         if (fm == 0 && !room) {                                      // the usual case: all of them go to I
-            if (valid) {
-                const int32_t at = q.in + popc64(vm & lanemask_lt(lane));
-                I4 a, b;
-                a.x = lo32(x.sum); a.y = hi32(x.sum); a.z = x.anom; a.w = x.qnz; b.x = x.qtot; b.y = x.node; b.z = x.cur; b.w = x.prev;
-                q.L->ibuf[at][0] = a; q.L->ibuf[at][1] = b;
-            }
-            q.in += popc64(vm);
+            if (live) qe_to_lds(q.L->ibuf[q.in + popc64(lm & lanemask_lt(lane))], x);
+            q.in += popc64(lm);
         } else {
-            for (uint64_t m = vm; m; m &= m - 1) {
+            for (uint64_t m = lm; m; m &= m - 1) {
                 const int j = ffs64(m) - 1;
                 const QE xj = qe_uni(x, j);
-                const int64_t xjq = mk64(__builtin_amdgcn_readlane(lo32(xq), j), __builtin_amdgcn_readlane(hi32(xq), j));
-                const bool fits = hd < nf ? qe_less_s(xj, maxF) : false;
-                if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < 64)) f_insert(xj, xjq);
-                else {
-                    if (lane == 0) {
-                        I4 a, b;
-                        a.x = lo32(xj.sum); a.y = hi32(xj.sum); a.z = xj.anom; a.w = xj.qnz; b.x = xj.qtot; b.y = xj.node; b.z = xj.cur; b.w = xj.prev;
-                        q.L->ibuf[q.in][0] = a; q.L->ibuf[q.in][1] = b;
-                    }
+                const bool fits = hd < nf ? qe_less(xj, maxF) : false;
+                if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < 64)) {
+                    I4 o0, o1;
+                    o0.x = __builtin_amdgcn_readlane(x0.x, j); o0.y = __builtin_amdgcn_readlane(x0.y, j); o0.z = __builtin_amdgcn_readlane(x0.z, j); o0.w = __builtin_amdgcn_readlane(x0.w, j);
+                    o1.x = __builtin_amdgcn_readlane(x1.x, j); o1.y = __builtin_amdgcn_readlane(x1.y, j); o1.z = 0; o1.w = 0;
+                    f_insert(xj, o0, o1);
+                } else {
+                    if (lane == 0) qe_to_lds(q.L->ibuf[q.in], xj);
                     q.in++;
                 }
             }
         }
     }
+#if defined(AASM_KPROF)
+    if (w.K >= 1000) KPROF_FLUSH(w.prof_heap, c, lane);              // diagnostic build: K8's sections replace K7's in the dump
+#endif
     if (lane == 0) {
         w.kfound[c] = found;
         atomic_add(&w.counters[CNT_PATHS], (int64_t)found);

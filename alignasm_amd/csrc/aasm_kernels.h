@@ -70,10 +70,10 @@ struct WS {
     int32_t *h_root, *bq, *h_cnt;
     // ---- enumeration
     Dist *kd;
-    int32_t *klast, *knodes, *kprev, *kfound;
+    int32_t *klast, *kfound;
+    I4 *kcand;                           // K8: two quads per pushed candidate, by insertion index: {heap node, predecessor, qry_score (2 words)}, {anom, qul_nonzero, qul_total, -}
     PqK *pq;                             // K8: queue storage, pq_stride entries per contig (heap form: 3K + 1; run form: enum_stride(K), aasm_enum.h)
     int64_t pq_stride;
-    int64_t *kcq;                        // K8: qry_score of every candidate, by insertion index
     // ---- selection / outputs
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;    // (u,v) pairs, 2*(N+2) ints per contig
     Dist *dist2;
@@ -115,7 +115,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -682,6 +682,7 @@ AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread pe
         return;
     }
     w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
+    if (N > 4096) atomic_max_i64(&w.counters[CNT_MAXN], N);         // longest contig of the batch (K8 picks its queue form by it; short ones need not report)
 }
 
 AASM_DEV void kb_vfill_rec(const KCtx &k, const WS &w) {            // thread per record
@@ -1942,7 +1943,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
 //
 // The queue is a wave-cooperative 8-ARY heap of 32-byte keys {score sum, anom, qul_nonzero, qul_total, heap
 // node, insertion index}: everything the order needs (the query / reference split of the score is not part of
-// it and waits in a side array, kcq, until the candidate is popped).  The 8 children of a heap node are 256
+// it and waits in the candidate record, kcand, until the candidate is popped).  The 8 children of a heap node are 256
 // contiguous bytes, fetched by 8 lanes in one pass and min-reduced on the score sum by three DPP steps inside
 // the 8 lanes - equal sums are settled by a short scalar loop over the tied lanes - so a pop descends log8(n)
 // levels (6 for the 30 001 entries of K = 10 000) instead of log2(n) = 15; the top four levels (1 + 8 + 64 +
@@ -2071,8 +2072,8 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
     const int64_t vb = w.voff[c];
     const int64_t K = w.K;
     Dist *kd = w.kd + c * K;
-    int32_t *klast = w.klast + c * K, *knodes = w.knodes + c * (3 * K + 1), *kprev = w.kprev + c * (3 * K + 1);
-    int64_t *kcq = w.kcq + c * (3 * K + 1);                          // qry_score of candidate `cur` (the key carries the sum)
+    int32_t *klast = w.klast + c * K;
+    I4 *kcand = w.kcand + 2 * c * (3 * K + 1);                       // {heap node, predecessor, qry_score} of candidate `cur` (the key carries the sum)
     Pq8 q; q.g = w.pq + c * w.pq_stride; q.l = (PqK *)k.lds; q.n = 0; q.pc_idx = -1;
     static_assert(PQ8_LDS_N * sizeof(PqK) <= AASM_ENUM_LDS_BYTES, "LDS budget");
     const HNode *nodes = w.hnodes + w.hoff[c];
@@ -2086,7 +2087,7 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
     const int32_t hs = uni(h[src]);
     auto emplace = [&](const Dist &dd, int32_t hp, int32_t pre) {    // :232-237
         PqK x; x.sum = uni(dd.qry + dd.ref); x.anom = uni(dd.anom); x.qnz = uni(dd.qnz); x.qtot = uni(dd.qtot); x.node = hp; x.cur = nn; x.pad = 0;
-        if (L0) { knodes[nn] = hp; kprev[nn] = pre; kcq[nn] = dd.qry; }
+        if (L0) { I4 cd; cd.x = hp; cd.y = pre; cd.z = (int32_t)(uint32_t)(uint64_t)dd.qry; cd.w = (int32_t)((uint64_t)dd.qry >> 32); kcand[2 * (int64_t)nn] = cd; }
         pq8_push(q, x, k.lane);
         nn++;
     };
@@ -2101,9 +2102,10 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
             KPROF_STAMP(0);                                          // pop
             const int32_t tcur = top.cur, tnode = top.node;
             wave_fence();
-            Dist dtop; dtop.qry = uni(kcq[tcur]); dtop.ref = top.sum - dtop.qry; dtop.anom = top.anom; dtop.qnz = top.qnz; dtop.qtot = top.qtot; dtop.pad = 0;
+            const I4 tcd = kcand[2 * (int64_t)tcur];
+            Dist dtop; dtop.qry = uni((int64_t)(((uint64_t)(uint32_t)tcd.w << 32) | (uint32_t)tcd.z)); dtop.ref = top.sum - dtop.qry; dtop.anom = top.anom; dtop.qnz = top.qnz; dtop.qtot = top.qtot; dtop.pad = 0;
             const HNode ch = nodes[tnode];
-            const int32_t prev_of_top = uni(kprev[tcur]);
+            const int32_t prev_of_top = uni(tcd.y);
             if (L0) { kd[found] = dtop; klast[found] = tcur; }
             found++;
             const int32_t hv = uni(h[ch.v]);
@@ -2277,16 +2279,17 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     const WS &w = *s.w;
     const int64_t K = w.K;
     if (kidx < 0 || kidx >= w.kfound[s.c]) return 0;
-    const int32_t *knodes = w.knodes + s.c * (3 * K + 1), *kprev = w.kprev + s.c * (3 * K + 1);
+    const I4 *kcand = w.kcand + 2 * s.c * (3 * K + 1);
     const HNode *nodes = w.hnodes + w.hoff[s.c];
     int32_t ns = 0;
     int32_t cur = w.klast[s.c * K + kidx];
     while (cur != -1) {                                             // sidetrack chain, newest first
         if (ns >= s.cap) { s.err = true; return -1; }
-        const HNode nd = nodes[knodes[cur]];
+        const I4 cd = kcand[2 * (int64_t)cur];                       // {heap node, predecessor, ...}
+        const HNode nd = nodes[cd.x];
         if (s.lane == 0) { s.pathT[2 * ns] = nd.u; s.pathT[2 * ns + 1] = nd.v; }
         ns++;
-        cur = kprev[cur];
+        cur = cd.y;
     }
     wave_fence();
     sel_out_begin(s, s.pathA);

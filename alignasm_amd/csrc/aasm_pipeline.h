@@ -251,8 +251,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
         be.scan_i32(w.mw_cap, C, w.mw_off);
-        int64_t hh[3];
-        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW}, hh);
+        int64_t hh[4];
+        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN}, hh);
         const int64_t HT = hh[0], HTM = hh[1], NMW = HTM > 0 ? hh[2] : 0;
         sz.HT = HT;
         w.avg_sidetracks = (int32_t)std::min<int64_t>((ET - VT + C) / (C > 0 ? C : 1), INT32_MAX);
@@ -272,9 +272,11 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // ---- K8 enumeration
         const int64_t K = w.K;
         A(kd, Dist, C * K, "kd"); A(klast, int32_t, C * K, "klast");
-        const bool enum_heap = B::host_emulation || (opts.reserved[0] & 8) != 0;   // reserved[0] bit 3 (tests): the d-ary heap form on the device too
+        // queue form: sorted front + sorted runs (aasm_enum.h) unless a contig is too long for its packed ratio key; reserved[0] bit 3
+        // (tests) forces the d-ary heap form, which is also what the 1-lane host emulation runs
+        const bool enum_heap = B::host_emulation || (opts.reserved[0] & 8) != 0 || hh[3] > AASM_ENUM_MAX_N;
         w.pq_stride = enum_heap ? 3 * K + 1 : enum_stride(K);
-        A(knodes, int32_t, C * (3 * K + 1), "knodes"); A(kprev, int32_t, C * (3 * K + 1), "kprev"); A(pq, PqK, C * w.pq_stride, "pq"); A(kcq, int64_t, C * (3 * K + 1), "kcq");
+        A(kcand, I4, 2 * C * (3 * K + 1), "kcand"); A(pq, PqK, C * w.pq_stride, "pq");
         CHECK_ALLOC();
         be.phase_begin(AASM_PH_ENUM);
         be.launch(enum_heap ? KN_ENUM_HEAP : KN_ENUM, C, AASM_WAVE, w);

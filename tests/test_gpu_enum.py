@@ -32,8 +32,8 @@ def test_enumeration_queue_forms_agree_with_each_other_and_the_oracle(T, case):
         kd = res.debug("kd", T.DIST_DT)[:nc * K].copy()
         klast = res.debug("klast", np.int32)[:nc * K].copy()
         S = 3 * K + 1
-        knodes = res.debug("knodes", np.int32)[:nc * S].copy()
-        kprev = res.debug("kprev", np.int32)[:nc * S].copy()
+        cand = res.debug("kcand", np.int32)[:nc * S * 8].reshape(nc * S, 8)    # {heap node, predecessor, qry (2 words)}, {anom, qnz, qtot, -}
+        knodes, kprev = cand[:, 0].copy(), cand[:, 1].copy()
         got[form] = (kf, kd, klast, knodes, kprev, res.fetch())
         if form == "runs":
             assert T.diff_intermediates(hb, res.debug, K) == []      # kfound + every popped distance vs the oracle
