@@ -61,7 +61,8 @@ namespace aasm {
 
 struct __attribute__((aligned(8))) I2 { int32_t x, y; };
 #define EQ_ILEN 64
-#define EQ_IFLUSH 58                     // flush I when it holds more than this (a pop adds <= 3 entries)
+#define EQ_BATCH 16                      // entries popped per step at most (3 successors each: 48 lanes)
+#define EQ_IFLUSH 40                     // flush I when it holds more than this (a step of P pops adds <= 3 P entries; P <= (64 - in) / 3)
 #define EQ_MAXLEV 28
 struct EnumLds {
     // per F slot, nine quads.  The entry itself: [0] {qry (2 words), anom, qnz}, [1].xy {qtot, prev}.  Its successors (cross heap
@@ -70,8 +71,9 @@ struct EnumLds {
     I4 slot[64][9];
     I2 ibuf[EQ_ILEN][3];                 // I: {sum}, {key2}, {index, node}
     int32_t run_slot[EQ_MAXLEV], run_head[EQ_MAXLEV], run_end[EQ_MAXLEV];
+    int32_t freel[64];                   // stack of the F slots no entry uses
 };
-#define AASM_ENUM2_LDS_BYTES (64 * 144 + EQ_ILEN * 24 + 3 * EQ_MAXLEV * 4)
+#define AASM_ENUM2_LDS_BYTES (64 * 144 + EQ_ILEN * 24 + 3 * EQ_MAXLEV * 4 + 256)
 static_assert(sizeof(EnumLds) <= AASM_ENUM2_LDS_BYTES, "LDS budget");
 
 struct QE { uint64_t sum, key2, nc; int32_t tag; };                  // nc = node << 32 | insertion index; tag: refill only (source level)
@@ -79,6 +81,11 @@ struct QE { uint64_t sum, key2, nc; int32_t tag; };                  // nc = nod
 AASM_DEV QE qe_inf() { QE e; e.sum = QE_INF_SUM; e.key2 = 0; e.nc = 0; e.tag = 0; return e; }
 AASM_DEV bool qe_less(const QE &a, const QE &b) {                    // score sums are non-negative: unsigned order == signed order
     return (a.sum < b.sum) | ((a.sum == b.sum) & ((a.key2 < b.key2) | ((a.key2 == b.key2) & (a.nc < b.nc))));
+}
+AASM_DEV bool qe_less_u(const QE &a, const QE &b) {                  // the same on wave-uniform values
+    if (a.sum != b.sum) return a.sum < b.sum;
+    if (a.key2 != b.key2) return a.key2 < b.key2;
+    return a.nc < b.nc;
 }
 AASM_DEV uint64_t qe_key2(int32_t anom, int32_t qnz, int32_t qtot) {
     const double r = (double)((uint64_t)(uint32_t)qnz << 41) / (double)(qtot ? qtot : 1);
@@ -286,7 +293,8 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     QE f = qe_inf();
     int32_t f_slot = 0;
     int32_t hd = 0, nf = 0;
-    uint64_t freemask = ~0ull;
+    int32_t ftop = 64;                                               // free slots: q.L->freel[0 .. ftop)
+    q.L->freel[lane] = 63 - lane;
     QE maxF = qe_inf();
 
     // x (wave-uniform; own = its {qry, anom, qnz}, {qtot, prev} words) into F; the caller has decided that it belongs there
@@ -294,12 +302,10 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
         const int32_t below = popc64(wave_ballot(lane >= hd && lane < nf && qe_less(f, x)));
         const int32_t pos = hd + below;
         if (nf == 64 && hd == 0) {                                   // full: the largest entry leaves for I
-            if (lane == 63) qe_to_lds(q.L->ibuf[q.in], f);
-            freemask |= 1ull << (__builtin_amdgcn_readlane(f_slot, 63) & 63);
-            q.in++; nf = 63;
+            if (lane == 63) { qe_to_lds(q.L->ibuf[q.in], f); q.L->freel[ftop] = f_slot & 63; }
+            ftop++; q.in++; nf = 63;
         }
-        const int32_t sl = ffs64(freemask) - 1;
-        freemask &= ~(1ull << sl);
+        const int32_t sl = uni(q.L->freel[--ftop]);
         bool mv; int32_t at;
         QE t; int32_t ts;
 #define EQ_SH(CTRL, v) __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false)
@@ -329,13 +335,15 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
         o0.x = uni(lo32((uint64_t)d0.qry)); o0.y = uni(hi32((uint64_t)d0.qry)); o0.z = uni(d0.anom); o0.w = uni(d0.qnz); o1.x = uni(d0.qtot); o1.y = -1; o1.z = 0; o1.w = 0;
         if (lane == 0) { I4 cd; cd.x = hs; cd.y = -1; cd.z = o0.x; cd.w = o0.y; kcand[0] = cd; I4 ce; ce.x = o0.z; ce.y = o0.w; ce.z = o1.x; ce.w = 0; kcand[1] = ce; }
         nn = 1;
+        wave_lds_sync();
         f_insert(x, o0, o1);
     }
 
+    const int32_t pi = (lane * 86) >> 8, pj = lane - 3 * pi;         // lane = 3 * (pop of the step) + (successor of that pop)
     KPROF_DECL;
     KPROF_START();
     while (found < K) {                                              // :240-248
-        KPROF_STAMP(0);                                              // pop + pushes
+        KPROF_STAMP(0);                                              // pops + pushes
         const bool need_refill = hd == nf;
         if (need_refill && q.in == 0 && q.nruns == 0) break;         // queue empty
         if (q.in > EQ_IFLUSH || (need_refill && q.in > 0)) { wave_lds_sync(); eq_flush(q, K - found, lane); KPROF_STAMP(1); }
@@ -359,17 +367,23 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
                     if (rh >= uni(q.L->run_end[l])) q.nruns--;
                 }
             }
-            wave_lds_sync();
             f = cnd; f.tag = 0;
             f_slot = lane | 0x200;                                   // 0x200: its own words are still in the candidate record
-            freemask = nf >= 64 ? 0ull : ~((1ull << nf) - 1ull);
+            ftop = 64 - nf;
+            if (lane < ftop) q.L->freel[lane] = 63 - lane;           // slots nf .. 63
+            wave_lds_sync();
             maxF = qe_uni(f, nf - 1);
-            wave_fence();                                            // candidate records written by lanes 0..2 of this wave
+            wave_fence();                                            // candidate records written by lanes of this wave
             KPROF_STAMP(2);
         }
+        // ---- how many entries this step pops: all of them must be there, fit K, and leave room in I for their successors
+        int32_t P = nf - hd;
+        if (P > EQ_BATCH) P = EQ_BATCH;
+        if (P > K - found) P = K - found;
+        if (3 * P > EQ_ILEN - q.in) P = (EQ_ILEN - q.in) / 3;
         // ---- successors of every entry of F that has none yet: heap node -> cross root -> keys; each lane builds the complete
         //      queue entries of its own entry's successors (their insertion index comes at the pop)
-        if (__builtin_amdgcn_readlane(f_slot, hd) & 0x300) {
+        if (wave_ballot(lane >= hd && lane < hd + P && (f_slot & 0x300)) != 0) {
             if (lane >= hd && lane < nf && (f_slot & 0x300)) {
                 const int32_t sl = f_slot & 63;
                 const int32_t fnode = hi32(f.nc), fcur = lo32(f.nc);
@@ -415,31 +429,39 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
 #endif
             KPROF_STAMP(3);
         }
-        // ---- pop (:241-244)
-        const uint64_t tsum = uni_u64(f.sum, hd);
-        const int32_t tcur = __builtin_amdgcn_readlane(lo32(f.nc), hd);
-        const int32_t tslot = __builtin_amdgcn_readlane(f_slot, hd) & 63;
-        hd++;
-        freemask |= 1ull << tslot;
-        const I4 t0 = q.L->slot[tslot][0], t1 = q.L->slot[tslot][1], t8 = q.L->slot[tslot][8];   // {qry, anom, qnz}, {qtot, prev, ..}
-        // ---- its successors, one per lane (:245-247): cross heap root, left, right
+        // ---- the successors of the P front entries (:245-247), lane 3 i + j: successor j (cross heap root, left, right) of front entry i
+        const int32_t srcl = (hd + pi) << 2;
+        const int32_t pslot = __builtin_amdgcn_ds_bpermute(srcl, f_slot) & 63;
+        const int32_t pcur = __builtin_amdgcn_ds_bpermute(srcl, lo32(f.nc));
         QE x = qe_inf();
         I4 x0, x1;
         x0.x = x0.y = x0.z = x0.w = 0; x1.x = x1.y = x1.z = x1.w = 0;
         bool valid = false;
-        if (lane < 3) {
-            const I4 a = q.L->slot[tslot][2 + 2 * lane], b = q.L->slot[tslot][3 + 2 * lane];
+        if (pi < P) {
+            const I4 a = q.L->slot[pslot][2 + 2 * pj], b = q.L->slot[pslot][3 + 2 * pj], t1 = q.L->slot[pslot][1], t8 = q.L->slot[pslot][8];
             valid = b.z >= 0;
             x.sum = mk64(a.x, a.y); x.key2 = mk64(a.z, a.w); x.nc = (uint64_t)(uint32_t)b.z << 32;
-            x0.x = b.x; x0.y = b.y; x0.z = b.w; x0.w = lane == 0 ? t1.z : lane == 1 ? t8.x : t8.z;
-            x1.x = lane == 0 ? t1.w : lane == 1 ? t8.y : t8.w; x1.y = lane == 0 ? tcur : t1.y;
+            x0.x = b.x; x0.y = b.y; x0.z = b.w; x0.w = pj == 0 ? t1.z : pj == 1 ? t8.x : t8.z;
+            x1.x = pj == 0 ? t1.w : pj == 1 ? t8.y : t8.w; x1.y = pj == 0 ? pcur : t1.y;
         }
-        if (lane == 0) {
+        // a successor smaller than a front entry behind its parent has to be popped before that entry: the step ends with its parent
+        if (P > 1) {
+            const QE elast = qe_uni(f, hd + P - 1);
+            const uint64_t viol = wave_ballot(valid && pi < P - 1 && qe_less(x, elast));
+            if (viol) { P = (((ffs64(viol) - 1) * 86) >> 8) + 1; valid = valid && pi < P; }
+        }
+        // ---- pop them (:241-244)
+        if (lane >= hd && lane < hd + P) {
+            const int32_t sl = f_slot & 63;
+            const I4 t0 = q.L->slot[sl][0];
+            const int32_t tt = q.L->slot[sl][1].x;
             const uint64_t tq = mk64(t0.x, t0.y);
-            Dist dtop; dtop.qry = (int64_t)tq; dtop.ref = (int64_t)(tsum - tq); dtop.anom = t0.z; dtop.qnz = t0.w; dtop.qtot = t1.x; dtop.pad = 0;
-            kd[found] = dtop; klast[found] = tcur;
+            Dist dtop; dtop.qry = (int64_t)tq; dtop.ref = (int64_t)(f.sum - tq); dtop.anom = t0.z; dtop.qnz = t0.w; dtop.qtot = tt; dtop.pad = 0;
+            const int32_t at = found + (lane - hd);
+            kd[at] = dtop; klast[at] = lo32(f.nc);
+            q.L->freel[ftop + (lane - hd)] = sl;
         }
-        found++;
+        ftop += P; hd += P; found += P;
         const uint64_t vm = wave_ballot(valid);
         if (vm == 0) continue;
         const int32_t xcur = nn + popc64(vm & lanemask_lt(lane));
@@ -453,25 +475,26 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
         const bool live = valid && qe_less(x, q.bound);              // (the others can never be popped: dropped here)
         const uint64_t lm = wave_ballot(live);
         if (lm == 0) continue;
-        const bool room = q.in == 0 && q.nruns == 0 && (nf - hd) < 64;       // nothing behind F: F may grow at its end
-        const uint64_t fm = wave_ballot(live && hd < nf && qe_less(x, maxF));
-        if (fm == 0 && !room) {                                      // the usual case: all of them go to I
-            if (live) qe_to_lds(q.L->ibuf[q.in + popc64(lm & lanemask_lt(lane))], x);
-            q.in += popc64(lm);
-        } else {
-            for (uint64_t m = lm; m; m &= m - 1) {
-                const int j = ffs64(m) - 1;
-                const QE xj = qe_uni(x, j);
-                const bool fits = hd < nf ? qe_less(xj, maxF) : false;
-                if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < 64)) {
-                    I4 o0, o1;
-                    o0.x = __builtin_amdgcn_readlane(x0.x, j); o0.y = __builtin_amdgcn_readlane(x0.y, j); o0.z = __builtin_amdgcn_readlane(x0.z, j); o0.w = __builtin_amdgcn_readlane(x0.w, j);
-                    o1.x = __builtin_amdgcn_readlane(x1.x, j); o1.y = __builtin_amdgcn_readlane(x1.y, j); o1.z = 0; o1.w = 0;
-                    f_insert(xj, o0, o1);
-                } else {
-                    if (lane == 0) qe_to_lds(q.L->ibuf[q.in], xj);
-                    q.in++;
-                }
+        const bool behind = q.in != 0 || q.nruns != 0;               // something behind F: an entry >= max(F) goes to I (else F may grow at its end)
+        const bool toF = live && (!behind || (hd < nf && qe_less(x, maxF)));
+        const uint64_t im = wave_ballot(live && !toF);
+        if (im) {                                                    // the usual case: to I, all at once
+            if (live && !toF) qe_to_lds(q.L->ibuf[q.in + popc64(im & lanemask_lt(lane))], x);
+            q.in += popc64(im);
+        }
+        for (uint64_t m = wave_ballot(toF); m; m &= m - 1) {        // into F, one at a time
+            const int j = ffs64(m) - 1;
+            const QE xj = qe_uni(x, j);
+            const bool fits = hd < nf ? qe_less_u(xj, maxF) : false;
+            if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < 64)) {
+                I4 o0, o1;
+                o0.x = __builtin_amdgcn_readlane(x0.x, j); o0.y = __builtin_amdgcn_readlane(x0.y, j); o0.z = __builtin_amdgcn_readlane(x0.z, j); o0.w = __builtin_amdgcn_readlane(x0.w, j);
+                o1.x = __builtin_amdgcn_readlane(x1.x, j); o1.y = __builtin_amdgcn_readlane(x1.y, j); o1.z = 0; o1.w = 0;
+                wave_lds_sync();
+                f_insert(xj, o0, o1);
+            } else {
+                if (lane == 0) qe_to_lds(q.L->ibuf[q.in], xj);
+                q.in++;
             }
         }
     }
