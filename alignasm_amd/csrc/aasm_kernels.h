@@ -1684,10 +1684,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         HeapStage *S = &L->stage;
         if (staged != u) {                                           // not staged (the root, a spilled queue entry): fetch now
             const I4 ha = vh[u], hb = vh2[u];
-            LaneArr<Dist> kk;
-            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) kk.at(t) = sk[(int64_t)so + t];
+            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; S->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
             c_nch = uni(ha.z); c_fc = uni(ha.w); c_sofc = uni(hb.z); c_nfc = uni(hb.w); c_c0lo = uni(hb.x); c_c0hi = uni(hb.y);
-            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) S->key[t] = kk.at(t);
             wave_lds_sync();
         }
         const int32_t nch = c_nch, fc = c_fc, so_fc = c_sofc, n_fc = c_nfc, c0lo = c_c0lo, c0hi = c_c0hi;
@@ -2133,7 +2131,8 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
 // ====================================================================================
 struct SelCtx {
     const WS *w;
-    int64_t c, b, N, V, vb, cap;     // cap = N + 2 edge pairs per path buffer
+    int64_t c, b, vb;
+    int32_t N, V, cap;               // cap = N + 2 edge pairs per path buffer
     int32_t src, dest;
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
     Dist *dist2;
@@ -2144,7 +2143,7 @@ struct SelCtx {
     bool err, res_lds;
     int lane;
     char *lds;
-    int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
+    int32_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters, per conversion / contig
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     int64_t kp_t0, kp_acc[8];
 #endif
@@ -2358,7 +2357,7 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
         if (s.stamp[u] != ep) continue;
         const Dist cd = s.dist2[u];
         const int64_t r0 = w.rowptr[s.vb + u], r1 = w.rowptr[s.vb + u + 1];
-        s.n_ispr_v++; s.n_ispr_e += r1 - r0;
+        s.n_ispr_v++; s.n_ispr_e += (int32_t)(r1 - r0);
         const bool u_ok = !(u == s.src || u == s.dest) && (w.v_j[s.vb + u] == wl);   // :767-773
         for (int64_t e = r0 + s.lane; e < r1; e += AASM_WAVE) {
             const int32_t v = w.e_col[e];
@@ -2507,47 +2506,37 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
                 continue;
             }
         }
+        // One step = at most ONE internal_shortest_path_recover call (a single call site: the routine is large and
+        // inlined).  mode 1: the result without its last edge (:812-833 / :879-899); 2: the whole result, and the step
+        // consumes two path edges (:834-843 / :900-909); 3: the last hop into dest (:845-858).
         const bool from_src = (u == s.src);
+        int32_t mode, start, target, wl = -1, nu = -1, nv = -1;
+        bool known = false;
         if (from_src || v != s.dest) {
-            int32_t start;
             if (from_src) start = u;                                 // :804
             else {
                 if (s.out_n == 0) { s.err = true; break; }
                 start = s.last_head;                                 // continuation_src (:863)
                 if (!v_single) { sel_push(s, u, v); continue; }      // :866-873
             }
-            const int32_t y = vj;
             if (it + 1 >= la) { s.err = true; break; }
-            int32_t nu, nv, nvj;
+            int32_t nvj;
             bool nvs, nsettled;
             sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs, nsettled);
             const bool nv_single = (nv == s.dest) || nvs;
-            const bool known = settled && start == u;                // the call would return (u, v), (v, nv): see sel_pa_get
-            if (nv_single) {                                         // :812-833 / :879-899
-                if (known) sel_push(s, u, v);                        // the result without its last edge
-                else {
-                    const int32_t n = sel_ispr(s, start, nv, true, y);
-                    if (n < 0) break;
-                    if (n == 0) sel_push(s, u, v);
-                    else sel_append_alt(s, n, true);
-                }
-            } else {                                                 // :834-843 / :900-909
-                if (known) { sel_push(s, u, v); sel_push(s, nu, nv); }
-                else {
-                    const int32_t n = sel_ispr(s, start, nv, false, -1);
-                    if (n < 0) break;
-                    if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
-                    else sel_append_alt(s, n, false);
-                }
-                ++it;
-            }
-        } else {                                                     // v == dest (:845-858)
+            known = settled && start == u;                           // the call would return (u, v), (v, nv): see sel_pa_get
+            mode = nv_single ? 1 : 2;
+            if (nv_single) wl = vj;
+            target = nv;
+        } else {                                                     // v == dest
             if (s.out_n == 0) { s.err = true; break; }
-            const int32_t start = s.last_head;
-            const int32_t n = sel_ispr(s, start, v, false, -1);
-            if (n < 0) break;
-            if (n > 0) sel_append_alt(s, n, false);
+            mode = 3; start = s.last_head; target = v;
         }
+        int32_t n = 0;
+        if (!known) { n = sel_ispr(s, start, target, mode == 1, wl); if (n < 0) break; }
+        if (n > 0) sel_append_alt(s, n, mode == 1);
+        else if (mode != 3) { sel_push(s, u, v); if (mode == 2) sel_push(s, nu, nv); }
+        if (mode == 2) ++it;
     }
     sel_out_flush(s);
     return s.out_n;
@@ -2686,15 +2675,15 @@ AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // one wave 
 
 AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
     const int64_t gb = w.rec_off[c];
-    s.w = &w; s.c = c; s.b = gb - w.R0; s.N = w.rec_off[c + 1] - gb; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
+    s.w = &w; s.c = c; s.b = gb - w.R0; s.N = (int32_t)(w.rec_off[c + 1] - gb); s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
     s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
     s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
     s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
 }
 AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
     if (s.lane == 0) {
-        atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
-        atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
+        atomic_add(&w.counters[CNT_ISPR_E], (int64_t)s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], (int64_t)s.n_ispr_v);
+        atomic_add(&w.counters[CNT_PATH_E], (int64_t)s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], (int64_t)s.n_out_e);
     }
 }
 
