@@ -48,7 +48,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_contig_costs", "aasm_partition_contigs", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
@@ -93,13 +93,13 @@ def reserve_workspace(device=0, nbytes=0):
 
 
 def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False,
-              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False):
+              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False):
     o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
     # bit 0: force the one-wave-per-contig selection kernel; bits 1 / 2: K7 with several waves per contig for every contig / for none
     # bit 3: K8 with the d-ary heap queue instead of the sorted-front / sorted-runs queue (cross-check of the two)
     o.reserved[0] = (1 if sequential_select else 0) | {"auto": 0, "all": 2, "none": 4}[heap_waves] | (8 if enum_heap else 0)
     o.reserved[1] = int(test_max_contigs)              # test hook: longer contig ranges "do not fit" (range split)
-    o.reserved[2] = 1 if test_inject_launch_failure else 0
+    o.reserved[2] = (1 if test_inject_launch_failure else 0) | (2 if wrap_devices else 0)   # bit 1: shards wrap around the devices that exist
     return o
 
 
@@ -185,10 +185,10 @@ def free_out(out: BatchOut):
 
 
 def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False,
-                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False):
+                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False):
     """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
     view = batch.view if isinstance(batch, HostBatch) else batch.view()
-    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap)
+    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap, wrap_devices)
     if n_devices > 1:
         out = BatchOut()
         _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(opts), int(n_devices), C.byref(out)))

@@ -280,6 +280,7 @@ struct DevCtx {
     int64_t *d_scratch = nullptr;       // scan tile sums
     size_t d_scratch_cap = 0;
     uint64_t generation = 0;
+    std::atomic<int> input_arrived{0};  // an upload for this context has begun: a warm-up that has not allocated yet stands back
     std::mutex mu;
     hipEvent_t ev_b[AASM_N_PHASES], ev_e[AASM_N_PHASES], ev_t0, ev_t1;
     int n_events_made = 0;              // ev_fork, ev_join, then timing_event(0 ..)
@@ -526,6 +527,14 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
         g_bad_record = res->sz.bad_record;
         set_last_error("malformed cs:Z tag in record " + std::to_string(res->sz.bad_record) + " of the batch");
     }
+    if (rc == AASM_E_HIP || rc == AASM_E_NOMEM) {
+        // a scan that did not run to its end (failed launch, aborted kernel) leaves tickets / tile words behind, and the single-pass
+        // scan of the NEXT solve on this context relies on finding them zero: wipe both scratch buffers before anybody else comes
+        (void)hipDeviceSynchronize();
+        if (cx.d_scratch) (void)hipMemset(cx.d_scratch, 0, cx.d_scratch_cap * 8);
+        if (cx.d_scratch2) (void)hipMemset(cx.d_scratch2, 0, cx.d_scratch2_cap * 8);
+        (void)hipGetLastError();
+    }
     if (rc != AASM_OK) { delete res; return rc; }
     if (timing) {
         for (int i = 0; i < AASM_N_PHASES; i++)
@@ -718,23 +727,36 @@ int aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *r
     };
     const int64_t *d_voff = (const int64_t *)up(g_voff, (size_t)(n_graphs + 1) * 8), *d_rowptr = (const int64_t *)up(rowptr, (size_t)(VT + 1) * 8);
     const int32_t *d_col = (const int32_t *)up(col, (size_t)ET * 4), *d_src = (const int32_t *)up(src, (size_t)n_graphs * 4);
-    const int64_t *d_w = (const int64_t *)up(w5, (size_t)ET * 40), *d_hoff = (const int64_t *)up(hoff.data(), (size_t)(n_graphs + 1) * 8);
+    const int64_t *d_w = (const int64_t *)up(w5, (size_t)ET * 40);
     Dist *d_d = (Dist *)up(nullptr, (size_t)VT * sizeof(Dist));
     int32_t *d_prv = (int32_t *)up(nullptr, (size_t)VT * 4);
-    DjEnt *d_heap = (DjEnt *)up(nullptr, (size_t)hoff[(size_t)n_graphs] * sizeof(DjEnt));
     std::vector<Dist> hd((size_t)VT);
-    if (ok) {
-        hipLaunchKernelGGL(aasm_sssp_dijkstra_kernel, dim3((unsigned)n_graphs), dim3(64), 0, g_ctx[device].stream, n_graphs, d_voff, d_rowptr, d_col, d_w, d_src, d_d, d_prv, d_heap, d_hoff);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
-        if (e == hipSuccess) e = hipMemcpy(hd.data(), d_d, (size_t)VT * sizeof(Dist), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(prev, d_prv, (size_t)VT * 4, hipMemcpyDeviceToHost);
-        ok = e == hipSuccess;
+    // Heap capacity.  With a monotone order every successful relaxation pushes once (<= E + 1 entries), but CALC_SUM's third
+    // key (the mapq ratio) is not monotone under addition and the reference re-expands a vertex whenever its distance
+    // improves, so stale entries of one edge can pile up: a graph whose heap overflows is run again with 4x, 16x, 64x the room.
+    int64_t overflowed = -1;
+    for (int64_t mult = 1; ok && mult <= 64; mult *= 4) {
+        std::vector<int64_t> ho((size_t)n_graphs + 1, 0);
+        for (int64_t g = 0; g < n_graphs; g++) ho[(size_t)g + 1] = ho[(size_t)g] + mult * (hoff[(size_t)g + 1] - hoff[(size_t)g]);
+        const size_t n_dev0 = dev.size();
+        const int64_t *d_hoff = (const int64_t *)up(ho.data(), (size_t)(n_graphs + 1) * 8);
+        DjEnt *d_heap = (DjEnt *)up(nullptr, (size_t)ho[(size_t)n_graphs] * sizeof(DjEnt));
+        if (ok) {
+            hipLaunchKernelGGL(aasm_sssp_dijkstra_kernel, dim3((unsigned)n_graphs), dim3(64), 0, g_ctx[device].stream, n_graphs, d_voff, d_rowptr, d_col, d_w, d_src, d_d, d_prv, d_heap, d_hoff);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
+            if (e == hipSuccess) e = hipMemcpy(hd.data(), d_d, (size_t)VT * sizeof(Dist), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(prev, d_prv, (size_t)VT * 4, hipMemcpyDeviceToHost);
+            ok = e == hipSuccess;
+        }
+        while (dev.size() > n_dev0) { hipFree(dev.back()); dev.pop_back(); }
+        overflowed = -1;
+        if (ok) for (int64_t g = 0; g < n_graphs; g++) if (prev[g_voff[g] + src[g]] == -2) { overflowed = g; break; }
+        if (overflowed < 0) break;
     }
     for (void *q : dev) hipFree(q);
     if (!ok) { set_last_error(hip_err("aasm_sssp_dijkstra", e)); return e == hipErrorOutOfMemory ? AASM_E_NOMEM : AASM_E_HIP; }
-    for (int64_t g = 0; g < n_graphs; g++)
-        if (prev[g_voff[g] + src[g]] == -2) { set_last_error("graph " + std::to_string(g) + ": dijkstra does not terminate (a cycle that keeps improving the distance order)"); return AASM_E_INTERNAL; }
+    if (overflowed >= 0) { set_last_error("graph " + std::to_string(overflowed) + ": dijkstra heap capacity exceeded at 64 x (E + 2) entries"); return AASM_E_OVERFLOW; }
     for (int64_t v = 0; v < VT; v++) { d5[5 * v] = hd[(size_t)v].qry; d5[5 * v + 1] = hd[(size_t)v].ref; d5[5 * v + 2] = hd[(size_t)v].anom; d5[5 * v + 3] = hd[(size_t)v].qnz; d5[5 * v + 4] = hd[(size_t)v].qtot; }
     return AASM_OK;
 }
@@ -773,6 +795,7 @@ static int upload_range(const aasm_batch_in *in, int64_t c0, int64_t c1, int dev
     int rc = ctx_init(device);
     if (rc != AASM_OK) return rc;
     hipSetDevice(device);
+    g_ctx[device].input_arrived.store(1);
     aasm_upload *up = new aasm_upload();
     up->device = device;
     bool ok = true, oom = false;
@@ -913,6 +936,9 @@ int aasm_reserve_workspace(int device, int64_t bytes) {
     if (rc != AASM_OK) return rc;
     DevCtx &cx = g_ctx[device];
     std::lock_guard<std::mutex> lk(cx.mu);
+    // the input is on its way (or a solve has run): the free-memory figure below no longer leaves room for it, and a solve
+    // that holds the lock first would make this call allocate memory nobody uses after it - the solve allocates for itself
+    if (cx.input_arrived.load() != 0) return AASM_OK;
     hipSetDevice(device);
     size_t have = 0;
     for (auto &b : cx.blocks) have += b.cap;
@@ -1035,6 +1061,12 @@ int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n
     contig_costs(in, cost.data());
     std::vector<int64_t> cut(n_devices + 1, 0);
     partition_by_cost(cost.data(), C, n_devices, cut.data());
+    // test hook (opts.reserved[2] bit 1, or AASM_TEST_WRAP_DEVICES=1 for the CLI): device ordinals wrap around the devices
+    // that exist, so that the one-thread-per-shard path runs on a box with fewer GPUs than shards (the shards of one
+    // device take turns on its context)
+    const char *wrap_env = getenv("AASM_TEST_WRAP_DEVICES");
+    const bool wrap = (o.reserved[2] & 2) != 0 || (wrap_env && wrap_env[0] == '1');
+    const int ndev = std::max(1, aasm_device_count());
     std::vector<aasm_batch_out> parts(n_devices);
     std::vector<int> rcs(n_devices, AASM_OK);
     std::vector<std::string> errs(n_devices);
@@ -1043,7 +1075,7 @@ int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n
         for (int d = 0; d < n_devices; d++)
             th.emplace_back([&, d] {
                 aasm_opts od = o;
-                od.device = o.device + d;
+                od.device = wrap ? (o.device + d) % ndev : o.device + d;
                 std::memset(&parts[d], 0, sizeof(parts[d]));
                 rcs[d] = solve_range(in, cut[d], cut[d + 1], od, &parts[d]);
                 if (rcs[d] != AASM_OK) errs[d] = aasm_last_error();

@@ -676,7 +676,11 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
 
 // buffers -> one file, in order; every thread writes its own buffer at its own offset
 static int write_buffers(const char *path, const std::vector<std::string> &bufs) {
-    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    // the rounds go to a temporary name beside the target, which takes its place only when every row is on disk: a row that
+    // cannot be formatted (a cs tag clipped inside an insertion: get_edited_paf_data throws) or a failing write leaves no
+    // truncated .paf behind
+    const std::string tmp_path = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
+    const int fd = ::open(tmp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
     const int T = (int)bufs.size();
     std::vector<int64_t> off((size_t)T + 1, 0);
@@ -717,7 +721,11 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
     std::vector<int64_t> rcut((size_t)R + 1, C);
     rcut[0] = 0;
     for (int64_t r = 1; r < R; r++) { rcut[r] = cut_at(W * r / R); if (rcut[r] < rcut[r - 1]) rcut[r] = rcut[r - 1]; }
-    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    // the rounds go to a temporary name beside the target, which takes its place only when every row is on disk: a row that
+    // cannot be formatted (a cs tag clipped inside an insertion: get_edited_paf_data throws) or a failing write leaves no
+    // truncated .paf behind
+    const std::string tmp_path = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
+    const int fd = ::open(tmp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
     std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
     std::vector<std::string> errs((size_t)T);
@@ -727,7 +735,7 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
     int64_t base = 0, total = 0;
     int fail_rc = AASM_OK;
     std::string fail_msg;
-    for (int64_t r = 0; r <= R && fail_rc == AASM_OK; r++) {             // step r: format round r (r < R), write round r - 1 (r > 0)
+    for (int64_t r = 0; r <= R && fail_rc == AASM_OK && wrc == AASM_OK; r++) {   // step r: format round r (r < R), write round r - 1 (r > 0)
         const int fset = (int)(r & 1), wset = fset ^ 1;
         const bool do_f = r < R, do_w = r > 0;
         std::vector<int64_t> tcut((size_t)T + 1, 0);
@@ -767,6 +775,8 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
     int rc = fail_rc;
     if (::close(fd) != 0 && rc == AASM_OK) rc = AASM_E_IO;
     if (rc == AASM_OK && wrc != AASM_OK) rc = wrc;
+    if (rc == AASM_OK && ::rename(tmp_path.c_str(), path) != 0) rc = AASM_E_IO;
+    if (rc != AASM_OK) ::unlink(tmp_path.c_str());
     if (fail_rc != AASM_OK) set_last_error(fail_msg);
     else if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
     if (std::getenv("AASM_IO_TIMING"))

@@ -36,6 +36,15 @@ def partition_contigs(batch, n_shards):
     return [int(x) for x in cuts]
 
 
+def partition_costs(cost, n_shards):
+    """The same cut for caller-supplied per-contig costs."""
+    cost = np.ascontiguousarray(cost, np.float64)
+    n_shards = max(1, min(int(n_shards), len(cost)))
+    cuts = np.zeros(n_shards + 1, np.int64)
+    _check(LIB.aasm_partition_costs(cost.ctypes.data_as(C.c_void_p), C.c_int64(len(cost)), n_shards, cuts.ctypes.data_as(C.c_void_p)))
+    return [int(x) for x in cuts]
+
+
 def concat_outputs(parts):
     """Concatenate per-shard result dicts (alignasm_amd._abi.unpack_out) in contig order."""
     out = {"n_contigs": sum(p["n_contigs"] for p in parts)}

@@ -92,7 +92,8 @@ typedef struct aasm_opts {
                                 *            bit 3: K8 on the d-ary heap queue (cross-check of the default sorted-front / sorted-runs queue)
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
-                                * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP)  */
+                                * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);
+                                *     bit 1: aasm_solve_batch_multi wraps device ordinals around the devices that exist  */
 } aasm_opts;
 
 /* ---- output ---------------------------------------------------------------------
@@ -182,10 +183,12 @@ int  aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int 
 
 /* The partition aasm_solve_batch_multi uses, for callers that run one process per GPU (bench.py, MPI-style
  * launchers): cost[c] = estimated GPU cost of contig c (records + a graph-density term from the part sizes);
- * cuts[0..n_shards] = cut points of the contiguous, cost-balanced partition (cuts[0] = 0, cuts[n] = n_contigs).
+ * cuts[0..n_shards] = cut points of the contiguous partition whose fullest block is as light as a contiguous partition
+ * allows (cuts[0] = 0, cuts[n] = n_contigs).  aasm_partition_costs: the same cut for caller-supplied costs.
  * Host pointers; only ctg_rec_off, qry_str and qry_end are read.                                       */
 int  aasm_contig_costs(const aasm_batch_in *in, double *cost);
 int  aasm_partition_contigs(const aasm_batch_in *in, int n_shards, int64_t *cuts);
+int  aasm_partition_costs(const double *cost, int64_t n_contigs, int n_shards, int64_t *cuts);
 
 /* The solver's generic single-source shortest paths, dijkstra() (src/k_shortest_walks.hpp:69-87), over a batch of
  * graphs that may contain cycles: graph g owns vertices [g_voff[g], g_voff[g+1]) (local ids 0..), rowptr is one CSR

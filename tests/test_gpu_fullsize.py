@@ -136,3 +136,50 @@ def test_multi_device_entry_equals_single(T):
     if api.device_count() == 1:
         with pytest.raises(api.AlignasmError):
             api.solve_batch(hb, max_paths=16, n_devices=2)
+
+
+def _mixed_file(T):
+    """Heavy-tailed sparse contigs with a block of dense ones in the middle: contig costs spread over three orders of magnitude."""
+    from alignasm_amd._abi import HostBatch
+    parts = [T.synth(40, 120, 9, heavy_tail=True, dup_every=5), T.synth(5, 260, 31, dense=True), T.synth(50, 90, 13, heavy_tail=True)]
+    a = parts[0].arrays
+    mixed = {k: np.concatenate([p.arrays[k] for p in parts]) for k in a if k not in ("ctg_rec_off", "rec_rng_off")}
+    for key in ("ctg_rec_off", "rec_rng_off"):
+        acc, off = [parts[0].arrays[key]], parts[0].arrays[key][-1]
+        for p in parts[1:]:
+            acc.append(p.arrays[key][1:] + off)
+            off += p.arrays[key][-1]
+        mixed[key] = np.concatenate(acc)
+    return HostBatch(mixed)
+
+
+@pytest.mark.parametrize("n_dev", [2, 3, 4, 8])
+def test_in_process_multi_device_path_on_the_devices_that_exist(T, n_dev):
+    """aasm_solve_batch_multi with n_devices > 1 (alignasm.cpp:351-359: one task per contig -> one thread + stream per device
+    block): the thread-per-shard path, the cost-balanced cuts and the concatenation, with device ordinals wrapped around the
+    devices of this box (opts.reserved[2] bit 1), against the oracle on a heavy-tailed + mixed dense / sparse file."""
+    api = T.api()
+    hb = _mixed_file(T)
+    want = T.oracle_solve(hb, 16)
+    got = api.solve_batch(hb, max_paths=16, n_devices=n_dev, wrap_devices=True)
+    assert T.diff_outputs(want, got, stats=False) == []
+    for k in ("n_vertices", "n_edges", "n_heap_nodes", "n_paths_found", "n_pairs"):
+        assert want["stats"][k] == got["stats"][k], k
+
+
+def test_cli_gpus_4_writes_the_same_bytes(T, tmp_path):
+    """`alignasm --gpus 4` (shards wrapped around the devices that exist: AASM_TEST_WRAP_DEVICES=1) against `--gpus 1`."""
+    import os, subprocess
+    api = T.api()
+    exe = os.path.join(T.ROOT, "alignasm_amd", "alignasm")
+    paf = api.Paf.synth(37, 150, 5, heavy_tail=True, dup_every=4)
+    outs = {}
+    for g in (1, 4):
+        d = tmp_path / ("g%d" % g)
+        d.mkdir()
+        paf.save(str(d / "x.paf"))
+        r = subprocess.run([exe, str(d / "x.paf"), "--gpus", str(g), "--max-paths", "32"], capture_output=True, text=True,
+                           env=dict(os.environ, AASM_TEST_WRAP_DEVICES="1"))
+        assert r.returncode == 0, r.stderr
+        outs[g] = [(d / ("x" + s)).read_bytes() for s in (".aln.paf", ".aln.alt.paf", ".aln.all.paf")]
+    assert outs[1] == outs[4] and len(outs[1][0]) > 10000

@@ -216,3 +216,29 @@ def test_writer_in_several_rounds_matches_io_oracle(T, tmp_path):
     got = [open(p, "rb").read() for p in paths]
     assert len(want[0]) > 3 * (4 << 20)                           # more than one round of three 4 MB shares
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+
+
+def test_a_row_that_cannot_be_written_leaves_no_file_behind(T, tmp_path):
+    """get_edited_paf_data throws for a clip that does not fit its cs tag (paf_data.cpp:211-218); the reference dies with the
+    exception.  Here the write fails with the same text - also when the bad row sits in a LATER round of the writer than the
+    ones already on disk - and neither a truncated output nor the temporary file stays."""
+    api = T.api()
+    text = api.Paf.synth(260, 150, 23, dup_every=5).to_text()
+    paf = api.Paf.parse(text)
+    from alignasm_amd._abi import BatchOut, Opts, OutElem
+    out = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(paf.view()), C.byref(Opts(6, 0, 0, 0, 0)), 2, C.byref(out)) == 0
+    n_main = int(C.cast(out.main_off, C.POINTER(C.c_int64))[out.n_contigs])
+    elems = C.cast(out.main_elems, C.POINTER(OutElem))
+    k = n_main - 7                                                  # far behind the first rounds (3 threads x ~4 MB each)
+    elems[k].edited_qry_str += 1                                    # the clip no longer matches its reference span
+    paths = [str(tmp_path / n) for n in ("z.aln.paf", "z.aln.alt.paf", "z.aln.all.paf")]
+    prev = api.set_host_threads(3)
+    try:
+        with pytest.raises(api.AlignasmError) as e:
+            paf.write_outputs(out, *paths)
+    finally:
+        api.set_host_threads(prev)
+    T.oracle().oracle_free_out(C.byref(out))
+    assert "Edited cs tag does not match edited PAF coordinates" in str(e.value) or "clipped inside a cs insertion" in str(e.value)
+    assert [p.name for p in tmp_path.iterdir()] == []

@@ -62,6 +62,42 @@ def test_partition_invariants(T):
             assert max(loads) < 1.25 * (sum(loads) / len(loads))
 
 
+def _lpt_makespan(cost, n):
+    """Longest-processing-time-first bin packing, no contiguity constraint."""
+    loads = [0.0] * n
+    for c in sorted(cost, reverse=True):
+        loads[loads.index(min(loads))] += c
+    return max(loads)
+
+
+@pytest.mark.parametrize("case", [("heavy", 400, 8), ("heavy", 1600, 8), ("mixed", 400, 4), ("mixed", 400, 8), ("dense_first", 440, 8)], ids=str)
+def test_contiguous_cuts_are_close_to_lpt(T, case):
+    """The partition keeps blocks contiguous (no gather / scatter of contigs).  What that costs against SURVEY 8(e)'s
+    LPT bin packing, on heavy-tailed files (contig sizes log-normal, 1 ... 8000), on a file whose dense contigs are
+    interleaved with sparse ones, and on one that STARTS with its dense contigs (44 contigs that hold 60 % of the cost, each
+    1.3 % of it: the worst case for contiguity at 8 blocks): fullest block within 5 % of LPT's, 8 % on the last file (measured
+    5.1 %), and never better than the lower bound both share."""
+    from alignasm_amd import shard
+    from alignasm_amd._abi import HostBatch
+    kind, nc, n = case
+    if kind == "heavy":
+        hb = T.synth(nc, 60, 7, heavy_tail=True)
+    else:
+        sparse, dense = T.synth(nc, 60, 7, heavy_tail=True), T.synth(nc // 10, 120, 31, dense=True)
+        a, b = sparse.arrays, dense.arrays
+        cs, cd = shard.contig_costs(sparse), shard.contig_costs(dense)
+        cost = np.concatenate([cd, cs]) if kind == "dense_first" else np.concatenate([cs[:nc // 2], cd, cs[nc // 2:]])
+        cuts = shard.partition_costs(cost, n)
+        loads = [cost[x:y].sum() for x, y in zip(cuts, cuts[1:])]
+        assert max(loads) <= (1.08 if kind == "dense_first" else 1.05) * _lpt_makespan(cost, n), (max(loads), _lpt_makespan(cost, n))
+        return
+    cost = shard.contig_costs(hb)
+    cuts = shard.partition_contigs(hb, n)
+    loads = [cost[x:y].sum() for x, y in zip(cuts, cuts[1:])]
+    lower = max(cost.max(), cost.sum() / n)
+    assert lower <= max(loads) <= 1.05 * _lpt_makespan(cost, n), (max(loads), _lpt_makespan(cost, n), lower)
+
+
 def test_cost_model_sees_graph_density(T):
     """the partition balances estimated GPU work, not record counts.  A dense contig
     (large parts -> E ~ N * part size) must weigh an order of magnitude more than a sparse one of the
