@@ -47,6 +47,7 @@ AASM_DEV void wave_lds_sync() {}
 AASM_DEV void block_barrier() {}
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return *p; }
 AASM_DEV void wave_sleep() {}
+AASM_DEV int64_t wave_realtime() { return 0; }
 AASM_DEV void store_drain() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
@@ -85,6 +86,7 @@ AASM_DEV void block_barrier() { __syncthreads(); }
 // a word another wave of the SAME workgroup may have just stored (global memory): workgroup-scope load
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 AASM_DEV void wave_sleep() { __builtin_amdgcn_s_sleep(2); }
+AASM_DEV int64_t wave_realtime() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }   // constant 100 MHz counter
 // every store of this wave has reached the cache its workgroup shares (before it tells another wave about them)
 AASM_DEV void store_drain() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 // order this wave's global-memory writes before its later reads (same CU, same L1)

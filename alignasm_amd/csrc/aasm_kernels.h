@@ -1855,11 +1855,15 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
             int32_t s = 0;
             if (k.lane == 0) s = atomic_add(&L->q_head, (int32_t)1);
             s = wave_bcast(s, 0);
+            const int64_t wait_t0 = wave_realtime();
             while (true) {
                 if (uni(ld_shared_i32(&L->stop)) || uni(ld_shared_i32(&L->n_done)) >= nv) { u = -2; break; }
                 const int32_t e = (s < V) ? uni(ld_shared_i32(&q[s])) : -1;
                 if (e >= 0) { u = e; hu = uni(ld_shared_i32(&h[u])); break; }
-                if (++guard > ((int64_t)1 << 34)) { u = -2; if (k.lane == 0) L->stop = 2; break; }   // (never: every wait ends with an entry or with n_done == nv)
+                // (never: every wait ends with an entry or with n_done == nv.)  Bounded by wall time, not by a spin count: a wave may
+                // rightly wait for as long as the others work on a path-like part of the tree, but 30 s without its ticket being
+                // served means a publishing wave is gone, and the launch ends with AASM_E_INTERNAL instead of sitting for minutes
+                if ((++guard & 1023) == 0 && wave_realtime() - wait_t0 > (int64_t)30 * 100000000) { u = -2; if (k.lane == 0) L->stop = 2; break; }
                 wave_sleep();
             }
             if (u == -2) break;
