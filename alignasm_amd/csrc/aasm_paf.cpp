@@ -696,7 +696,8 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
         }
     });
     if (::close(fd) != 0) rc = AASM_E_IO;
-    if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
+    if (rc == AASM_OK && ::rename(tmp_path.c_str(), path) != 0) rc = AASM_E_IO;
+    if (rc != AASM_OK) { ::unlink(tmp_path.c_str()); set_last_error(std::string("write to ") + path + " failed"); }
     return rc;
 }
 

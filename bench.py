@@ -23,8 +23,13 @@ under "weak".  `--workload c5` (dense, K=16) is defined on 8 GPUs at 1 250 conti
 10 000-contig file does not fit one GPU -- and keeps that per-GPU share for any N (weak).
 
 Extra keys of the N = 1 line: `step_with_fetch_ms` (the step plus the D2H + ragged pack of the
-three result lists), `k10000` (the same hot path at the reference's shipped MAX_PATH_COUNT = 10000,
-paf_data.cpp:729, on the first 1 000 contigs of the batch).
+three result lists); `k10000` (the same hot path at the reference's shipped MAX_PATH_COUNT = 10000,
+paf_data.cpp:729, on the WHOLE batch, and on its first 1 000 contigs as in earlier rounds);
+`c3_heavy_tail` (SURVEY 8(d)'s variant: contig sizes log-normal(ln 600, 1) clipped to [1, 8000] and
+rescaled to the same 5 M records, seed 21) and `c3_dup3` (every third record duplicated on another
+chromosome: equal (qry_str, qry_end) keys and tied path scores, the multi-mapping regime), each with
+its phase times and its ratio to the uniform step; `e2e` (the `alignasm` command line on the C3 file
+with cs tags: stage seconds and file bytes; skipped with --no-e2e).
 
 roofline: the dominant kernel of the timed region (largest average HIP-event time on the
 library's stream), its ALGORITHMIC bytes per launch (byte model: DESIGN.md "Byte model")
@@ -100,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip step_with_fetch / k10000 / weak (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="contigs of the workload timed on the CPU oracle")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end command-line run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,21 +198,45 @@ def main():
             res.close()
         extras["step_with_fetch_ms"] = round(allreduce((time.perf_counter() - t) * 1e3 / max(args.steps, 1), dist.ReduceOp.MAX if dist else None), 3)
         if world == 1:
-            # the reference's shipped MAX_PATH_COUNT (paf_data.cpp:729) on a slice of the same batch
+            # the reference's shipped MAX_PATH_COUNT (paf_data.cpp:729): the whole batch, and a 1000-contig slice of it
+            def at_k10000(batch_dev, n):
+                batch_dev.solve(max_paths=10000).close()
+                t = time.perf_counter()
+                for _ in range(2):
+                    r = batch_dev.solve(max_paths=10000, timing=True)
+                    stk = r.stats()
+                    r.close()
+                msk = (time.perf_counter() - t) * 1e3 / 2
+                return {"ms_per_step": round(msk, 3), "contigs": n, "contigs_per_sec": round(n / msk * 1e3, 1), "paths_found": stk["n_paths_found"],
+                        "pq_pushes": stk["pq_pushes"], "enum_ms": round(stk["phase_ms"].get("enum", 0.0), 3), "select_ms": round(stk["phase_ms"].get("select", 0.0), 3)}
+            full = at_k10000(db, my_contigs)
             nk = min(1000, my_contigs)
             hbk = HostBatch.from_view_range(mine.view() if not isinstance(mine, HostBatch) else mine.view, 0, nk)
             dbk = A.DeviceBatch(hbk, device=local_rank)
-            dbk.solve(max_paths=10000).close()
-            t = time.perf_counter()
-            for _ in range(2):
-                r = dbk.solve(max_paths=10000, timing=True)
-                stk = r.stats()
-                r.close()
-            msk = (time.perf_counter() - t) * 1e3 / 2
-            extras["k10000"] = {"ms_per_step": round(msk, 3), "contigs": nk, "contigs_per_sec": round(nk / msk * 1e3, 1), "max_paths": 10000,
-                                "paths_found": stk["n_paths_found"], "enum_ms": round(stk["phase_ms"].get("enum", 0.0), 3),
-                                "note": "first %d contigs of the same batch at the reference's shipped MAX_PATH_COUNT" % nk}
+            part = at_k10000(dbk, nk)
             dbk.close()
+            extras["k10000"] = dict(full, max_paths=10000, first_1000=part,
+                                    note="the same batch at the reference's shipped MAX_PATH_COUNT; first_1000 = its first %d contigs alone" % nk)
+            if args.workload == "c3" and not custom:
+                # the shapes real PAFs have (alignasm.cpp:346-361 takes contigs of any size): same record count, same K
+                uniform_ms = elapsed * 1e3 / max(args.steps, 1)
+                for key, kw, what in (("c3_heavy_tail", {"heavy_tail": True}, "contig sizes log-normal(ln 600, 1) clipped to [1, 8000], rescaled to 5M records"),
+                                      ("c3_dup3", {"dup_every": 3}, "every third record duplicated on another chromosome (equal sort keys, tied scores)")):
+                    pv = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True, **kw)
+                    sizes = pv.batch().arrays["ctg_rec_off"]
+                    longest = int((sizes[1:] - sizes[:-1]).max())
+                    dbv = A.DeviceBatch(pv, device=local_rank)
+                    dbv.solve(max_paths=K).close()
+                    ev, pacc, stv = timed_steps(dbv, K, args.steps, barrier)
+                    msv = ev * 1e3 / max(args.steps, 1)
+                    extras[key] = {"ms_per_step": round(msv, 3), "contigs_per_sec": round(nc / msv * 1e3, 1), "ratio_to_uniform": round(msv / uniform_ms, 3),
+                                   "records": int(sizes[-1]), "longest_contig": longest, "V": stv["n_vertices"], "E": stv["n_edges"], "H": stv["n_heap_nodes"],
+                                   "paths_converted": stv["n_paths_converted"], "phase_ms": {k: round(v / max(args.steps, 1), 3) for k, v in pacc.items() if v > 0},
+                                   "shape": what}
+                    dbv.close()
+                    pv.close()
+            if not args.no_e2e and not custom:
+                extras["e2e"] = e2e_cli(nc, nr, seed, dense, K)
         if strong:
             # weak scaling beside it: every rank solves its own C3-sized file
             db.close()
@@ -293,23 +323,85 @@ def pmc_traffic(workload, not_profiled_shape, kernel):
 
 
 def cpu_baseline(paf, nc, K, sample):
-    """Oracle (CPU restatement, kind 'port') on the first `sample` contigs, all host cores."""
+    """Oracle (CPU restatement, kind 'port') on the first `sample` contigs, all host cores; beside it the same port on 1 thread
+    and on a ladder of thread counts (bounded samples), so the all-cores figure can be read: `value_1t`, `scaling`,
+    `stops_scaling_at` = the smallest thread count that reaches 90 % of the best rate of the ladder."""
     import ctypes as C
     import aasm_testlib as T
     from alignasm_amd._abi import BatchOut, HostBatch, Opts
     cores = max(1, os.cpu_count() or 1)
-    n = min(sample, nc)
-    hb = HostBatch.from_view_range(paf.view(), 0, n)
     lib = T.oracle()
     o = Opts(int(K), 0, 0, 0, 0)
-    out = BatchOut()
-    t0 = time.perf_counter()
-    rc = lib.oracle_solve_batch(C.byref(hb.view), C.byref(o), cores, C.byref(out))
-    dt = time.perf_counter() - t0
-    lib.oracle_free_out(C.byref(out))
-    assert rc == 0
-    return {"value": round(n / dt, 2), "unit": "contigs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {cores} threads, {dt:.2f} s wall"}
+
+    def run(n, threads):
+        hb = HostBatch.from_view_range(paf.view(), 0, n)
+        out = BatchOut()
+        t0 = time.perf_counter()
+        rc = lib.oracle_solve_batch(C.byref(hb.view), C.byref(o), threads, C.byref(out))
+        dt = time.perf_counter() - t0
+        lib.oracle_free_out(C.byref(out))
+        assert rc == 0
+        return n / dt, dt
+
+    n = min(sample, nc)
+    rate, dt = run(n, cores)
+    r1, dt1 = run(min(40, nc), 1)
+    ladder = []
+    for t in sorted({2, 4, 8, 16, 32, 64, 128, cores} - {1}):
+        if t > cores:
+            continue
+        rt, _ = run(min(nc, max(40, 25 * t)), t)
+        ladder.append((t, rt))
+    best = max([rate] + [r for _, r in ladder])
+    stops = next((t for t, r in ladder if r >= 0.9 * best), cores)
+    return {"value": round(rate, 2), "unit": "contigs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {cores} threads, {dt:.2f} s wall",
+            "value_1t": round(r1, 2), "sample_1t": f"first {min(40, nc)} contigs on 1 thread, {dt1:.2f} s",
+            "scaling": [{"threads": t, "contigs_per_sec": round(r, 1)} for t, r in ladder], "stops_scaling_at": stops}
+
+
+def e2e_cli(nc, nr, seed, dense, K):
+    """`alignasm <file.paf> --max-paths K` on the workload's file WITH cs tags (solve-only AND end to end): the
+    process's own stage clock (--timing) of the second of two runs (input in the page cache), file sizes, wall time."""
+    import shutil
+    import subprocess
+    import tempfile
+    import alignasm_amd as A
+    d = tempfile.mkdtemp(prefix="aasm_e2e_")
+    try:
+        path = os.path.join(d, "synth.paf")
+        t0 = time.perf_counter()
+        paf = A.Paf.synth(nc, nr, seed, dense=dense)
+        paf.save(path)
+        paf.close()
+        gen_s = time.perf_counter() - t0
+        exe = os.path.join(ROOT, "alignasm_amd", "alignasm")
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, path, "--max-paths", str(K), "--timing"], capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "alignasm exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+            line = [ln for ln in r.stderr.splitlines() if ln.startswith("alignasm timing:")]
+            stage = {}
+            if line:
+                tok = line[-1].replace("(", " ").replace(")", " ").split()
+                for i, t in enumerate(tok):
+                    if t in ("read_s", "solve_s", "upload", "device", "fetch", "write_s", "total_s", "records", "contigs", "overlap_s"):
+                        try:
+                            stage[t] = float(tok[i + 1])
+                        except (ValueError, IndexError):
+                            pass
+            runs.append({"wall_s": round(wall, 3), "stages": stage})
+        out_bytes = sum(os.path.getsize(path[:-4] + sfx) for sfx in (".aln.paf", ".aln.alt.paf", ".aln.all.paf"))
+        best = min(runs, key=lambda x: x["stages"].get("total_s", x["wall_s"]))
+        return {"total_s": best["stages"].get("total_s"), "process_wall_s": best["wall_s"], "stages": best["stages"], "runs": runs,
+                "input_bytes": os.path.getsize(path), "output_bytes": out_bytes, "gen_s": round(gen_s, 2),
+                "cmd": "alignasm synth.paf --max-paths %d --timing" % K,
+                "note": "total_s = inside the process, file open to last byte written (outputs into the page cache); process_wall_s adds exec + HIP start-up + exit"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

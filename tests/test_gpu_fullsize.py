@@ -183,3 +183,35 @@ def test_cli_gpus_4_writes_the_same_bytes(T, tmp_path):
         assert r.returncode == 0, r.stderr
         outs[g] = [(d / ("x" + s)).read_bytes() for s in (".aln.paf", ".aln.alt.paf", ".aln.all.paf")]
     assert outs[1] == outs[4] and len(outs[1][0]) > 10000
+
+
+# ---- the C3 variants real PAFs look like: heavy-tailed contig sizes; duplicated records (multi-mapping)
+@pytest.mark.parametrize("variant", ["heavy_tail", "dup3"])
+def test_c3_variants_at_full_size(T, variant):
+    """5 000 contigs / 5 M records with log-normal contig sizes (1 ... 8 000 records), and with every third record duplicated on
+    another chromosome (equal sort keys -> the std::sort replay; tied path scores -> tie runs of conversions): chain properties
+    of the whole result, the longest contigs and a random sample against the oracle, all three lists."""
+    from alignasm_amd._abi import HostBatch
+    api = T.api()
+    kw = {"heavy_tail": True} if variant == "heavy_tail" else {"dup_every": 3}
+    paf = api.Paf.synth(5000, 1000, 21, no_cs=True, **kw)
+    db = api.DeviceBatch(paf)
+    res = db.solve(max_paths=4, timing=True)
+    out, st = res.fetch(), res.stats()
+    if variant == "heavy_tail":
+        _chain_properties(paf, out, st, 5000)
+    else:                                                            # duplicates: two records may share a query interval, the chain is non-decreasing
+        assert (out["status"] == 0).all() and st["n_internal_errors"] == 0
+    sizes = np.diff(paf.batch().arrays["ctg_rec_off"])
+    rng = np.random.default_rng(11)
+    pick = set(int(c) for c in np.argsort(-sizes)[:2]) | set(int(c) for c in rng.choice(5000, size=24, replace=False))
+    if variant == "heavy_tail":
+        assert sizes.max() > 5000 and sizes.min() <= 20
+    for c0 in sorted(pick):
+        hb = HostBatch.from_view_range(paf.view(), c0, c0 + 1)
+        want = T.oracle_solve(hb, 4)
+        mo, ao, po, eo = out["main_off"], out["alt_off"], out["all_path_off"], out["all_elem_off"]
+        assert np.array_equal(want["main"], out["main"][mo[c0]:mo[c0 + 1]]), (variant, c0)
+        assert np.array_equal(want["alt"], out["alt"][ao[c0]:ao[c0 + 1]]), (variant, c0)
+        assert np.array_equal(want["all"], out["all"][eo[po[c0]]:eo[po[c0 + 1]]]), (variant, c0)
+    res.close(); db.close(); paf.close()
