@@ -48,7 +48,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_solve_batch_range", "aasm_writer_open", "aasm_writer_append", "aasm_writer_close", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 

@@ -1032,6 +1032,16 @@ static int solve_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aa
     return AASM_OK;
 }
 
+// contigs [c0, c1) of the batch: what a caller that streams a file runs per chunk (out covers c1 - c0 contigs)
+int aasm_solve_batch_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts *opts, aasm_batch_out *out) {
+    if (!in || !out || c0 < 0 || c1 > in->n_contigs || c0 >= c1) return AASM_E_INVAL;
+    aasm_opts o;
+    std::memset(&o, 0, sizeof(o));
+    if (opts) o = *opts;
+    if (c0 == 0) { const int rc = validate_batch(in); if (rc != AASM_OK) return rc; }    // (the whole batch is checked once, with its first range)
+    return solve_range(in, c0, c1, o, out);
+}
+
 int aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
     if (!in || !out) return AASM_E_INVAL;
     aasm_opts o;

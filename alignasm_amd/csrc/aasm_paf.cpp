@@ -23,9 +23,9 @@
 #include <thread>
 #include <unordered_map>
 #include <climits>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 namespace aasm {
@@ -706,9 +706,8 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
 // threads writes round r from the other set at offsets that are known by then (sizes of everything before it).
 // So the formatting runs beside the page-cache copy, and the buffers are a few MB each, reused, instead of one
 // fresh allocation the size of the file.  Rows leave in contig order, as process_output writes them.
-template <class EMIT>   // EMIT(contig, buf, err) -> rc : appends every line of one contig
-static int write_file_mt(const aasm_paf &paf, const char *path, const std::vector<int64_t> &weight_prefix, EMIT emit) {
-    const int64_t C = paf.n_contigs();
+template <class EMIT>   // EMIT(contig, buf, err) -> rc : appends every line of one contig (contigs 0 .. C-1 of this call)
+static int append_rounds(int fd, int64_t &file_off, const char *path, int64_t C, const std::vector<int64_t> &weight_prefix, EMIT emit) {
     const int64_t W = weight_prefix[C];
     int T = host_threads();
     if (W < (1 << 20)) T = 1;
@@ -722,18 +721,12 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
     std::vector<int64_t> rcut((size_t)R + 1, C);
     rcut[0] = 0;
     for (int64_t r = 1; r < R; r++) { rcut[r] = cut_at(W * r / R); if (rcut[r] < rcut[r - 1]) rcut[r] = rcut[r - 1]; }
-    // the rounds go to a temporary name beside the target, which takes its place only when every row is on disk: a row that
-    // cannot be formatted (a cs tag clipped inside an insertion: get_edited_paf_data throws) or a failing write leaves no
-    // truncated .paf behind
-    const std::string tmp_path = std::string(path) + ".tmp." + std::to_string((long long)::getpid());
-    const int fd = ::open(tmp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) { set_last_error(std::string("cannot open ") + path + " for writing"); return AASM_E_IO; }
     std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
     std::vector<std::string> errs((size_t)T);
     std::vector<int> rcs((size_t)T, AASM_OK);
     std::vector<int64_t> off((size_t)T + 1, 0);                          // file offsets of the round being written
     std::atomic<int> wrc{AASM_OK};
-    int64_t base = 0, total = 0;
+    int64_t base = file_off;
     int fail_rc = AASM_OK;
     std::string fail_msg;
     for (int64_t r = 0; r <= R && fail_rc == AASM_OK && wrc == AASM_OK; r++) {   // step r: format round r (r < R), write round r - 1 (r > 0)
@@ -770,19 +763,16 @@ static int write_file_mt(const aasm_paf &paf, const char *path, const std::vecto
             off[0] = base;
             for (int t = 0; t < T; t++) off[t + 1] = off[t] + (int64_t)bufs[fset][t].size();
             base = off[T];
-            total = base;
         }
     }
     int rc = fail_rc;
-    if (::close(fd) != 0 && rc == AASM_OK) rc = AASM_E_IO;
     if (rc == AASM_OK && wrc != AASM_OK) rc = wrc;
-    if (rc == AASM_OK && ::rename(tmp_path.c_str(), path) != 0) rc = AASM_E_IO;
-    if (rc != AASM_OK) ::unlink(tmp_path.c_str());
     if (fail_rc != AASM_OK) set_last_error(fail_msg);
     else if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
     if (std::getenv("AASM_IO_TIMING"))
         std::fprintf(stderr, "aasm io: %s format + write %.3f s (%.1f MB, %d threads x %lld rounds)\n", path,
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), total / 1e6, T, (long long)R);
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (base - file_off) / 1e6, T, (long long)R);
+    file_off = base;
     return rc;
 }
 
@@ -906,12 +896,62 @@ int aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *v) {
     return AASM_OK;
 }
 
-int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const char *main_path, const char *alt_path,
-                           const char *all_path) {
-    if (!paf || !out || out->n_contigs != paf->n_contigs()) return AASM_E_INVAL;
+// ---- output session: the three files are opened once (under temporary names), receive the rows of consecutive contig
+// ranges - so that a caller can solve one range while the rows of the range before are written - and take their final
+// names only when everything is on disk (commit); a row that cannot be formatted (a cs tag clipped inside an insertion:
+// get_edited_paf_data throws) or a failing write leaves no truncated .paf behind.
+struct aasm_writer {
+    std::string path[3], tmp[3];
+    int fd[3] = {-1, -1, -1};
+    int64_t off[3] = {0, 0, 0};
+    int64_t next_contig = 0;
+    bool failed = false;
+};
+
+int aasm_writer_open(const char *main_path, const char *alt_path, const char *all_path, aasm_writer **w_out) {
+    if (!w_out) return AASM_E_INVAL;
+    aasm_writer *w = new aasm_writer();
+    const char *p[3] = {main_path, alt_path, all_path};
+    for (int i = 0; i < 3; i++) {
+        if (!p[i]) continue;
+        w->path[i] = p[i];
+        w->tmp[i] = w->path[i] + ".tmp." + std::to_string((long long)::getpid());
+        w->fd[i] = ::open(w->tmp[i].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (w->fd[i] < 0) {
+            set_last_error(std::string("cannot open ") + p[i] + " for writing");
+            w->path[i].clear();
+            aasm_writer_close(w, 0);
+            return AASM_E_IO;
+        }
+    }
+    *w_out = w;
+    return AASM_OK;
+}
+
+int aasm_writer_close(aasm_writer *w, int commit) {
+    if (!w) return AASM_E_INVAL;
+    int rc = AASM_OK;
+    for (int i = 0; i < 3; i++) {
+        if (w->fd[i] >= 0 && ::close(w->fd[i]) != 0) rc = AASM_E_IO;
+        w->fd[i] = -1;
+    }
+    const bool keep = commit && !w->failed && rc == AASM_OK;
+    for (int i = 0; i < 3; i++) {
+        if (w->path[i].empty()) continue;
+        if (keep) { if (::rename(w->tmp[i].c_str(), w->path[i].c_str()) != 0) { rc = AASM_E_IO; set_last_error("cannot rename " + w->tmp[i]); } }
+        else ::unlink(w->tmp[i].c_str());
+    }
+    if (commit && w->failed && rc == AASM_OK) rc = AASM_E_IO;
+    delete w;
+    return rc;
+}
+
+// rows of contigs [contig0, contig0 + out->n_contigs) of `paf`; ranges must arrive in order, without gaps
+int aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out *out, int64_t contig0) {
+    if (!w || !paf || !out || contig0 != w->next_contig || contig0 + out->n_contigs > paf->n_contigs()) return AASM_E_INVAL;
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
-    const int64_t C = paf->n_contigs();
-    int rc;
+    if (w->failed) return AASM_E_IO;
+    const int64_t C = out->n_contigs;
     // upper estimate of a contig's output bytes: every element costs its record's cs tag + the 14 other columns
     auto bytes_prefix = [&](const int64_t *off, const aasm_out_elem *el, int64_t extra_name) {
         std::vector<int64_t> wp((size_t)C + 1, 0);
@@ -919,11 +959,11 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
             const int T = host_threads();
             for (int64_t c = C * t / T; c < C * (t + 1) / T; c++) {
                 int64_t b = 0;
-                const int64_t r0 = paf->ctg_rec_off[c], nrec = paf->ctg_rec_off[c + 1] - r0;
+                const int64_t r0 = paf->ctg_rec_off[contig0 + c], nrec = paf->ctg_rec_off[contig0 + c + 1] - r0;
                 for (int64_t k = off[c]; k < off[c + 1]; k++) {
                     const int64_t ci = el[k].ctg_index;
                     if (ci >= 0 && ci < nrec) b += paf->cs_off[r0 + ci + 1] - paf->cs_off[r0 + ci];
-                    b += 150 + (int64_t)paf->ctg_name[c].size() + extra_name;
+                    b += 150 + (int64_t)paf->ctg_name[contig0 + c].size() + extra_name;
                 }
                 wp[c + 1] = b;
             }
@@ -931,47 +971,74 @@ int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const
         for (int64_t c = 0; c < C; c++) wp[c + 1] += wp[c];
         return wp;
     };
-    if (main_path) {                                                    // process_output, :407-443
+    int rcs[3] = {AASM_OK, AASM_OK, AASM_OK};
+    std::string errs[3];
+    auto do_main = [&]() {                                              // process_output, :407-443
+        if (w->fd[0] < 0) return;
         const std::vector<int64_t> wp = bytes_prefix(out->main_off, out->main_elems, 0);
-        rc = write_file_mt(*paf, main_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
+        rcs[0] = append_rounds(w->fd[0], w->off[0], w->path[0].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
             for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++) {
-                const int r = emit_line(*paf, c, paf->ctg_name[c], out->main_elems[k], buf, err);
+                const int r = emit_line(*paf, contig0 + c, paf->ctg_name[contig0 + c], out->main_elems[k], buf, err);
                 if (r != AASM_OK) return r;
             }
             return (int)AASM_OK;
         });
-        if (rc != AASM_OK) return rc;
-    }
-    if (alt_path) {
-        const std::vector<int64_t> wp = bytes_prefix(out->alt_off, out->alt_elems, 0);
-        rc = write_file_mt(*paf, alt_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
-            for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
-                const int r = emit_line(*paf, c, paf->ctg_name[c], out->alt_elems[k], buf, err);
-                if (r != AASM_OK) return r;
-            }
-            return (int)AASM_OK;
-        });
-        if (rc != AASM_OK) return rc;
-    }
-    if (all_path) {                                                     // process_max_output, :445-485
-        std::vector<int64_t> eoff((size_t)C + 1);
-        for (int64_t c = 0; c <= C; c++) eoff[c] = out->all_elem_off[out->all_path_off[c]];
-        const std::vector<int64_t> wp = bytes_prefix(eoff.data(), out->all_elems, 12);
-        rc = write_file_mt(*paf, all_path, wp, [&](int64_t c, std::string &buf, std::string &err) {
-            int32_t cnt = 0;
-            for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
-                ++cnt;
-                const std::string name = paf->ctg_name[c] + "." + std::to_string(cnt);
-                for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++) {
-                    const int r = emit_line(*paf, c, name, out->all_elems[k], buf, err);
+        if (rcs[0] != AASM_OK) errs[0] = aasm_last_error();
+    };
+    auto do_rest = [&]() {                                              // the two small files, beside the big one (three inodes: three write locks)
+        if (w->fd[1] >= 0) {
+            const std::vector<int64_t> wp = bytes_prefix(out->alt_off, out->alt_elems, 0);
+            rcs[1] = append_rounds(w->fd[1], w->off[1], w->path[1].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
+                for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
+                    const int r = emit_line(*paf, contig0 + c, paf->ctg_name[contig0 + c], out->alt_elems[k], buf, err);
                     if (r != AASM_OK) return r;
                 }
-            }
-            return (int)AASM_OK;
-        });
-        if (rc != AASM_OK) return rc;
+                return (int)AASM_OK;
+            });
+            if (rcs[1] != AASM_OK) errs[1] = aasm_last_error();
+        }
+        if (w->fd[2] >= 0 && rcs[1] == AASM_OK) {                        // process_max_output, :445-485
+            std::vector<int64_t> eoff((size_t)C + 1);
+            for (int64_t c = 0; c <= C; c++) eoff[c] = out->all_elem_off[out->all_path_off[c]];
+            const std::vector<int64_t> wp = bytes_prefix(eoff.data(), out->all_elems, 12);
+            rcs[2] = append_rounds(w->fd[2], w->off[2], w->path[2].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
+                int32_t cnt = 0;
+                for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
+                    ++cnt;
+                    const std::string name = paf->ctg_name[contig0 + c] + "." + std::to_string(cnt);
+                    for (int64_t k = out->all_elem_off[pth]; k < out->all_elem_off[pth + 1]; k++) {
+                        const int r = emit_line(*paf, contig0 + c, name, out->all_elems[k], buf, err);
+                        if (r != AASM_OK) return r;
+                    }
+                }
+                return (int)AASM_OK;
+            });
+            if (rcs[2] != AASM_OK) errs[2] = aasm_last_error();
+        }
+    };
+    {
+        std::thread side(do_rest);
+        do_main();
+        side.join();
     }
+    w->next_contig = contig0 + C;
+    for (int i = 0; i < 3; i++)
+        if (rcs[i] != AASM_OK) { w->failed = true; set_last_error(errs[i]); return rcs[i]; }   // (the main file's error first: file order of the reference's writers)
     return AASM_OK;
+}
+
+int aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out, const char *main_path, const char *alt_path,
+                           const char *all_path) {
+    if (!paf || !out || out->n_contigs != paf->n_contigs()) return AASM_E_INVAL;
+    if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
+    aasm_writer *w = nullptr;
+    int rc = aasm_writer_open(main_path, alt_path, all_path, &w);
+    if (rc != AASM_OK) return rc;
+    rc = aasm_writer_append(w, paf, out, 0);
+    const std::string msg = rc != AASM_OK ? aasm_last_error() : "";
+    const int rc2 = aasm_writer_close(w, rc == AASM_OK ? 1 : 0);
+    if (rc != AASM_OK) { set_last_error(msg); return rc; }
+    return rc2;
 }
 
 int64_t aasm_cs_match_ranges(const char *cs, int64_t cs_len, int aln_fwd, int64_t qry_str, int64_t qry_end, int64_t ref_str,

@@ -12,6 +12,9 @@
 #include <cstring>
 #include <chrono>
 #include <filesystem>
+#include <condition_variable>
+#include <mutex>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include <iostream>
@@ -109,23 +112,89 @@ int main(int argc, char **argv) {
     aasm_paf_batch(paf, &view);
     std::cout << "Analyze PAF " << view.n_contigs << " data in parallel" << std::endl;   // :349
     const auto t1 = clk::now();                                                 // (the warm-up threads are not waited for: the upload runs beside them, the solve takes the context's lock after them)
-    aasm_batch_out out;
-    rc = aasm_solve_batch_multi(&view, &opts, gpus, &out);
-    const auto t2 = clk::now();
-    if (rc == AASM_E_PARSE) { std::cerr << aasm_last_error() << "\n"; aasm_paf_free(paf); return 1; }       // malformed cs tag, found by the device parser
-    if (rc != AASM_OK) { std::cerr << "alignasm: solver failed (" << rc << "): " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 2; }
-    if (out.stats.n_internal_errors) std::cerr << "alignasm: " << out.stats.n_internal_errors << " contig(s) hit an internal error state\n";
-    std::cout << "Write output PAF file" << std::endl;                           // :487
     auto ap = std::filesystem::absolute(p);
     auto f_main = ap; f_main.replace_extension(".aln.paf");
     auto f_alt = ap; f_alt.replace_extension(".aln.alt.paf");
     auto f_all = ap; f_all.replace_extension(".aln.all.paf");
-    rc = aasm_paf_write_outputs(paf, &out, f_main.c_str(), f_alt.c_str(), f_all.c_str());
-    if (rc != AASM_OK) std::cerr << "alignasm: writing outputs failed: " << aasm_last_error() << "\n";
+    double upload_s = 0, device_s = 0, fetch_s = 0, solve_busy_s = 0, write_busy_s = 0;
+    int64_t n_internal = 0;
+    clk::time_point t2 = t1;
+    if (gpus <= 1 && view.n_contigs >= 64 && view.n_records >= (1 << 16)) {
+        // ---- one GPU: the file goes through in contig ranges of about equal record counts; while the GPU solves range k
+        //      (upload -> K0 .. K9 -> fetch) the host threads format and write the rows of range k - 1.  The three outputs
+        //      are appended to in contig order (aasm_writer_*), so the bytes are those of the one-piece path.
+        const int n_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(2, view.n_records / (1 << 19)));
+        std::vector<int64_t> cut(n_chunks + 1, view.n_contigs);
+        cut[0] = 0;
+        for (int k = 1; k < n_chunks; k++) {
+            const int64_t want = view.n_records * k / n_chunks;
+            int64_t c = std::lower_bound(view.ctg_rec_off, view.ctg_rec_off + view.n_contigs + 1, want) - view.ctg_rec_off;
+            cut[k] = std::min<int64_t>(std::max<int64_t>(c, cut[k - 1] + 1), view.n_contigs - (n_chunks - k));
+        }
+        aasm_writer *wr = nullptr;
+        rc = aasm_writer_open(f_main.c_str(), f_alt.c_str(), f_all.c_str(), &wr);
+        if (rc != AASM_OK) { std::cerr << "alignasm: writing outputs failed: " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 3; }
+        std::vector<aasm_batch_out> outs(n_chunks);
+        std::vector<int> rcs(n_chunks, AASM_OK);
+        std::vector<std::string> errs(n_chunks);
+        std::mutex mu;
+        std::condition_variable cv;
+        int solved = 0;                                                         // ranges [0, solved) are ready for the writer
+        bool stop = false;
+        std::thread solver([&] {
+            for (int k = 0; k < n_chunks; k++) {
+                { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
+                const auto a0 = clk::now();
+                std::memset(&outs[k], 0, sizeof(outs[k]));
+                rcs[k] = aasm_solve_batch_range(&view, cut[k], cut[k + 1], &opts, &outs[k]);
+                if (rcs[k] != AASM_OK) errs[k] = aasm_last_error();
+                else { upload_s += outs[k].stats.reserved_f[0] / 1e3; device_s += outs[k].stats.reserved_f[2] / 1e3; fetch_s += outs[k].stats.reserved_f[1] / 1e3; n_internal += outs[k].stats.n_internal_errors; }
+                solve_busy_s += secs(a0, clk::now());
+                { std::lock_guard<std::mutex> lk(mu); solved = k + 1; }
+                cv.notify_all();
+                if (rcs[k] != AASM_OK) break;
+            }
+        });
+        bool said_write = false;
+        int wrc = AASM_OK, src_ = AASM_OK;
+        std::string fail;
+        for (int k = 0; k < n_chunks; k++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return solved > k; }); }
+            if (rcs[k] != AASM_OK) { src_ = rcs[k]; fail = errs[k]; break; }
+            if (k == n_chunks - 1) t2 = clk::now();
+            if (!said_write) { std::cout << "Write output PAF file" << std::endl; said_write = true; }   // :487
+            const auto a0 = clk::now();
+            wrc = aasm_writer_append(wr, paf, &outs[k], cut[k]);
+            write_busy_s += secs(a0, clk::now());
+            if (wrc != AASM_OK) { fail = aasm_last_error(); break; }
+        }
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        solver.join();
+        const int crc = aasm_writer_close(wr, src_ == AASM_OK && wrc == AASM_OK ? 1 : 0);
+        if (src_ == AASM_E_PARSE) { std::cerr << fail << "\n"; aasm_paf_free(paf); return 1; }             // malformed cs tag, found by the device parser
+        if (src_ != AASM_OK) { std::cerr << "alignasm: solver failed (" << src_ << "): " << fail << "\n"; aasm_paf_free(paf); return 2; }
+        if (n_internal) std::cerr << "alignasm: " << n_internal << " contig(s) hit an internal error state\n";
+        rc = wrc != AASM_OK ? wrc : crc;
+        if (rc != AASM_OK) std::cerr << "alignasm: writing outputs failed: " << (wrc != AASM_OK ? fail : std::string(aasm_last_error())) << "\n";
+    } else {
+        aasm_batch_out out;
+        rc = aasm_solve_batch_multi(&view, &opts, gpus, &out);
+        t2 = clk::now();
+        if (rc == AASM_E_PARSE) { std::cerr << aasm_last_error() << "\n"; aasm_paf_free(paf); return 1; }       // malformed cs tag, found by the device parser
+        if (rc != AASM_OK) { std::cerr << "alignasm: solver failed (" << rc << "): " << aasm_last_error() << "\n"; aasm_paf_free(paf); return 2; }
+        if (out.stats.n_internal_errors) std::cerr << "alignasm: " << out.stats.n_internal_errors << " contig(s) hit an internal error state\n";
+        upload_s = out.stats.reserved_f[0] / 1e3; device_s = out.stats.reserved_f[2] / 1e3; fetch_s = out.stats.reserved_f[1] / 1e3;
+        solve_busy_s = secs(t1, t2);
+        std::cout << "Write output PAF file" << std::endl;                           // :487
+        rc = aasm_paf_write_outputs(paf, &out, f_main.c_str(), f_alt.c_str(), f_all.c_str());
+        if (rc != AASM_OK) std::cerr << "alignasm: writing outputs failed: " << aasm_last_error() << "\n";
+        write_busy_s = secs(t2, clk::now());
+    }
     const auto t3 = clk::now();
     if (timing)
-        std::cerr << "alignasm timing: records " << view.n_records << " contigs " << view.n_contigs << " read_s " << secs(t0, t1) << " solve_s " << secs(t1, t2)
-                  << " (upload " << out.stats.reserved_f[0] / 1e3 << " device " << out.stats.reserved_f[2] / 1e3 << " fetch " << out.stats.reserved_f[1] / 1e3 << ") write_s " << secs(t2, t3) << " total_s " << secs(t0, t3) << "\n";
+        std::cerr << "alignasm timing: records " << view.n_records << " contigs " << view.n_contigs << " read_s " << secs(t0, t1) << " solve_s " << solve_busy_s
+                  << " (upload " << upload_s << " device " << device_s << " fetch " << fetch_s << ") write_s " << write_busy_s
+                  << " overlap_s " << (solve_busy_s + write_busy_s - secs(t1, t3)) << " total_s " << secs(t0, t3) << "\n";
     // the process ends here: the GBs of parsed text and results go back to the OS in one piece
     // instead of vector by vector (1.7 s of page freeing for a 5M-record file)
     std::cout.flush(); std::cerr.flush();

@@ -175,6 +175,9 @@ const char *aasm_last_error(void);
 /* solve_ctg_read over a batch (replaces the dispatch loop src/alignasm.cpp:346-397).
  * Host pointers in, host arrays out (malloc'ed into *out).                           */
 int  aasm_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out);
+/* The same for contigs [c0, c1) of the batch (out then covers c1 - c0 contigs): a caller that streams a file solves one
+ * range while it writes the rows of the range before (aasm_writer_*).  The batch is validated with the range c0 = 0.   */
+int  aasm_solve_batch_range(const aasm_batch_in *in, int64_t c0, int64_t c1, const aasm_opts *opts, aasm_batch_out *out);
 
 /* Contig-sharded solve across n_devices GPUs of one node (devices opts->device .. +n-1):
  * static per-contig partition, one host thread + stream per device, outputs concatenated
@@ -262,6 +265,13 @@ int64_t aasm_paf_n_contigs(const aasm_paf *paf);
 /* write <stem>.aln.paf / .aln.alt.paf / .aln.all.paf (alignasm.cpp:407-490)          */
 int  aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out,
                             const char *main_path, const char *alt_path, const char *all_path);
+/* The same in pieces: the three files are opened once (under temporary names), receive the rows of consecutive contig
+ * ranges in order (out = the result of contigs [contig0, contig0 + out->n_contigs)), and take their final names at
+ * aasm_writer_close(w, 1); close(w, 0), or any failed append, removes them.                                        */
+typedef struct aasm_writer aasm_writer;
+int  aasm_writer_open(const char *main_path, const char *alt_path, const char *all_path, aasm_writer **w);
+int  aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out *out, int64_t contig0);
+int  aasm_writer_close(aasm_writer *w, int commit);
 /* get_overlap_range (paf_data.cpp:90): returns #ranges or <0; arrays may be NULL      */
 int64_t aasm_cs_match_ranges(const char *cs, int64_t cs_len, int aln_fwd,
                              int64_t qry_str, int64_t qry_end, int64_t ref_str, int64_t ref_end,
