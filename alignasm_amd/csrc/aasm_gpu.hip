@@ -43,6 +43,7 @@ namespace aasm {
     }
 AASM_DEF_KERNEL(aasm_k0_cs_ranges, KN_CS_RANGES, 256)
 AASM_DEF_KERNEL_LDS(aasm_k1_sort, KN_SORT, 256, AASM_SORT_LDS_BYTES, 2)
+AASM_DEF_KERNEL(aasm_k1_sort_rank, KN_SORT_RANK, 256)
 AASM_DEF_KERNEL_LDS(aasm_k1_sort_fix, KN_SORT_FIX, 64, AASM_SORTFIX_LDS_BYTES, 1)
 AASM_DEF_KERNEL(aasm_k1_gather_parts, KN_GATHER_PARTS, 64)
 AASM_DEF_KERNEL(aasm_k2_ov_count, KN_OV_COUNT, 256)
@@ -409,7 +410,7 @@ struct GpuBackend {
         dim3 g((unsigned)nblocks), b((unsigned)nthreads);
         switch (kn) {
 #define L(KN, name) case KN: hipLaunchKernelGGL(name, g, b, 0, stream, w); break;
-            L(KN_CS_RANGES, aasm_k0_cs_ranges) L(KN_SORT, aasm_k1_sort) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
+            L(KN_CS_RANGES, aasm_k0_cs_ranges) L(KN_SORT, aasm_k1_sort) L(KN_SORT_RANK, aasm_k1_sort_rank) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
             L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
             L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill)

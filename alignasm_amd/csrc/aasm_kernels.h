@@ -115,7 +115,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -271,25 +271,9 @@ AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
         else for (int32_t t = k.tid; t < n; t += k.nthreads) { t_qs[base + t] = L->qs[t]; t_qe[base + t] = L->qe[t]; t_ix[base + t] = L->idx[t]; }
         block_barrier();
     }
-    if (nch > 1) {                                                   // rank = place in own chunk + lower bounds in the others
-        for (int64_t g = k.tid; g < N; g += k.nthreads) {
-            const int64_t a0 = t_qs[g], a1 = t_qe[g];
-            const int32_t a2 = t_ix[g];
-            const int64_t own = g / SORT_CHUNK;
-            int64_t rank = g - own * SORT_CHUNK;
-            for (int64_t ch = 0; ch < nch; ch++) {
-                if (ch == own) continue;
-                const int64_t base = ch * SORT_CHUNK;
-                int64_t lo = 0, hi = (N - base < SORT_CHUNK) ? (N - base) : SORT_CHUNK;
-                while (lo < hi) {
-                    const int64_t m = (lo + hi) >> 1;
-                    if (sortkey_lt(t_qs[base + m], t_qe[base + m], t_ix[base + m], a0, a1, a2)) lo = m + 1; else hi = m;
-                }
-                rank += lo;
-            }
-            w.perm[b + rank] = a2;
-        }
-        block_barrier();
+    if (nch > 1) {                                                   // the sorted chunks stay in scratch: kb_sort_rank merges them, a thread per record
+        if (k.tid == 0) atomic_add(&w.counters[CNT_LONGSORT], (int64_t)1);
+        return;
     }
     if (N > 16) {                                                    // duplicate keys are neighbours now
         int dup = 0;
@@ -299,6 +283,40 @@ AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
         }
         if (dup) w.dupflag[c] = 1;
     }
+}
+// contigs longer than one chunk: rank of a record = place in its own sorted chunk + its lower bounds in the other chunks of
+// its contig (binary searches).  One THREAD PER RECORD of the batch (a block per contig spent 64 of the 71 ms sort of a
+// 100 000-record contig here); a batch without such a contig leaves after one load.  A record with an equal (qry_str, qry_end)
+// key anywhere in its contig shows up next to one of the lower bounds: dupflag as in kb_sort.
+AASM_DEV void kb_sort_rank(const KCtx &k, const WS &w) {
+    if (w.counters[CNT_LONGSORT] == 0) return;
+    const int64_t g = k.bid * k.nthreads + k.tid;                    // record, relative to R0
+    if (g >= w.R) return;
+    int64_t lo_c = 0, hi_c = w.C;                                    // contig of the record: last c with rec_off[c] - R0 <= g
+    while (hi_c - lo_c > 1) { const int64_t m = (lo_c + hi_c) >> 1; if (w.rec_off[m] - w.R0 <= g) lo_c = m; else hi_c = m; }
+    const int64_t c = lo_c, gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
+    if (N <= SORT_CHUNK) return;
+    const int64_t *t_qs = w.s_qs + b, *t_qe = w.s_qe + b;
+    const int32_t *t_ix = w.s_orig + b;
+    const int64_t i = g - b, nch = (N + SORT_CHUNK - 1) / SORT_CHUNK;
+    const int64_t a0 = t_qs[i], a1 = t_qe[i];
+    const int32_t a2 = t_ix[i];
+    const int64_t own = i / SORT_CHUNK;
+    int64_t rank = i - own * SORT_CHUNK;
+    bool dup = (i > own * SORT_CHUNK && t_qs[i - 1] == a0 && t_qe[i - 1] == a1);
+    for (int64_t ch = 0; ch < nch; ch++) {
+        if (ch == own) continue;
+        const int64_t base = ch * SORT_CHUNK, len = (N - base < SORT_CHUNK) ? (N - base) : SORT_CHUNK;
+        int64_t lo = 0, hi = len;
+        while (lo < hi) {
+            const int64_t m = (lo + hi) >> 1;
+            if (sortkey_lt(t_qs[base + m], t_qe[base + m], t_ix[base + m], a0, a1, a2)) lo = m + 1; else hi = m;
+        }
+        rank += lo;
+        dup |= (lo < len && t_qs[base + lo] == a0 && t_qe[base + lo] == a1) || (lo > 0 && t_qs[base + lo - 1] == a0 && t_qe[base + lo - 1] == a1);
+    }
+    w.perm[b + rank] = a2;
+    if (dup) w.dupflag[c] = 1;
 }
 
 // ---- libstdc++ (GCC 11) std::sort replayed (hazard B1) -------------------------------

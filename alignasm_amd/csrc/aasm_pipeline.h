@@ -21,7 +21,7 @@
 namespace aasm {
 
 enum Kern {
-    KN_CS_RANGES, KN_SORT, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
+    KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
@@ -32,6 +32,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
     switch (kn) {
         case KN_CS_RANGES: kb_cs_ranges(k, w); break;
         case KN_SORT: kb_sort(k, w); break;
+        case KN_SORT_RANK: kb_sort_rank(k, w); break;
         case KN_SORT_FIX: kb_sort_fix(k, w); break;
         case KN_GATHER_PARTS: kb_gather_parts(k, w); break;
         case KN_OV_COUNT: kb_ov_count(k, w); break;
@@ -135,6 +136,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     CHECK_ALLOC();
     if (opts.reserved[2] & 1) be.launch(KN_SORT, C, 4096, w);       // test hook: an invalid launch configuration (block size > 1024)
     be.launch(KN_SORT, C, 256, w);
+    be.launch(KN_SORT_RANK, cdiv(R, 256), 256, w);
     be.launch(KN_SORT_FIX, C, AASM_WAVE, w);
     be.launch(KN_GATHER_PARTS, C, AASM_WAVE, w);
     be.phase_end(AASM_PH_SORT);
