@@ -191,6 +191,9 @@ template <class P> AASM_DEV uint64_t wave_index_mask(int n, int lane, P pred) {
 }
 
 AASM_DEV bool wave_any(bool p) { return wave_ballot(p) != 0; }
+AASM_DEV int32_t hi32(uint64_t x) { return (int32_t)(x >> 32); }
+AASM_DEV int32_t lo32(uint64_t x) { return (int32_t)(uint32_t)x; }
+AASM_DEV uint64_t mk64(int32_t lo, int32_t hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; }
 AASM_DEV uint64_t lanemask_lt(int lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
 
 // inclusive wave scans (Hillis-Steele over 64 lanes; identity with one lane)

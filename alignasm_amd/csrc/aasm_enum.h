@@ -91,9 +91,6 @@ AASM_DEV uint64_t qe_key2(int32_t anom, int32_t qnz, int32_t qtot) {
     const double r = (double)((uint64_t)(uint32_t)qnz << 41) / (double)(qtot ? qtot : 1);
     return ((uint64_t)(uint32_t)anom << 42) | ((((uint64_t)1 << 42) - 1) - (uint64_t)r);
 }
-AASM_DEV int32_t hi32(uint64_t x) { return (int32_t)(x >> 32); }
-AASM_DEV int32_t lo32(uint64_t x) { return (int32_t)(uint32_t)x; }
-AASM_DEV uint64_t mk64(int32_t lo, int32_t hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; }
 
 // value of lane (lane ^ M): DPP inside a row of 16, ds_swizzle inside 32 lanes, bpermute across the halves
 template <int M> AASM_DEV int32_t lane_xor(int32_t x, int lane) {

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards).
-#   gpurun -- 'bash tools/collect_profiles.sh r02'
+#   gpurun -- 'bash tools/collect_profiles.sh r03'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -21,5 +21,11 @@ cp $O/kt5/*/*kernel_stats.csv $O/${TAG}_c5_kernel_stats.csv
 for n in 250 625 1000 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --dup 3 --shuffle 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_dup3_shuffled.json
 python3 $R/tools/phase_probe.py --contigs 1000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_1000contigs.json
-rm -rf $O/kt $O/kt5 $O/pmc_fetch $O/pmc_write $O/pmc_sq
+python3 $R/tools/phase_probe.py --contigs 5000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_5000contigs.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktk -- python3 $R/tools/phase_probe.py --contigs 5000 --k 10000 --reps 3 > /dev/null 2> $O/ktk.err || exit 1
+cp $O/ktk/*/*kernel_stats.csv $O/${TAG}_c3_k10000_kernel_stats.csv
+python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --heavy 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_heavy_tail.json
+python3 $R/tools/giant_probe.py > $O/${TAG}_giant_contigs.jsonl 2>&1
+python3 $R/tools/e2e_cli.py --contigs 5000 --k 4 > $O/${TAG}_e2e_cli.log 2>&1
+rm -rf $O/kt $O/kt5 $O/ktk $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O

@@ -5,7 +5,8 @@ os.environ["AASM_LIB_OVERRIDE"] = os.environ.get("AASM_KPROF_LIB") or os.path.jo
 sys.path.insert(0, ROOT)
 import numpy as np, alignasm_amd as A
 nc, nr, K, dense, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-paf = A.Paf.synth(nc, nr, seed, dense=bool(dense), no_cs=True)
+dup = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+paf = A.Paf.synth(nc, nr, seed, dense=bool(dense), dup_every=dup, no_cs=True)
 db = A.DeviceBatch(paf)
 for _ in range(2):
     res = db.solve(max_paths=K, timing=True, keep_debug=True)
