@@ -74,10 +74,7 @@ AASM_DEF_KERNEL_LDS(aasm_k8_enum_heap, KN_ENUM_HEAP, 64, AASM_ENUM_LDS_BYTES, 2)
 AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
 AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
-#ifndef AASM_SELCONV_WAVES
-#define AASM_SELCONV_WAVES 5
-#endif
-AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES, AASM_SELCONV_WAVES)
+AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k9_topo_fill, KN_TOPO_FILL, 64)

@@ -115,7 +115,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_ISB_HIT, CNT_ISB_MISS, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -2153,8 +2153,7 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
 // ====================================================================================
 struct SelCtx {
     const WS *w;
-    int64_t c, b, vb;
-    int32_t N, V, cap;               // cap = N + 2 edge pairs per path buffer
+    int64_t c, b, N, V, vb, cap;     // cap = N + 2 edge pairs per path buffer
     int32_t src, dest;
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
     Dist *dist2;
@@ -2165,8 +2164,7 @@ struct SelCtx {
     bool err, res_lds;
     int lane;
     char *lds;
-    int32_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters, per conversion / contig
-    int32_t n_isb_hit, n_isb_miss;                   // window DPs answered by a batch of eight / run wave-wide
+    int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     int64_t kp_t0, kp_acc[8];
 #endif
@@ -2183,11 +2181,6 @@ struct SelCtx {
 // intermediate lists in LDS: the ISPR window + result, a 64-edge read window over the
 // recovered path and a 64-edge write buffer that is flushed by one coalesced store.
 #define ISPR_MAX_E 192
-#define ISB_N 8                    // window DPs per batch: eight lanes each
-#define ISB_MAXW 7                 // ... for windows whose target sits at most this many topological positions behind the start
-#define ISB_MAXRES 3               // ... and results of at most this many edges (longer ones run the wave-wide DP)
-#define ISB_WORDS (5 + 2 * ISB_MAXRES)
-#define ISB_ROWE (ISPR_MAX_E / ISB_N)  // row edges of one window of a batch (its share of the DP's LDS edge arrays)
 #define SEL_WIN 64
 struct SelLds {
     int64_t wq[ISPR_MAX_E];
@@ -2204,10 +2197,8 @@ struct SelLds {
     uint8_t pa_sg[SEL_WIN];        // ... and whether it is a single-record vertex (v_i == v_j): bit 0; bit 1: the ISPR over this edge
                                    //     and the next one is decided without running it (see sel_pa_get)
     int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
-    int32_t isb[ISB_N][ISB_WORDS]; // results of the window DPs run eight at a time (sel_isb_fill): {path edge, #edges | -1, #rows, #row edges, mode, edges (u, v) newest first}
-    int32_t isb_slot[ISB_N];       // scratch: window slot of the g-th candidate
 };
-#define AASM_SEL_LDS_BYTES 7872
+#define AASM_SEL_LDS_BYTES 7488
 static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
@@ -2387,7 +2378,7 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
         if (s.stamp[u] != ep) continue;
         const Dist cd = s.dist2[u];
         const int64_t r0 = w.rowptr[s.vb + u], r1 = w.rowptr[s.vb + u + 1];
-        s.n_ispr_v++; s.n_ispr_e += (int32_t)(r1 - r0);
+        s.n_ispr_v++; s.n_ispr_e += r1 - r0;
         const bool u_ok = !(u == s.src || u == s.dest) && (w.v_j[s.vb + u] == wl);   // :767-773
         for (int64_t e = r0 + s.lane; e < r1; e += AASM_WAVE) {
             const int32_t v = w.e_col[e];
@@ -2492,129 +2483,6 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     SPROF(s, 4);                                                     // ISPR backtrack
     return n;
 }
-#if !defined(AASM_HOST_EMUL)
-// internal_shortest_path_recover for EIGHT path edges at once.  The upgrade loop asks for one window DP per unsettled
-// single-record head; run alone, such a DP keeps two or three lanes busy (its window has a handful of vertices) and pays
-// three dependent round trips of staging - and with thousands of conversion waves on the chip the kernel is bound by
-// the number of instructions issued.  Here the next eight candidates of the path window are taken together, eight lanes
-// each: lane j of a group IS window position j (its distance, predecessor and reached flag live in its registers), the
-// group walks its rows source by source - every lane reads the same edge, the lane the edge points at relaxes itself -
-// so rows are relaxed in list order and sources in topological order, as the reference does (strict '<': first wins).
-// The result of a candidate is what sel_ispr would return IF the step starts at the edge's own tail (it does 99 % of the
-// time) - the upgrade loop checks that before it uses one; anything out of the ordinary (window longer than ISB_MAXW, more
-// than ISB_ROWE row edges, result longer than ISB_MAXRES, target not reached) is recorded as "not here" and the wave-wide DP runs.
-AASM_DEV void sel_isb_fill(SelCtx &s, int32_t it0, int32_t la) {
-    SelLds *L = (SelLds *)s.lds;
-    const WS &w = *s.w;
-    const int lane = s.lane, g = lane >> 3, j = lane & 7, gl0 = lane & ~7;
-    const int32_t n_win = (la - s.pa_base < SEL_WIN) ? (la - s.pa_base) : SEL_WIN;
-    // ---- candidates: window slots x >= it0 - pa_base whose step would call the DP (see sel_upgrade)
-    const int32_t x = it0 - s.pa_base + lane;
-    bool cand = false;
-    if (x >= 0 && x < n_win) {
-        const int32_t u = L->pa_win[2 * x], v = L->pa_win[2 * x + 1], fl = L->pa_sg[x];
-        if (v == s.dest) cand = true;
-        else if ((u == s.src || (fl & 1)) && x + 1 < n_win) cand = !(fl & 2);
-    }
-    const uint64_t cm = wave_ballot(cand);
-    const int32_t rank = popc64(cm & lanemask_lt(lane));
-    if (lane < ISB_N) L->isb_slot[lane] = -1;
-    wave_lds_sync();
-    if (cand && rank < ISB_N) L->isb_slot[rank] = x;
-    wave_lds_sync();
-    const int32_t xs = L->isb_slot[g];
-    bool ok = xs >= 0;
-    int32_t a = 0, bd = 0, wl = -1, mode = 0;
-    if (ok) {
-        const int32_t u = L->pa_win[2 * xs], v = L->pa_win[2 * xs + 1];
-        a = u;
-        if (v == s.dest) { mode = 3; bd = v; }
-        else {
-            const int32_t nv = L->pa_win[2 * (xs + 1) + 1];
-            const bool nv_single = (nv == s.dest) || (L->pa_sg[xs + 1] & 1);
-            mode = nv_single ? 1 : 2; bd = nv;
-            if (nv_single) wl = L->pa_vj[xs];
-        }
-    }
-    const bool wl_flag = mode == 1;
-    int32_t pa = 0, W = 0;
-    if (ok) { pa = w.fwd_pos[s.vb + a]; W = w.fwd_pos[s.vb + bd] - pa; ok = W >= 1 && W <= ISB_MAXW; }
-    // ---- lane j: row start, vertex and v_j of window position j (j == W: the end of the last row, the target)
-    int64_t row = 0;
-    int32_t uj = -1, vjj = -3;
-    if (ok && j <= W) { row = w.tp_ptr[s.vb + pa + j]; uj = w.fwd_order[s.vb + pa + j]; vjj = w.tp_vj[s.vb + pa + j]; }
-    const int64_t e_start = wave_bcast(row, gl0);                    // (per-lane source: the group's lane 0)
-    const int32_t rel0 = (int32_t)(row - e_start);                   // my row's first edge, relative
-    // ---- the rows of the window, staged in the wave-wide DP's edge arrays (idle now): ISB_ROWE slots per group, one round trip
-    const int32_t T = __builtin_amdgcn_ds_bpermute((gl0 + (W & 7)) << 2, rel0);
-    ok = ok && T <= ISB_ROWE;
-    const int32_t eb = g * ISB_ROWE;
-    if (ok)
-        for (int32_t idx = j; idx < T; idx += 8) {
-            const int64_t e = e_start + idx;
-            int32_t rel = w.te_tgt[e] - pa;
-            if (rel > W) rel = -1;
-            L->tgt[eb + idx] = (int8_t)rel; L->wq[eb + idx] = w.te_wq[e]; L->wr[eb + idx] = w.te_wr[e]; L->fl[eb + idx] = w.te_fl[e];
-        }
-    wave_lds_sync();
-    Dist dj = dist_zero();
-    bool reach = ok && j == 0;
-    int32_t pre = -1, n_rows = 0, n_edges = 0;
-    for (int32_t t = 0; t < ISB_MAXW; t++) {
-        const int src_lane = gl0 + t;
-        const bool r_t = __builtin_amdgcn_ds_bpermute(src_lane << 2, reach ? 1 : 0) != 0;
-        const bool act = ok && t < W && r_t;
-        if (!wave_any(act)) continue;
-        Dist cd;
-        cd.qry = (int64_t)mk64(__builtin_amdgcn_ds_bpermute(src_lane << 2, lo32((uint64_t)dj.qry)), __builtin_amdgcn_ds_bpermute(src_lane << 2, hi32((uint64_t)dj.qry)));
-        cd.ref = (int64_t)mk64(__builtin_amdgcn_ds_bpermute(src_lane << 2, lo32((uint64_t)dj.ref)), __builtin_amdgcn_ds_bpermute(src_lane << 2, hi32((uint64_t)dj.ref)));
-        cd.anom = __builtin_amdgcn_ds_bpermute(src_lane << 2, dj.anom); cd.qnz = __builtin_amdgcn_ds_bpermute(src_lane << 2, dj.qnz);
-        cd.qtot = __builtin_amdgcn_ds_bpermute(src_lane << 2, dj.qtot); cd.pad = 0;
-        const int32_t r0 = __builtin_amdgcn_ds_bpermute(src_lane << 2, rel0), r1 = __builtin_amdgcn_ds_bpermute((src_lane + 1) << 2, rel0);
-        const int32_t vj_t = __builtin_amdgcn_ds_bpermute(src_lane << 2, vjj);
-        const bool to_dest_ok = !wl_flag || vj_t == wl;              // :767-773 (src / dest have vj < 0)
-        const int32_t len = act ? r1 - r0 : 0;
-        if (act) { n_rows++; n_edges += len; }
-        for (int32_t idx = 0; wave_any(idx < len); idx++) {
-            if (idx < len) {
-                const int32_t sl = eb + r0 + idx;
-                const int32_t tg = L->tgt[sl];
-                if (tg == j && !(tg == W && !to_dest_ok)) {          // (heads behind the window were staged as -1)
-                    const Dist nd = dist_add(cd, edge_dist(L->wq[sl], L->wr[sl], L->fl[sl]));
-                    if (!reach || dist_lt<QRY_SCORE_MODE>(nd, dj)) { dj = nd; pre = t; reach = true; }
-                }
-            }
-        }
-    }
-    // ---- backtrack from the target (lane W of the group); edges newest first, as sel_ispr leaves them
-    const bool reached = __builtin_amdgcn_ds_bpermute((gl0 + (W & 7)) << 2, reach ? 1 : 0) != 0;
-    int32_t n = -1;
-    int32_t ev[2 * ISB_MAXRES];
-    AASM_UNROLL
-    for (int q = 0; q < 2 * ISB_MAXRES; q++) ev[q] = -1;
-    if (ok && reached) {
-        n = 0;
-        int32_t last = W;
-        AASM_UNROLL
-        for (int q = 0; q < ISB_MAXRES + 1; q++) {
-            const int32_t pv = __builtin_amdgcn_ds_bpermute((gl0 + (last & 7)) << 2, pre);
-            const int32_t u_pv = __builtin_amdgcn_ds_bpermute((gl0 + (pv & 7)) << 2, uj), u_last = __builtin_amdgcn_ds_bpermute((gl0 + (last & 7)) << 2, uj);
-            if (last != 0 && n >= 0) {
-                if (q < ISB_MAXRES) { ev[2 * q] = u_pv; ev[2 * q + 1] = (last == W) ? bd : u_last; n++; last = pv; }
-                else n = -1;                                         // longer than the cache holds
-            }
-        }
-    }
-    if (xs >= 0 && j == 0) {
-        int32_t *r = L->isb[g];
-        r[0] = s.pa_base + xs; r[1] = n; r[2] = n_rows; r[3] = n_edges; r[4] = mode;
-        AASM_UNROLL
-        for (int q = 0; q < 2 * ISB_MAXRES; q++) r[5 + q] = ev[q];
-    }
-    if (xs < 0 && j == 0) L->isb[g][0] = -1;
-    wave_lds_sync();
-}
-#endif
 // append the ISPR result (reverse order), optionally without its last edge
 AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last) {
     SelLds *L = (SelLds *)s.lds;
@@ -2630,10 +2498,6 @@ AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last) {
 AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
     sel_out_begin(s, s.pathB);
     s.pa_base = -SEL_WIN - 1;
-#if !defined(AASM_HOST_EMUL)
-    if (s.lane < ISB_N) ((SelLds *)s.lds)->isb[s.lane][0] = -1;
-    wave_lds_sync();
-#endif
     for (int32_t it = 0; it < la && !s.err; ++it) {
         int32_t u, v, vj;
         bool v_single, settled;
@@ -2663,58 +2527,47 @@ AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
                 continue;
             }
         }
-        // One step = at most ONE internal_shortest_path_recover call (a single call site: the routine is large and
-        // inlined).  mode 1: the result without its last edge (:812-833 / :879-899); 2: the whole result, and the step
-        // consumes two path edges (:834-843 / :900-909); 3: the last hop into dest (:845-858).
         const bool from_src = (u == s.src);
-        int32_t mode, start, target, wl = -1, nu = -1, nv = -1;
-        bool known = false;
         if (from_src || v != s.dest) {
+            int32_t start;
             if (from_src) start = u;                                 // :804
             else {
                 if (s.out_n == 0) { s.err = true; break; }
                 start = s.last_head;                                 // continuation_src (:863)
                 if (!v_single) { sel_push(s, u, v); continue; }      // :866-873
             }
+            const int32_t y = vj;
             if (it + 1 >= la) { s.err = true; break; }
-            int32_t nvj;
+            int32_t nu, nv, nvj;
             bool nvs, nsettled;
             sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs, nsettled);
             const bool nv_single = (nv == s.dest) || nvs;
-            known = settled && start == u;                           // the call would return (u, v), (v, nv): see sel_pa_get
-            mode = nv_single ? 1 : 2;
-            if (nv_single) wl = vj;
-            target = nv;
-        } else {                                                     // v == dest
-            if (s.out_n == 0) { s.err = true; break; }
-            mode = 3; start = s.last_head; target = v;
-        }
-        int32_t n = 0;
-        if (!known) {
-            bool cached = false;
-#if !defined(AASM_HOST_EMUL)
-            if (start == u && it >= s.pa_base) {                     // the DP of this step may be one of a batch of eight (sel_isb_fill)
-                SelLds *L = (SelLds *)s.lds;
-                uint64_t hit = wave_ballot(s.lane < ISB_N && L->isb[s.lane & (ISB_N - 1)][0] == it);
-                if (!hit) { SPROF(s, 5); sel_isb_fill(s, it, la); SPROF(s, 2); hit = wave_ballot(s.lane < ISB_N && L->isb[s.lane & (ISB_N - 1)][0] == it); }
-                if (hit) {
-                    const int32_t *r = L->isb[ffs64(hit) - 1];
-                    const int32_t rn = uni(r[1]);
-                    if (rn >= 0 && uni(r[4]) == mode) {
-                        n = rn; cached = true; s.n_isb_hit++;
-                        s.n_ispr_v += uni(r[2]); s.n_ispr_e += uni(r[3]);
-                        if (s.lane < 2 * ISB_MAXRES) L->res[s.lane] = r[5 + s.lane];
-                        s.res_lds = true;
-                        wave_lds_sync();
-                    }
+            const bool known = settled && start == u;                // the call would return (u, v), (v, nv): see sel_pa_get
+            if (nv_single) {                                         // :812-833 / :879-899
+                if (known) sel_push(s, u, v);                        // the result without its last edge
+                else {
+                    const int32_t n = sel_ispr(s, start, nv, true, y);
+                    if (n < 0) break;
+                    if (n == 0) sel_push(s, u, v);
+                    else sel_append_alt(s, n, true);
                 }
+            } else {                                                 // :834-843 / :900-909
+                if (known) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                else {
+                    const int32_t n = sel_ispr(s, start, nv, false, -1);
+                    if (n < 0) break;
+                    if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                    else sel_append_alt(s, n, false);
+                }
+                ++it;
             }
-#endif
-            if (!cached) { s.n_isb_miss++; n = sel_ispr(s, start, target, mode == 1, wl); if (n < 0) break; }
+        } else {                                                     // v == dest (:845-858)
+            if (s.out_n == 0) { s.err = true; break; }
+            const int32_t start = s.last_head;
+            const int32_t n = sel_ispr(s, start, v, false, -1);
+            if (n < 0) break;
+            if (n > 0) sel_append_alt(s, n, false);
         }
-        if (n > 0) sel_append_alt(s, n, mode == 1);
-        else if (mode != 3) { sel_push(s, u, v); if (mode == 2) sel_push(s, nu, nv); }
-        if (mode == 2) ++it;
     }
     sel_out_flush(s);
     return s.out_n;
@@ -2853,16 +2706,15 @@ AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // one wave 
 
 AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
     const int64_t gb = w.rec_off[c];
-    s.w = &w; s.c = c; s.b = gb - w.R0; s.N = (int32_t)(w.rec_off[c + 1] - gb); s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
+    s.w = &w; s.c = c; s.b = gb - w.R0; s.N = w.rec_off[c + 1] - gb; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
     s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
     s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
-    s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0; s.n_isb_hit = s.n_isb_miss = 0;
+    s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
 }
 AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
     if (s.lane == 0) {
-        atomic_add(&w.counters[CNT_ISPR_E], (int64_t)s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], (int64_t)s.n_ispr_v);
-        atomic_add(&w.counters[CNT_PATH_E], (int64_t)s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], (int64_t)s.n_out_e);
-        atomic_add(&w.counters[CNT_ISB_HIT], (int64_t)s.n_isb_hit); atomic_add(&w.counters[CNT_ISB_MISS], (int64_t)s.n_isb_miss);
+        atomic_add(&w.counters[CNT_ISPR_E], s.n_ispr_e); atomic_add(&w.counters[CNT_ISPR_V], s.n_ispr_v);
+        atomic_add(&w.counters[CNT_PATH_E], s.n_path_e); atomic_add(&w.counters[CNT_OUT_E], s.n_out_e);
     }
 }
 

@@ -8,8 +8,8 @@ for dup in (0, 3):
     paf = A.Paf.synth(nc, 1000, 21, dup_every=dup, no_cs=True)
     db = A.DeviceBatch(paf)
     for _ in range(2):
-        res = db.solve(max_paths=4, timing=True, keep_debug=True); st = res.stats(); cnt = res.debug('counters', 'int64'); res.close()
+        res = db.solve(max_paths=4, timing=True); st = res.stats(); res.close()
     print(json.dumps({"dup": dup, "select_ms": round(st["phase_ms"]["select"], 3), "final_ms": round(st["phase_ms"]["final"], 3), "converted": st["n_paths_converted"],
                       "ispr_edges": st["ispr_edges"], "ispr_vertices": st["ispr_vertices"], "path_edges": st["path_edges"], "out_elems": st["out_elems"],
-                      "dp_batched": int(cnt[16]), "dp_wave_wide": int(cnt[17]), "V": st["n_vertices"], "E": st["n_edges"], "pairs": st["n_pairs"]}))
+                      "V": st["n_vertices"], "E": st["n_edges"], "pairs": st["n_pairs"]}))
     db.close(); paf.close()
