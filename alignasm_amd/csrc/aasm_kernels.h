@@ -990,11 +990,22 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
     if (gv >= w.VT) return;
     const int64_t c = w.v_ctg[gv], vb = w.voff[c], e_base = w.rowptr[vb];
     const int32_t u = (int32_t)(gv - vb);
-    for (int64_t e = w.rowptr[gv]; e < w.rowptr[gv + 1]; e++) {
-        const int64_t tv = vb + w.e_col[e];
-        const int64_t pos = w.rptr[tv] + atomic_add(&w.rcur[tv], (int32_t)1);
-        w.r_e[pos] = (int32_t)(e - e_base);
-        w.tmp_pk[pos] = pack_in_edge(u, w.e_wq[e], w.e_wr[e], w.e_fl[e]);   // in the order the atomics landed; kb_rev_place / kb_rev_hdr move it to its place in r_pk
+    const int64_t r0 = w.rowptr[gv], r1 = w.rowptr[gv + 1];
+    for (int64_t e0 = r0; e0 < r1; e0 += 4) {                        // four edges per round: heads -> (list start, cursor) -> the two stores
+        int32_t hv[4], wr[4], cur[4];
+        int64_t wq[4], rp[4];
+        uint8_t fl[4];
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) { const bool in = e0 + i < r1; hv[i] = in ? w.e_col[e0 + i] : -1; wq[i] = in ? w.e_wq[e0 + i] : 0; wr[i] = in ? w.e_wr[e0 + i] : 0; fl[i] = in ? w.e_fl[e0 + i] : 0; }
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) { rp[i] = 0; cur[i] = 0; if (hv[i] >= 0) { rp[i] = w.rptr[vb + hv[i]]; cur[i] = atomic_add(&w.rcur[vb + hv[i]], (int32_t)1); } }
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) {
+            if (hv[i] < 0) continue;
+            const int64_t pos = rp[i] + cur[i];
+            w.r_e[pos] = (int32_t)(e0 + i - e_base);
+            w.tmp_pk[pos] = pack_in_edge(u, wq[i], wr[i], fl[i]);    // in the order the atomics landed; kb_rev_place / kb_rev_hdr move it to its place in r_pk
+        }
     }
 }
 
@@ -1378,10 +1389,19 @@ AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread p
     const int32_t u = (int32_t)(gv - vb);
     const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
     int32_t n = 0, prev = -1;
-    for (int64_t t = r0; t < r1; t++) {
-        const int32_t src = w.r_pk[t].x;
-        if (src != prev && w.sp_best[vb + src] == u) w.cval[r0 + n++] = src;
-        prev = src;
+    // (a thread has two or three in-edges and every one is two dependent loads: four edges per round, their loads issued
+    // together - the kernel waits on memory 93 % of its time, not on bandwidth)
+    for (int64_t t = r0; t < r1; t += 4) {
+        int32_t src[4], bst[4];
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) src[i] = (t + i < r1) ? w.r_pk[t + i].x : -1;
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) bst[i] = src[i] >= 0 ? w.sp_best[vb + src[i]] : -1;
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) {
+            if (src[i] >= 0 && src[i] != prev && bst[i] == u) w.cval[r0 + n++] = src[i];
+            if (src[i] >= 0) prev = src[i];
+        }
     }
     w.ccnt[gv] = n;
 }
@@ -1403,13 +1423,21 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     const bool reach = !dist_is_max(du);
     bool seen_p = false, bad = false;
     int32_t n_ins = 0;
-    for (int64_t e = r0; e < r1; e++) {
-        const int32_t v = w.e_col[e];
-        const Dist dv = d[v];
-        if (!dist_is_max(dv)) {
-            Dist cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), du);
-            if (!seen_p && v == bu && dist_eq(cc, dist_zero())) seen_p = true;
-            else { bad |= reach && (cc.qry + cc.ref) < 0; cc.pad = v; w.st_cost[r0 + n_ins] = cc; n_ins++; }
+    for (int64_t e0 = r0; e0 < r1; e0 += 4) {                        // four edges per round: heads, then their distances and weights, together
+        int32_t hv[4], wr[4];
+        int64_t wq[4];
+        uint8_t fl[4];
+        Dist dvv[4];
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) { const bool in = e0 + i < r1; hv[i] = in ? w.e_col[e0 + i] : -1; wq[i] = in ? w.e_wq[e0 + i] : 0; wr[i] = in ? w.e_wr[e0 + i] : 0; fl[i] = in ? w.e_fl[e0 + i] : 0; }
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) dvv[i] = hv[i] >= 0 ? d[hv[i]] : dist_max();
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) {
+            if (hv[i] < 0 || dist_is_max(dvv[i])) continue;
+            Dist cc = dist_sub(dist_add(edge_dist(wq[i], wr[i], fl[i]), dvv[i]), du);
+            if (!seen_p && hv[i] == bu && dist_eq(cc, dist_zero())) seen_p = true;
+            else { bad |= reach && (cc.qry + cc.ref) < 0; cc.pad = hv[i]; w.st_cost[r0 + n_ins] = cc; n_ins++; }
         }
     }
     w.st_n[gv] = n_ins;
@@ -1445,10 +1473,19 @@ AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
         o[0] = j;
         for (int t = 1; t < 4; t++) { j = (j.w >= 0) ? w.tnx[vb + j.w] : neg; o[t] = j; }
     }
-    for (int64_t t = c0; t < c1; t++) {
-        const int32_t ch = w.cval[t];
-        I4 ci; ci.x = ch; ci.y = (int32_t)(w.rowptr[vb + ch] - e_base); ci.z = w.st_n[vb + ch]; ci.w = 0;
-        w.cinfo[t] = ci;
+    for (int64_t t0 = c0; t0 < c1; t0 += 4) {                        // four children per round (their two gathers each issued together)
+        int32_t ch[4], sn[4];
+        int64_t rp[4];
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) ch[i] = (t0 + i < c1) ? w.cval[t0 + i] : -1;
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) { rp[i] = 0; sn[i] = 0; if (ch[i] >= 0) { rp[i] = w.rowptr[vb + ch[i]]; sn[i] = w.st_n[vb + ch[i]]; } }
+        AASM_UNROLL
+        for (int i = 0; i < 4; i++) {
+            if (ch[i] < 0) continue;
+            I4 ci; ci.x = ch[i]; ci.y = (int32_t)(rp[i] - e_base); ci.z = sn[i]; ci.w = 0;
+            w.cinfo[t0 + i] = ci;
+        }
     }
 }
 
