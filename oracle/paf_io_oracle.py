@@ -11,13 +11,15 @@ and (never) by the product.  All citations are into /root/reference/src.
   --alt second-PAF merge ................... alignasm.cpp:186-332
   process_output / process_max_output ...... alignasm.cpp:398-490
 
-PINNING STATUS: "parity unpinned".  paf_data.cpp and alignasm.cpp cannot be compiled in
-this image (ankerl/unordered_dense.h, argparse, csv-parser, indicators and oneTBB are absent,
-no stand-ins are written) and the reference ships no fixtures, so this file is a second,
-independent reading of the source text.  Its value: the product's reader, cs codec, K0 kernel
-and writers (C++/HIP, single-pass scanners) are diffed against a formulation that keeps the
-reference's own structure (operation list -> filter -> reverse -> render), so a misreading
-would have to be made twice, in two different shapes, to go unnoticed.
+PINNING STATUS: the cs codec part (parse_short_cs, get_overlap_range, get_edited_paf_data) is PINNED to the
+reference's own code since round 3: oracle/_ref/libaasm_ref_cs.so is built from the head of paf_data.cpp and
+tests/test_cs_ref.py diffs this file against it live (6 000 tags, 17 000 clips, every exception text) and against the
+recorded vectors tests/golden/ref_cs.json.gz.  The rest - reader framing, --alt merge, writers - stays "parity
+unpinned": alignasm.cpp cannot be compiled in this image (argparse, csv-parser, indicators and oneTBB are absent, no
+stand-ins are written) and the reference ships no fixtures, so that part is a second, independent reading of the source
+text.  Its value: the product's reader and writers (C++, single-pass scanners) are diffed against a formulation that keeps
+the reference's own structure (operation list -> filter -> reverse -> render), so a misreading would have to be made
+twice, in two different shapes, to go unnoticed.
 
 csv-parser behaviour that is assumed, not restated (parity unpinned): rows are
 split on TAB, one row per '\\n'-terminated line, empty lines skipped, fields containing TAB,
