@@ -364,6 +364,19 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
                     if (rh >= uni(q.L->run_end[l])) q.nruns--;
                 }
             }
+            // a tighter bound: a run that still holds K - found - |F| entries behind the new front has, at that place, an entry with
+            // K - found smaller ones in front of it (F's and its own): nothing from there on can be popped any more
+            {
+                int32_t need = K - found - nf;
+                if (need < 1) need = 1;
+                for (int32_t l = q.lmax; l >= 0 && l >= q.lmax - 1; l--) {
+                    const int32_t rh = uni(q.L->run_head[l]), re = uni(q.L->run_end[l]);
+                    if (re - rh < need) continue;
+                    const QE cand = qe_uni(qe_load(eq_slot(q, l, uni(q.L->run_slot[l])), rh + need - 1 - lane, re, lane), 0);   // (lane 0 reads entry rh + need - 1)
+                    if (qe_less_u(cand, q.bound)) q.bound = cand;
+                    break;
+                }
+            }
             f = cnd; f.tag = 0;
             f_slot = lane | 0x200;                                   // 0x200: its own words are still in the candidate record
             ftop = 64 - nf;

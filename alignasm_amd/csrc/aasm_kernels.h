@@ -1218,7 +1218,9 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
             Dist du = dist_max();
             uh0.x = uh0.y = uh0.z = uh0.w = 0; uh1 = uh0; uh2 = uh0;
             if (act) {
-                const I4 rc = (t < 2) ? E->rec[t] : w.r_pk[r0 + t];
+                I4 rc;                                               // (two loads kept apart: as one flat load of a selected address it waited for vmcnt(0) every time)
+                if (t < 2) rc = E->rec[t];
+                else { rc = w.r_pk[r0 + t]; asm volatile("" ::: "memory"); }
                 u = rc.x;
                 Dist wd;
                 wd.qry = (int64_t)(((uint64_t)(uint32_t)rc.z << 32) | (uint32_t)rc.y); wd.ref = rc.w & 0xffffff;
@@ -1769,7 +1771,9 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         for (int32_t t = 0; t < n && !hs.ovf; t++) {
             Dist cc;
             if (t < HEAP_KMAX) cc = S->key[t];
-            else cc = sk[(int64_t)so + t];                           // rows with more sidetracks than a slot holds (dense graphs)
+            else { cc = sk[(int64_t)so + t]; asm volatile("" ::: "memory"); }   // rows with more sidetracks than a slot holds (dense graphs).  The barrier
+                                                                     // keeps the two loads apart: merged into ONE flat load of a selected address, every insert
+                                                                     // waited for vmcnt(0) - i.e. for the next vertex's prefetch issued a moment earlier
             hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
         }
         KPROF_STAMP(3);                                              // inserts
