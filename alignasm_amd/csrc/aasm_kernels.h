@@ -2717,19 +2717,30 @@ AASM_DEV int32_t sel_plan_wave(const KCtx &k, const WS &w, int64_t c, bool fill)
         int64_t ans_up = 0, ans_down = 0;
         int32_t ans_idx = -1;
         Dist ans_d = mind;
-        for (int32_t base = 1; base < found; base += AASM_WAVE) {
-            const int32_t idx = base + k.lane;
-            uint64_t m = wave_ballot(idx < found && kd[idx].anom < mind.anom);
-            while (m) {
-                const int bit = ffs64(m) - 1;
-                m &= m - 1;
-                const int32_t i = base + bit;
-                const Dist dd = kd[i];
-                const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref), down = (int64_t)mind.anom - dd.anom;
-                int32_t kind = -1;
-                if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; ans_d = dd; kind = 2; }
-                else if (dist_sel_equal(dd, ans_d)) kind = 3;
-                if (kind >= 0) { if (fill && k.lane == 0) put(n, i, kind); n++; }
+        for (int32_t base0 = 1; base0 < found; base0 += 4 * AASM_WAVE) {   // four loads of 64 distances in flight per round; the candidates are then taken
+            LaneArr<Dist> dl[4];                                            // from the lanes' registers, not re-read one by one (K = 10 000: thousands of them per contig)
+            AASM_UNROLL
+            for (int j = 0; j < 4; j++) {
+                const int32_t idx = base0 + j * AASM_WAVE + k.lane;
+                Dist x = dist_zero(); x.anom = INT32_MAX;
+                if (idx < found) x = kd[idx];
+                dl[j].at(0) = x;
+            }
+            AASM_UNROLL
+            for (int j = 0; j < 4; j++) {
+                const int32_t base = base0 + j * AASM_WAVE;
+                uint64_t m = wave_ballot(dl[j].at(0).anom < mind.anom);
+                while (m) {
+                    const int bit = ffs64(m) - 1;
+                    m &= m - 1;
+                    const int32_t i = base + bit;
+                    const Dist dd = la_get_dist(dl[j], bit);
+                    const int64_t up = (dd.qry + dd.ref) - (mind.qry + mind.ref), down = (int64_t)mind.anom - dd.anom;
+                    int32_t kind = -1;
+                    if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; ans_d = dd; kind = 2; }
+                    else if (dist_sel_equal(dd, ans_d)) kind = 3;
+                    if (kind >= 0) { if (fill && k.lane == 0) put(n, i, kind); n++; }
+                }
             }
         }
     }
