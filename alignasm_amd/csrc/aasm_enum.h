@@ -64,17 +64,22 @@ struct __attribute__((aligned(8))) I2 { int32_t x, y; };
 #define EQ_BATCH 16                      // entries popped per step at most (3 successors each: 48 lanes)
 #define EQ_IFLUSH 40                     // flush I when it holds more than this (a step of P pops adds <= 3 P entries; P <= (64 - in) / 3)
 #define EQ_MAXLEV 28
-struct EnumLds {
+template <int FMAX> struct EnumLdsT {
     // per F slot, nine quads.  The entry itself: [0] {qry (2 words), anom, qnz}, [1].xy {qtot, prev}.  Its successors (cross heap
     // root, left, right), COMPLETE but for the insertion index: j at [2 + 2j] {sum (2), key2 (2)}, [3 + 2j] {qry (2), heap node | -1, anom},
     // and their {qnz, qtot} pairs at [1].zw, [8].xy, [8].zw
-    I4 slot[64][9];
+    I4 slot[FMAX][9];
     I2 ibuf[EQ_ILEN][3];                 // I: {sum}, {key2}, {index, node}
     int32_t run_slot[EQ_MAXLEV], run_head[EQ_MAXLEV], run_end[EQ_MAXLEV];
     int32_t freel[64];                   // stack of the F slots no entry uses
 };
-#define AASM_ENUM2_LDS_BYTES (64 * 144 + EQ_ILEN * 24 + 3 * EQ_MAXLEV * 4 + 256)
-static_assert(sizeof(EnumLds) <= AASM_ENUM2_LDS_BYTES, "LDS budget");
+// F holds up to FMAX entries: 64 (11.1 KB of LDS per wave: 14 waves per CU), or 40 (7.7 KB: 20 waves per CU, i.e. the 5 per SIMD
+// that keep 5 000 contigs resident at once - a batch of 4 000 took 28 ms against 22.6 ms for 3 500, the residency cliff of the 64 form)
+#define AASM_ENUM2_LDS_BYTES_F(FMAX) ((FMAX) * 144 + EQ_ILEN * 24 + 3 * EQ_MAXLEV * 4 + 256)
+#define AASM_ENUM2_LDS_BYTES AASM_ENUM2_LDS_BYTES_F(64)
+#define EQ_FSMALL 40
+typedef EnumLdsT<64> EnumLds;
+static_assert(sizeof(EnumLdsT<64>) <= AASM_ENUM2_LDS_BYTES_F(64) && sizeof(EnumLdsT<EQ_FSMALL>) <= AASM_ENUM2_LDS_BYTES_F(EQ_FSMALL), "LDS budget");
 
 struct QE { uint64_t sum, key2, nc; int32_t tag; };                  // nc = node << 32 | insertion index; tag: refill only (source level)
 #define QE_INF_SUM 0x7fffffffffffffffull
@@ -170,16 +175,16 @@ AASM_DEV void qe_to_lds(I2 *dst, const QE &e) {
     dst[0] = a; dst[1] = b; dst[2] = c;
 }
 
-struct EnumQ {
-    EnumLds *L;
+template <int FMAX> struct EnumQT {
+    EnumLdsT<FMAX> *L;
     PqK *g;                              // run storage of this contig
     int32_t lmax, k64;
     int32_t in;                          // entries in I
     int32_t nruns;                       // non-empty levels
     QE bound;                            // nothing >= bound can still be popped (+inf: no bound yet)
 };
-AASM_DEV int32_t eq_cap(const EnumQ &q, int32_t l) { const int64_t c = (int64_t)64 << l; return l < q.lmax && c < q.k64 ? (int32_t)c : q.k64; }
-AASM_DEV PqK *eq_slot(const EnumQ &q, int32_t l, int32_t s) {
+template <class Q> AASM_DEV int32_t eq_cap(const Q &q, int32_t l) { const int64_t c = (int64_t)64 << l; return l < q.lmax && c < q.k64 ? (int32_t)c : q.k64; }
+template <class Q> AASM_DEV PqK *eq_slot(const Q &q, int32_t l, int32_t s) {
     const int32_t lb = l < q.lmax ? l : q.lmax;
     return q.g + 128 * (((int64_t)1 << lb) - 1) + (int64_t)s * eq_cap(q, l);
 }
@@ -218,7 +223,7 @@ AASM_DEV QE eq_merge(const PqK *A, int32_t a_len, const PqK *B, int32_t b_len, P
 
 // I -> a sorted block, merged down the levels of the LSM tree (one run per level at rest; level l < lmax has two
 // slots of 64 << l entries, the top level three of k64: the output of a merge goes to a slot none of its inputs uses)
-AASM_DEV void eq_flush(EnumQ &q, int32_t keep, int lane) {
+template <class Q> AASM_DEV void eq_flush(Q &q, int32_t keep, int lane) {
     QE s = qe_inf();
     if (lane < q.in) {
         const I2 a = q.L->ibuf[lane][0], b = q.L->ibuf[lane][1], c = q.L->ibuf[lane][2];
@@ -261,7 +266,7 @@ AASM_DEV void eq_flush(EnumQ &q, int32_t keep, int lane) {
     wave_lds_sync();
 }
 
-AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave per contig
+template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     const int lane = k.lane;
@@ -275,8 +280,8 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     const HNode *nodes = w.hnodes + w.hoff[c];
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
-    EnumQ q;
-    q.L = (EnumLds *)k.lds; q.g = w.pq + c * w.pq_stride; q.lmax = enum_lmax(K); q.k64 = (int32_t)enum_k64(K); q.in = 0; q.nruns = 0; q.bound = qe_inf();
+    EnumQT<FMAX> q;
+    q.L = (EnumLdsT<FMAX> *)k.lds; q.g = w.pq + c * w.pq_stride; q.lmax = enum_lmax(K); q.k64 = (int32_t)enum_k64(K); q.in = 0; q.nruns = 0; q.bound = qe_inf();
     if (lane < EQ_MAXLEV) { q.L->run_slot[lane] = 0; q.L->run_head[lane] = 0; q.L->run_end[lane] = 0; }
     wave_lds_sync();
 
@@ -290,17 +295,17 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
     QE f = qe_inf();
     int32_t f_slot = 0;
     int32_t hd = 0, nf = 0;
-    int32_t ftop = 64;                                               // free slots: q.L->freel[0 .. ftop)
-    q.L->freel[lane] = 63 - lane;
+    int32_t ftop = FMAX;                                             // free slots: q.L->freel[0 .. ftop)
+    if (lane < FMAX) q.L->freel[lane] = FMAX - 1 - lane;
     QE maxF = qe_inf();
 
     // x (wave-uniform; own = its {qry, anom, qnz}, {qtot, prev} words) into F; the caller has decided that it belongs there
     auto f_insert = [&](const QE &x, const I4 &own0, const I4 &own1) {
         const int32_t below = popc64(wave_ballot(lane >= hd && lane < nf && qe_less(f, x)));
         const int32_t pos = hd + below;
-        if (nf == 64 && hd == 0) {                                   // full: the largest entry leaves for I
-            if (lane == 63) { qe_to_lds(q.L->ibuf[q.in], f); q.L->freel[ftop] = f_slot & 63; }
-            ftop++; q.in++; nf = 63;
+        if (nf - hd == FMAX) {                                       // full: the largest entry leaves for I
+            if (lane == nf - 1) { qe_to_lds(q.L->ibuf[q.in], f); q.L->freel[ftop] = f_slot & 63; }
+            ftop++; q.in++; nf--;
         }
         const int32_t sl = uni(q.L->freel[--ftop]);
         bool mv; int32_t at;
@@ -354,8 +359,9 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
                 blk.tag = l;
                 qe_merge(cnd, blk, lane, false);
             }
-            const uint64_t fin = wave_ballot(cnd.sum != QE_INF_SUM);
+            const uint64_t fin = wave_ballot(cnd.sum != QE_INF_SUM && lane < FMAX);
             nf = popc64(fin); hd = 0;
+            if (FMAX < 64 && lane >= FMAX) cnd = qe_inf();          // (the entries behind the front's capacity stay in their runs)
             for (int32_t l = 0; l <= q.lmax; l++) {
                 const int32_t took = popc64(wave_ballot(cnd.sum != QE_INF_SUM && cnd.tag == l));
                 if (took) {
@@ -379,8 +385,8 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
             }
             f = cnd; f.tag = 0;
             f_slot = lane | 0x200;                                   // 0x200: its own words are still in the candidate record
-            ftop = 64 - nf;
-            if (lane < ftop) q.L->freel[lane] = 63 - lane;           // slots nf .. 63
+            ftop = FMAX - nf;
+            if (lane < ftop) q.L->freel[lane] = FMAX - 1 - lane;     // slots nf .. FMAX - 1
             wave_lds_sync();
             maxF = qe_uni(f, nf - 1);
             wave_fence();                                            // candidate records written by lanes of this wave
@@ -496,7 +502,7 @@ AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {             // one wave 
             const int j = ffs64(m) - 1;
             const QE xj = qe_uni(x, j);
             const bool fits = hd < nf ? qe_less_u(xj, maxF) : false;
-            if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < 64)) {
+            if (fits || (q.in == 0 && q.nruns == 0 && (nf - hd) < FMAX)) {
                 I4 o0, o1;
                 o0.x = __builtin_amdgcn_readlane(x0.x, j); o0.y = __builtin_amdgcn_readlane(x0.y, j); o0.z = __builtin_amdgcn_readlane(x0.z, j); o0.w = __builtin_amdgcn_readlane(x0.w, j);
                 o1.x = __builtin_amdgcn_readlane(x1.x, j); o1.y = __builtin_amdgcn_readlane(x1.y, j); o1.z = 0; o1.w = 0;

@@ -23,7 +23,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -57,9 +57,10 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_HEAP: kb_heap(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
 #if defined(AASM_HOST_EMUL)
-        case KN_ENUM: case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
+        case KN_ENUM: case KN_ENUM_S: case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
 #else
-        case KN_ENUM: kb_enum_lsm(k, w); break;
+        case KN_ENUM: kb_enum_lsm<64>(k, w); break;
+        case KN_ENUM_S: kb_enum_lsm<EQ_FSMALL>(k, w); break;
         case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
 #endif
         case KN_SELECT: kb_select(k, w); break;
@@ -281,7 +282,10 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(kcand, I4, 2 * C * (3 * K + 1), "kcand"); A(pq, PqK, C * w.pq_stride, "pq");
         CHECK_ALLOC();
         be.phase_begin(AASM_PH_ENUM);
-        be.launch(enum_heap ? KN_ENUM_HEAP : KN_ENUM, C, AASM_WAVE, w);
+        // a few more contigs than the 64-entry front keeps resident (14 waves per CU = 3 584): the 40-entry front (18 per CU = 4 608) runs them
+        // in one residency round (4 000 contigs: 28.0 -> 25.7 ms); beyond that its extra refills and flushes cost more than the second round
+        // of the big front (5 000 contigs: 31.5 vs 30.2 ms)
+        be.launch(enum_heap ? KN_ENUM_HEAP : ((C > 14 * 256 && C <= 18 * 256 && K > 21) || (opts.reserved[0] & 16)) ? KN_ENUM_S : KN_ENUM, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_ENUM);
     }
 

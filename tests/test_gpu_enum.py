@@ -26,8 +26,8 @@ def test_enumeration_queue_forms_agree_with_each_other_and_the_oracle(T, case):
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup)
     db = api.DeviceBatch(hb)
     got = {}
-    for form in ("runs", "heap"):
-        res = db.solve(max_paths=K, keep_debug=True, enum_heap=(form == "heap"))
+    for form in ("runs", "runs40", "heap"):                          # 64-entry front, the 40-entry front of big batches, the d-ary heap
+        res = db.solve(max_paths=K, keep_debug=True, enum_heap=(form == "heap"), enum_small=(form == "runs40"))
         kf = res.debug("kfound", np.int32)[:nc].copy()
         kd = res.debug("kd", T.DIST_DT)[:nc * K].copy()
         klast = res.debug("klast", np.int32)[:nc * K].copy()
@@ -39,17 +39,18 @@ def test_enumeration_queue_forms_agree_with_each_other_and_the_oracle(T, case):
             assert T.diff_intermediates(hb, res.debug, K) == []      # kfound + every popped distance vs the oracle
         res.close()
     db.close()
-    a, b = got["runs"], got["heap"]
-    assert np.array_equal(a[0], b[0])
-    for c in range(nc):
-        n = int(a[0][c])
-        assert n >= 1
-        for f in ("qry", "ref", "anom", "qnz", "qtot"):
-            assert np.array_equal(a[1][f][c * K:c * K + n], b[1][f][c * K:c * K + n]), (c, f)
-        assert np.array_equal(a[2][c * K:c * K + n], b[2][c * K:c * K + n]), c
-        S = 3 * K + 1
-        pushed = int(a[2][c * K:c * K + n].max()) + 1                # every push up to the last popped one was numbered alike
-        assert np.array_equal(a[3][c * S:c * S + pushed], b[3][c * S:c * S + pushed]), c
-        assert np.array_equal(a[4][c * S:c * S + pushed], b[4][c * S:c * S + pushed]), c
-    assert T.diff_outputs(a[5], b[5]) == []
-    assert T.diff_outputs(T.oracle_solve(hb, K), a[5]) == []
+    for other in ("heap", "runs40"):
+        a, b = got["runs"], got[other]
+        assert np.array_equal(a[0], b[0]), other
+        for c in range(nc):
+            n = int(a[0][c])
+            assert n >= 1
+            for f in ("qry", "ref", "anom", "qnz", "qtot"):
+                assert np.array_equal(a[1][f][c * K:c * K + n], b[1][f][c * K:c * K + n]), (other, c, f)
+            assert np.array_equal(a[2][c * K:c * K + n], b[2][c * K:c * K + n]), (other, c)
+            S = 3 * K + 1
+            pushed = int(a[2][c * K:c * K + n].max()) + 1            # every push up to the last popped one was numbered alike
+            assert np.array_equal(a[3][c * S:c * S + pushed], b[3][c * S:c * S + pushed]), (other, c)
+            assert np.array_equal(a[4][c * S:c * S + pushed], b[4][c * S:c * S + pushed]), (other, c)
+        assert T.diff_outputs(a[5], b[5]) == [], other
+    assert T.diff_outputs(T.oracle_solve(hb, K), got["runs"][5]) == []
