@@ -54,3 +54,28 @@ def test_enumeration_queue_forms_agree_with_each_other_and_the_oracle(T, case):
             assert np.array_equal(a[4][c * S:c * S + pushed], b[4][c * S:c * S + pushed]), (other, c)
         assert T.diff_outputs(a[5], b[5]) == [], other
     assert T.diff_outputs(T.oracle_solve(hb, K), got["runs"][5]) == []
+
+
+def test_queue_forms_agree_on_mixed_batches_and_many_k(T):
+    """Heavy-tailed, dense and duplicate-heavy contigs at K around the front's capacity (22, 65, 130) and above: the two front
+    capacities of the sorted-runs queue against the d-ary heap form (tools/k8_stress.py runs the long version)."""
+    api = T.api()
+    n_checked = 0
+    for seed, nc, nr, dense, dup, heavy in ((1, 40, 300, False, 0, True), (3, 16, 220, True, 0, False), (4, 30, 120, True, 2, True)):
+        hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, heavy_tail=heavy)
+        db = api.DeviceBatch(hb)
+        for K in (22, 65, 130, 2500):
+            got = {}
+            for form in ("heap", "runs", "runs40"):
+                res = db.solve(max_paths=K, keep_debug=True, enum_heap=(form == "heap"), enum_small=(form == "runs40"))
+                got[form] = (res.debug("kfound", np.int32)[:nc].copy(), res.debug("kd", T.DIST_DT)[:nc * K].copy(), res.debug("klast", np.int32)[:nc * K].copy())
+                res.close()
+            for other in ("runs", "runs40"):
+                a, b = got["heap"], got[other]
+                assert np.array_equal(a[0], b[0]), (seed, K, other)
+                for c in range(nc):
+                    n = int(a[0][c])
+                    assert np.array_equal(a[1][c * K:c * K + n], b[1][c * K:c * K + n]) and np.array_equal(a[2][c * K:c * K + n], b[2][c * K:c * K + n]), (seed, K, other, c)
+                    n_checked += 1
+        db.close()
+    assert n_checked == 2 * 4 * (40 + 16 + 30)
