@@ -905,7 +905,6 @@ struct aasm_writer {
     int fd[3] = {-1, -1, -1};
     int64_t off[3] = {0, 0, 0};
     int64_t next_contig = 0;
-    const aasm_paf *last_paf = nullptr;    // ranges of one aasm_paf arrive in order; a caller that reads its file in parts appends one aasm_paf after the other
     bool failed = false;
 };
 
@@ -949,9 +948,7 @@ int aasm_writer_close(aasm_writer *w, int commit) {
 
 // rows of contigs [contig0, contig0 + out->n_contigs) of `paf`; ranges must arrive in order, without gaps
 int aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out *out, int64_t contig0) {
-    if (!w || !paf || !out) return AASM_E_INVAL;
-    if (paf != w->last_paf) { w->last_paf = paf; w->next_contig = 0; }
-    if (contig0 != w->next_contig || contig0 + out->n_contigs > paf->n_contigs()) return AASM_E_INVAL;
+    if (!w || !paf || !out || contig0 != w->next_contig || contig0 + out->n_contigs > paf->n_contigs()) return AASM_E_INVAL;
     if (!paf->has_cs) { set_last_error("PAF was generated without cs strings"); return AASM_E_INVAL; }
     if (w->failed) return AASM_E_IO;
     const int64_t C = out->n_contigs;

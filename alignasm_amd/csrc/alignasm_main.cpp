@@ -22,164 +22,6 @@
 
 #include "../../include/alignasm_amd.h"
 
-
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <deque>
-
-namespace {
-using clk = std::chrono::steady_clock;
-double secs_between(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
-
-// first byte of the first line at or behind `from` whose query name (column 1) differs from the line before it
-int64_t next_contig_start(const char *text, int64_t len, int64_t from) {
-    if (from <= 0) return 0;
-    if (from >= len) return len;
-    const char *nl = (const char *)std::memchr(text + from - 1, '\n', (size_t)(len - from + 1));
-    if (!nl) return len;
-    int64_t cur = (nl - text) + 1;                                   // a line start
-    // name of the line before `cur`
-    int64_t prev = cur - 1;                                          // its '\n'
-    int64_t ps = prev;
-    while (ps > 0 && text[ps - 1] != '\n') ps--;
-    auto name_of = [&](int64_t ls, int64_t &nlen) { const char *t = (const char *)std::memchr(text + ls, '\t', (size_t)(len - ls)); nlen = t ? (t - (text + ls)) : 0; return text + ls; };
-    int64_t pl = 0;
-    const char *pn = name_of(ps, pl);
-    while (cur < len) {
-        int64_t cl = 0;
-        const char *cn = name_of(cur, cl);
-        if (cl != pl || std::memcmp(cn, pn, (size_t)cl) != 0) return cur;
-        const char *e = (const char *)std::memchr(text + cur, '\n', (size_t)(len - cur));
-        if (!e) return len;
-        cur = (e - text) + 1;
-    }
-    return len;
-}
-
-struct Part { aasm_paf *paf = nullptr; aasm_batch_in view; aasm_batch_out out; int64_t row0 = 0; int rc = AASM_OK; std::string err; };
-
-// returns the process exit code, or -1000 when the file cannot be streamed (caller falls back to the one-piece path)
-int stream_file(const std::filesystem::path &ap, const aasm_opts &opts, bool host_ranges, bool timing, clk::time_point t0) {
-    const int fd = ::open(ap.c_str(), O_RDONLY);
-    if (fd < 0) return -1000;
-    struct stat st;
-    if (::fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return -1000; }
-    const int64_t len = (int64_t)st.st_size;
-    void *m = ::mmap(nullptr, (size_t)len, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (m == MAP_FAILED) return -1000;
-    ::madvise(m, (size_t)len, MADV_WILLNEED);
-    const char *text = (const char *)m;
-    // ---- cuts: ~8 parts of equal bytes, the first two half as long (the GPU and the writer start earlier), each ending at a contig boundary
-    std::vector<int64_t> cut{0};
-    {
-        const int n_parts = 8;
-        std::vector<double> frac{0.0625, 0.125};
-        for (int k = 2; k < n_parts + 1; k++) frac.push_back(0.125 + (1.0 - 0.125) * (k - 1) / (n_parts - 1));
-        for (double f : frac) {
-            const int64_t c = next_contig_start(text, len, (int64_t)(f * (double)len));
-            if (c > cut.back() && c < len) cut.push_back(c);
-        }
-        cut.push_back(len);
-    }
-    const int n = (int)cut.size() - 1;
-    std::vector<Part> parts((size_t)n);
-    std::mutex mu;
-    std::condition_variable cv;
-    int parsed = 0, solved = 0;
-    bool stop = false;
-    double read_busy = 0, solve_busy = 0, write_busy = 0, upload_s = 0, device_s = 0, fetch_s = 0;
-    int64_t n_records = 0, n_contigs = 0, n_internal = 0;
-    std::thread reader([&] {
-        int64_t rows = 0;
-        for (int k = 0; k < n; k++) {
-            { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
-            const auto a0 = clk::now();
-            Part &P = parts[(size_t)k];
-            P.row0 = rows;
-            P.rc = aasm_paf_parse_mem_opts(text + cut[k], cut[k + 1] - cut[k], host_ranges ? 0 : AASM_READ_DEVICE_RANGES, &P.paf);
-            if (P.rc != AASM_OK) P.err = aasm_last_error();
-            else { aasm_paf_batch(P.paf, &P.view); rows += P.view.n_records; }
-            read_busy += secs_between(a0, clk::now());
-            { std::lock_guard<std::mutex> lk(mu); parsed = k + 1; }
-            cv.notify_all();
-            if (P.rc != AASM_OK) break;
-        }
-    });
-    std::thread solver([&] {
-        for (int k = 0; k < n; k++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return parsed > k || stop; }); if (stop) break; }
-            Part &P = parts[(size_t)k];
-            if (P.rc == AASM_OK) {
-                const auto a0 = clk::now();
-                std::memset(&P.out, 0, sizeof(P.out));
-                P.rc = aasm_solve_batch(&P.view, &opts, &P.out);
-                if (P.rc != AASM_OK) P.err = aasm_last_error();
-                else { upload_s += P.out.stats.reserved_f[0] / 1e3; device_s += P.out.stats.reserved_f[2] / 1e3; fetch_s += P.out.stats.reserved_f[1] / 1e3; n_internal += P.out.stats.n_internal_errors; }
-                solve_busy += secs_between(a0, clk::now());
-            }
-            { std::lock_guard<std::mutex> lk(mu); solved = k + 1; }
-            cv.notify_all();
-            if (P.rc != AASM_OK) break;
-        }
-    });
-    auto f_main = ap; f_main.replace_extension(".aln.paf");
-    auto f_alt = ap; f_alt.replace_extension(".aln.alt.paf");
-    auto f_all = ap; f_all.replace_extension(".aln.all.paf");
-    aasm_writer *wr = nullptr;
-    int rc = aasm_writer_open(f_main.c_str(), f_alt.c_str(), f_all.c_str(), &wr);
-    int exit_code = 0;
-    std::string fail;
-    bool said_read = false;
-    clk::time_point t_first = t0;
-    if (rc != AASM_OK) { fail = std::string("alignasm: writing outputs failed: ") + aasm_last_error(); exit_code = 3; }
-    for (int k = 0; k < n && exit_code == 0; k++) {
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return solved > k; }); }
-        Part &P = parts[(size_t)k];
-        if (P.rc != AASM_OK) {
-            // reader errors (missing cs:Z tag, malformed row) and a malformed cs tag met on the GPU: the reference's exit code 1;
-            // "(record N)" counts inside the part: make it a row of the file
-            std::string msg = P.err;
-            const size_t at = msg.rfind("(record ");
-            if (at != std::string::npos && P.paf) { const long long r = std::atoll(msg.c_str() + at + 8); msg = msg.substr(0, at) + "(record " + std::to_string(r + P.row0) + ")"; }
-            const bool user_err = P.rc == AASM_E_PARSE || !P.paf;
-            fail = user_err ? msg : "alignasm: solver failed (" + std::to_string(P.rc) + "): " + msg;
-            exit_code = user_err ? 1 : 2;
-            break;
-        }
-        if (k == 0) {
-            t_first = clk::now();
-            std::cout << "File read complete" << std::endl;          // (:340; the rest of the file is still being read)
-            said_read = true;
-            std::cout << "Analyze PAF data in parallel" << std::endl;
-            std::cout << "Write output PAF file" << std::endl;       // :487
-        }
-        n_records += P.view.n_records; n_contigs += P.view.n_contigs;
-        const auto a0 = clk::now();
-        rc = aasm_writer_append(wr, P.paf, &P.out, 0);
-        write_busy += secs_between(a0, clk::now());
-        if (rc != AASM_OK) { fail = std::string("alignasm: writing outputs failed: ") + aasm_last_error(); exit_code = 3; break; }
-        aasm_free_out(&P.out);
-        aasm_paf_free(P.paf); P.paf = nullptr;
-    }
-    (void)said_read;
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
-    cv.notify_all();
-    reader.join(); solver.join();
-    if (wr) { const int crc = aasm_writer_close(wr, exit_code == 0 ? 1 : 0); if (exit_code == 0 && crc != AASM_OK) { fail = std::string("alignasm: writing outputs failed: ") + aasm_last_error(); exit_code = 3; } }
-    if (!fail.empty()) std::cerr << fail << "\n";
-    if (exit_code == 0 && n_internal) std::cerr << "alignasm: " << n_internal << " contig(s) hit an internal error state\n";
-    const auto t3 = clk::now();
-    if (timing)
-        std::cerr << "alignasm timing: records " << n_records << " contigs " << n_contigs << " parts " << n << " read_s " << read_busy << " solve_s " << solve_busy
-                  << " (upload " << upload_s << " device " << device_s << " fetch " << fetch_s << ") write_s " << write_busy
-                  << " overlap_s " << (read_busy + solve_busy + write_busy - secs_between(t0, t3)) << " first_part_s " << secs_between(t0, t_first) << " total_s " << secs_between(t0, t3) << "\n";
-    return exit_code;
-}
-}  // namespace
-
 static void usage(std::ostream &os) {
     os << "Usage: alignasm [--help] [--version] [--thread THREAD] [--alt PAF_ALT_LOC] [--alt_baseline ALT_BASELINE] "
           "[--non_skip_linkable] [--max-paths K] [--gpus N] [--device D] [--timing] [--host-ranges] PAF_LOC\n\n"
@@ -256,21 +98,6 @@ int main(int argc, char **argv) {
         if (use_alt) { const auto s2 = std::filesystem::file_size(alt_loc, ec); if (!ec) text += (double)s2; }
         const int64_t per_gpu = (int64_t)(text * 3.7 / (gpus > 0 ? gpus : 1)) + ((int64_t)256 << 20);
         for (int g = 0; g < (gpus > 0 ? gpus : 1); g++) warm.emplace_back([=] { (void)aasm_reserve_workspace(opts.device + g, per_gpu); });
-    }
-    // ---- one GPU, no --alt, a big file: three stages side by side.  The file is mapped and cut into parts at contig
-    //      boundaries (a part ends where the query name changes); part k + 2 is being parsed while part k + 1 is on the
-    //      GPU and the rows of part k are formatted and written.  Every part is an aasm_paf of its own (contigs are
-    //      independent; reference names are printed, not numbered), the three outputs are appended to in file order.
-    {
-        std::error_code ec;
-        const auto fsz = std::filesystem::file_size(p, ec);
-        const char *env_min = std::getenv("AASM_STREAM_MIN_BYTES");
-        const uint64_t min_bytes = env_min ? std::strtoull(env_min, nullptr, 10) : ((uint64_t)256 << 20);
-        if (!ec && gpus <= 1 && !use_alt && fsz >= min_bytes) {
-            const int rcs = stream_file(std::filesystem::absolute(p), opts, host_ranges, timing, t0);
-            if (rcs != -1000) { std::cout.flush(); std::cerr.flush(); for (auto &th : warm) if (th.joinable()) th.join(); std::_Exit(rcs); }
-            // (-1000: could not map / cut the file: the one-piece path below reads it)
-        }
     }
     aasm_paf *paf = nullptr;
     // the reader only indexes the rows; the cs tags are turned into match ranges on the GPU

@@ -267,8 +267,7 @@ int64_t aasm_paf_n_contigs(const aasm_paf *paf);
 int  aasm_paf_write_outputs(const aasm_paf *paf, const aasm_batch_out *out,
                             const char *main_path, const char *alt_path, const char *all_path);
 /* The same in pieces: the three files are opened once (under temporary names), receive the rows of consecutive contig
- * ranges in order (out = the result of contigs [contig0, contig0 + out->n_contigs) of `paf`; a file read in parts is appended one
- * aasm_paf after the other, each from its contig 0), and take their final names at
+ * ranges in order (out = the result of contigs [contig0, contig0 + out->n_contigs)), and take their final names at
  * aasm_writer_close(w, 1); close(w, 0), or any failed append, removes them.                                        */
 typedef struct aasm_writer aasm_writer;
 int  aasm_writer_open(const char *main_path, const char *alt_path, const char *all_path, aasm_writer **w);
