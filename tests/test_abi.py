@@ -52,3 +52,39 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "libaasm_emul" not in txt and "oracle_solve" not in txt, (dirpath, f)
+
+
+def test_range_solve_and_writer_session_reject_misuse(T, tmp_path):
+    """Argument checks of the entry points a streaming caller uses (no device needed to fail them): contig ranges outside the
+    batch, writer ranges out of order or beyond the file; a closed-without-commit session leaves nothing on disk."""
+    import ctypes as C
+    from alignasm_amd._abi import BatchOut, Opts
+    api = T.api()
+    paf = api.Paf.synth(5, 20, 3)
+    view = paf.view()
+    out = BatchOut()
+    for c0, c1 in ((-1, 2), (3, 3), (4, 2), (0, 6)):
+        assert api.LIB.aasm_solve_batch_range(C.byref(view), C.c_int64(c0), C.c_int64(c1), C.byref(Opts(4, 0, 0, 0, 0)), C.byref(out)) == -1   # AASM_E_INVAL
+    if api.device_count() == 0:                                     # a valid range without a device: the loud failure, no fallback
+        assert api.LIB.aasm_solve_batch_range(C.byref(view), C.c_int64(0), C.c_int64(5), C.byref(Opts(4, 0, 0, 0, 0)), C.byref(out)) == -2
+    sol = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(view), C.byref(Opts(4, 0, 0, 0, 0)), 1, C.byref(sol)) == 0
+    w = C.c_void_p()
+    names = [str(tmp_path / n).encode() for n in ("m.paf", "a.paf", "l.paf")]
+    assert api.LIB.aasm_writer_open(names[0], names[1], names[2], C.byref(w)) == 0
+    assert api.LIB.aasm_writer_append(w, paf._h, C.byref(sol), C.c_int64(1)) == -1        # must start at contig 0
+    assert api.LIB.aasm_writer_append(w, paf._h, C.byref(sol), C.c_int64(0)) == 0
+    assert api.LIB.aasm_writer_append(w, paf._h, C.byref(sol), C.c_int64(0)) == -1        # that range is already written
+    assert api.LIB.aasm_writer_append(w, paf._h, C.byref(sol), C.c_int64(5)) == -1        # beyond the file
+    assert api.LIB.aasm_writer_close(w, 0) == 0                                           # abandon: nothing stays
+    assert list(tmp_path.iterdir()) == []
+    w = C.c_void_p()
+    assert api.LIB.aasm_writer_open(names[0], names[1], names[2], C.byref(w)) == 0
+    assert api.LIB.aasm_writer_append(w, paf._h, C.byref(sol), C.c_int64(0)) == 0
+    assert api.LIB.aasm_writer_close(w, 1) == 0
+    one_piece = [str(tmp_path / n) for n in ("m1.paf", "a1.paf", "l1.paf")]
+    paf.write_outputs(sol, *one_piece)
+    for a, b in zip(names, one_piece):
+        assert open(a, "rb").read() == open(b, "rb").read()
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["a.paf", "a1.paf", "l.paf", "l1.paf", "m.paf", "m1.paf"]
+    T.oracle().oracle_free_out(C.byref(sol))
