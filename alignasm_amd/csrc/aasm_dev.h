@@ -43,11 +43,13 @@ AASM_DEV uint64_t wave_ballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> AASM_DEV T wave_bcast(T x, int) { return x; }
 template <class T> AASM_DEV T wave_shfl_up(T x, int, T fill) { (void)x; return fill; }
 template <class T> AASM_DEV T wave_shfl_xor(T x, int) { return x; }
+template <class T> AASM_DEV T wave_shfl_idx(T x, int) { return x; }
 AASM_DEV void wave_lds_sync() {}
 AASM_DEV void block_barrier() {}
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return *p; }
 AASM_DEV void wave_sleep() {}
 AASM_DEV int64_t wave_realtime() { return 0; }
+template <class T> AASM_DEV void keep_load(T &) {}
 AASM_DEV void store_drain() {}
 AASM_DEV void wave_fence() {}
 template <class T> AASM_DEV T atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
@@ -71,6 +73,10 @@ AASM_DEV int64_t wave_shfl_up(int64_t x, int d, int64_t fill) {
     int64_t y = ((int64_t)hi << 32) | (uint32_t)lo;
     return ((int)(threadIdx.x & 63) >= d) ? y : fill;
 }
+AASM_DEV int64_t wave_shfl_idx(int64_t x, int src) {                // src may differ from lane to lane
+    const int lo = __shfl((int)(uint32_t)(uint64_t)x, src, 64), hi = __shfl((int)((uint64_t)x >> 32), src, 64);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
 AASM_DEV int wave_shfl_xor(int x, int m) { return __shfl_xor(x, m, 64); }
 AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
     int lo = __shfl_xor((int)(x & 0xffffffffll), m, 64), hi = __shfl_xor((int)(x >> 32), m, 64);
@@ -86,6 +92,8 @@ AASM_DEV void block_barrier() { __syncthreads(); }
 // a word another wave of the SAME workgroup may have just stored (global memory): workgroup-scope load
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 AASM_DEV void wave_sleep() { __builtin_amdgcn_s_sleep(2); }
+// a loaded value is wanted HERE, in a register: keeps the compiler from sinking the load into a later branch (a second round trip)
+template <class T> AASM_DEV void keep_load(T &x) { asm volatile("" : "+v"(x)); }
 AASM_DEV int64_t wave_realtime() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }   // constant 100 MHz counter
 // every store of this wave has reached the cache its workgroup shares (before it tells another wave about them)
 AASM_DEV void store_drain() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }

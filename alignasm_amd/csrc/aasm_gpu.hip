@@ -690,6 +690,59 @@ int aasm_debug_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t
     return AASM_OK;
 }
 
+// Test entry (hazard B1): K1's std::sort replay alone, on arbitrary keys.  rec_off[n_contigs + 1] from 0; perm_out[r] per
+// record = the input index (relative to its contig) that std::sort leaves at sorted position r.  depth_test as aasm_opts.reserved[2] bits 8-15.
+int aasm_debug_sort_replay(const int64_t *rec_off, int64_t n_contigs, const int64_t *qs, const int64_t *qe, int32_t *perm_out, int depth_test, int device) {
+    if (!rec_off || !qs || !qe || !perm_out || n_contigs <= 0 || rec_off[0] != 0) return AASM_E_INVAL;
+    for (int64_t c = 0; c < n_contigs; c++) if (rec_off[c + 1] < rec_off[c]) return AASM_E_INVAL;
+    const int64_t R = rec_off[n_contigs];
+    if (R <= 0 || R > INT32_MAX) return AASM_E_INVAL;
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    hipSetDevice(device);
+    std::vector<void *> dev;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *p, size_t bytes, int fill) -> void * {
+        void *q = nullptr;
+        if (e != hipSuccess) return nullptr;
+        if ((e = hipMalloc(&q, bytes ? bytes : 8)) != hipSuccess) return nullptr;
+        dev.push_back(q);
+        if (p) e = hipMemcpy(q, p, bytes, hipMemcpyHostToDevice);
+        else e = hipMemset(q, fill, bytes);
+        return q;
+    };
+    WS w;
+    std::memset(&w, 0, sizeof(w));
+    w.C = n_contigs; w.R = R; w.R0 = 0; w.sort_depth_test = depth_test;
+    w.rec_off = (const int64_t *)up(rec_off, (size_t)(n_contigs + 1) * 8, 0);
+    w.in_qs = (const int64_t *)up(qs, (size_t)R * 8, 0); w.in_qe = (const int64_t *)up(qe, (size_t)R * 8, 0);
+    w.s_qs = (int64_t *)up(nullptr, (size_t)R * 8, 0); w.s_qe = (int64_t *)up(nullptr, (size_t)R * 8, 0); w.s_orig = (int32_t *)up(nullptr, (size_t)R * 4, 0);
+    w.perm = (int32_t *)up(nullptr, (size_t)R * 4, 0xff);
+    std::vector<int32_t> ones((size_t)n_contigs, 1);
+    w.dupflag = (int32_t *)up(ones.data(), (size_t)n_contigs * 4, 0);
+#if defined(AASM_KPROF)
+    w.prof_heap = (int64_t *)up(nullptr, (size_t)n_contigs * 64, 0);
+#endif
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(aasm_k1_sort_fix, dim3((unsigned)n_contigs), dim3(64), 0, g_ctx[device].stream, w);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
+    if (e == hipSuccess) e = hipMemcpy(perm_out, w.perm, (size_t)R * 4, hipMemcpyDeviceToHost);
+#if defined(AASM_KPROF)
+    if (e == hipSuccess) {                                           // diagnostic build: mean cycles per section over the contigs
+        std::vector<int64_t> kp((size_t)n_contigs * 8);
+        hipMemcpy(kp.data(), w.prof_heap, kp.size() * 8, hipMemcpyDeviceToHost);
+        double m[8] = {0};
+        for (int64_t c = 0; c < n_contigs; c++) for (int i = 0; i < 8; i++) m[i] += (double)kp[(size_t)c * 8 + i] / (double)n_contigs;
+        fprintf(stderr, "sort_fix sections (mean cycles): load %.0f  A %.0f  B %.0f  C %.0f  global partitions %.0f  wave lifetime %.1f us\n", m[0], m[1], m[2], m[3], m[4], m[7] / 100.0);
+    }
+#endif
+    for (void *q : dev) hipFree(q);
+    if (e != hipSuccess) { set_last_error(hip_err("aasm_debug_sort_replay", e)); return AASM_E_HIP; }
+    return AASM_OK;
+}
+
 // dijkstra (k_shortest_walks.hpp:69-87) over a batch of graphs; host pointers in and out
 int aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int64_t *w5,
                        const int32_t *src, int64_t *d5, int32_t *prev, int device) {

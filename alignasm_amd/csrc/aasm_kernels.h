@@ -27,6 +27,7 @@ struct WS {
     int64_t C, R, R0, S, VT, ET;
     int32_t K, nsl;
     int32_t avg_sidetracks;              // mean #sidetracks per contig of the batch (K7's wave priority)
+    int32_t sort_depth_test;             // 0; tests: kb_sort_fix starts its introsort with (this - 1) partition levels instead of 2 lg N
     // ---- input batch (device), original record order; rec_off already points at the chunk
     const int64_t *rec_off, *in_qs, *in_qe, *in_rs, *in_re, *in_qt, *in_rng_off, *rql, *rqr, *rrl;
     const int32_t *in_chr;
@@ -334,18 +335,52 @@ struct SortGlob {                        // elements are record indices; keys ar
     AASM_MEM int64_t scan_down(int64_t hi, E pivot) const { while (lt(pivot, a[hi])) --hi; return hi; }
 };
 struct SortTuple { int64_t qs, qe; int32_t ix; };
-#define SF_MAX 1536                      // records of a contig that fit the LDS form (31 KB: five contigs per CU at a time)
+AASM_DEV void keep_tuple(SortTuple &e) { keep_load(e.qs); keep_load(e.qe); keep_load(e.ix); }
+struct SortGlobT {                       // (qry_str, qry_end, record index) tuples in global scratch, moved as a whole; `tab` = the contig's perm slice
+    int64_t *qs, *qe; int32_t *ix; int32_t *tab;
+    typedef SortTuple E;
+    AASM_MEM E get(int64_t i) const { E e; e.qs = qs[i]; e.qe = qe[i]; e.ix = ix[i]; return e; }
+    AASM_MEM E getk(int64_t i) const { E e; e.qs = qs[i]; e.qe = qe[i]; e.ix = 0; return e; }   // the keys alone
+    AASM_MEM void set(int64_t i, const E &v) const { qs[i] = v.qs; qe[i] = v.qe; ix[i] = v.ix; }
+    AASM_MEM bool lt(const E &x, const E &y) const { if (x.qs != y.qs) return x.qs < y.qs; return x.qe < y.qe; }
+    AASM_MEM void tput(int64_t k, int64_t pos) const { tab[k] = (int32_t)pos; }
+    AASM_MEM int64_t tget(int64_t k) const { return tab[k]; }
+    AASM_MEM void sync() const { wave_fence(); }
+    AASM_MEM int64_t scan_up(int64_t lo, const E &pivot) const { while (qs[lo] < pivot.qs || (qs[lo] == pivot.qs && qe[lo] < pivot.qe)) ++lo; return lo; }
+    AASM_MEM int64_t scan_down(int64_t hi, const E &pivot) const { while (pivot.qs < qs[hi] || (pivot.qs == qs[hi] && pivot.qe < qe[hi])) --hi; return hi; }
+};
+#define SF_MAX 1536                      // records of a contig (or of a sub-range of a longer one) that fit the LDS form (38 KB: four per CU at a time)
 #define SF_QN 256
+#define SF_ST 72                         // depth of the two range stacks (introsort's depth limit is 2 lg N <= 62)
+#ifndef SF_WMIN
+#define SF_WMIN 96                       // ranges of this many elements and more are partitioned by the whole wave,
+#endif
+#ifndef SF_GW
+#define SF_GW 8
+#endif
+#define SF_G (AASM_WAVE >= 64 ? SF_GW : 1) // shorter ones by this many lanes,
+#define SF_NG (AASM_WAVE / SF_G)          // that many ranges at a time
 #define SF_PAD 4                         // slack in front of and behind the elements (the partition scans read 4 at a time)
-struct SfLds { int64_t qs[SF_MAX + 2 * SF_PAD], qe[SF_MAX + 2 * SF_PAD]; int32_t ix[SF_MAX + 2 * SF_PAD]; int32_t qf[SF_QN], ql[SF_QN], qd[SF_QN]; int32_t qn, ovf; };
-#define AASM_SORTFIX_LDS_BYTES ((SF_MAX + 2 * SF_PAD) * 20 + SF_QN * 12 + 16)
+struct SfLds {
+    int64_t qs[SF_MAX + 2 * SF_PAD], qe[SF_MAX + 2 * SF_PAD]; int32_t ix[SF_MAX + 2 * SF_PAD];
+    int32_t qf[SF_QN], ql[SF_QN], qd[SF_QN];                       // work list of the lane-per-range phase
+    int32_t af[SF_ST], al[SF_ST], ad[SF_ST];                       // stack of the wave-per-range phase
+    int32_t gf[SF_ST], gl[SF_ST], gd[SF_ST];                       // stack of the global-memory form
+    int16_t tab[SF_MAX + 2 * SF_PAD];                              // right stops of the partition in hand
+    int32_t qn, ovf;
+};
+#define AASM_SORTFIX_LDS_BYTES ((SF_MAX + 2 * SF_PAD) * 22 + SF_QN * 12 + SF_ST * 24 + 16)
 static_assert(sizeof(SfLds) <= AASM_SORTFIX_LDS_BYTES, "LDS budget");
 struct SortLdsAcc {                      // elements are (qry_str, qry_end, record index) tuples, moved as a whole
     SfLds *L;
     typedef SortTuple E;
     AASM_MEM E get(int64_t i) const { E e; e.qs = L->qs[i]; e.qe = L->qe[i]; e.ix = L->ix[i]; return e; }   // (callers pass positions shifted by SF_PAD)
+    AASM_MEM E getk(int64_t i) const { E e; e.qs = L->qs[i]; e.qe = L->qe[i]; e.ix = 0; return e; }   // the keys alone
     AASM_MEM void set(int64_t i, const E &v) const { L->qs[i] = v.qs; L->qe[i] = v.qe; L->ix[i] = v.ix; }
     AASM_MEM bool lt(const E &x, const E &y) const { if (x.qs != y.qs) return x.qs < y.qs; return x.qe < y.qe; }
+    AASM_MEM void tput(int64_t k, int64_t pos) const { L->tab[k] = (int16_t)pos; }
+    AASM_MEM int64_t tget(int64_t k) const { return L->tab[k]; }
+    AASM_MEM void sync() const { wave_lds_sync(); }
     // the partition's two scans, four elements per LDS round trip (reading past the stop is harmless: the arrays
     // carry 4 elements of slack at both ends of the LDS block)
     AASM_MEM int64_t scan_up(int64_t lo, const E &pivot) const {
@@ -478,75 +513,271 @@ template <class A> AASM_DEV void ss_std_sort(const A &a, int64_t n, int depth_ov
     } else ss_insertion_sort(a, 0, n);
 }
 
-// One wave per contig with duplicate keys.  LDS form (N <= SF_MAX): the partition phase of the introsort is a
-// tree of independent sub-ranges - a range's partition only looks at its own elements - so the lanes take one
-// pending range each per round (a work list in LDS), partition it and put both halves back; ranges of <= 16
-// elements are insertion-sorted on the spot.  That equals libstdc++'s final pass: an insertion sort is a
-// stable sort, the leaf ranges are ordered among themselves (Hoare partition), and an element never moves
-// past an equal one, so the whole-array pass never carries an element across a leaf boundary either.
-// The root range costs one lane N steps, the two halves N/2 each in parallel, ...: ~2N steps instead of
-// N log N, on LDS instead of global memory.
+// __unguarded_partition_pivot(first, last) by the whole wave, with the result of the sequential statement.  In the
+// array as it stands after the median step, call "left stops" A_0 < A_1 < ... the positions whose element is not < pivot
+// and "right stops" B_0 > B_1 > ... those whose element is not > pivot.  The sequential loop swaps A_k with B_k for as
+// long as A_k < B_k (a swap only touches positions outside the stretch the scans have yet to cross, so the k-th stops it
+// finds are these), and returns min(A_m, B_(m-1)) for the first k = m that fails.  A_k < B_k holds for a prefix of k, the
+// pairs are disjoint, and every B_k of the prefix lies right of every A_k of it - so: the right stops are listed from the
+// right end in `tab` (ballot + prefix count per 64 positions, as far ahead as the left side needs them), the left side is
+// walked 64 positions at a time, every lane ranks its left stop and swaps it with its partner if that lies to the right;
+// the first lane that finds its partner on the wrong side gives the cut.  A position read late (after a swap put another
+// element there) is a B_k of the prefix: right of every swap that can still happen, so its stale rank never matters.
+// G = lanes that work on the range together: the whole wave for a long range, 8 for a short one (eight ranges at a time).
+#define SS_U 4                           // chunks of G positions in flight
+template <int G> AASM_DEV uint64_t group_ballot(bool p, int gbase) {
+    const uint64_t m = wave_ballot(p);
+    return G >= AASM_WAVE ? m : ((m >> gbase) & ((1ull << (G & 63)) - 1ull));
+}
+template <int G, class A> AASM_DEV int64_t ss_partition_group(const A &a, int64_t first, int64_t last, int lane) {
+    typedef typename A::E E;
+    const int gl = lane & (G - 1), gbase = lane - gl;
+    E pivot;
+    {   // __move_median_to_first(first, first+1, mid, last-1): every lane picks, the group's first lane swaps
+        const int64_t pa = first + 1, pb = first + (last - first) / 2, pc = last - 1;
+        E ea = a.get(pa), eb = a.get(pb), ec = a.get(pc), ef = a.get(first);
+        keep_tuple(ea); keep_tuple(eb); keep_tuple(ec); keep_tuple(ef);
+        int64_t pick;
+        if (a.lt(ea, eb)) pick = a.lt(eb, ec) ? pb : (a.lt(ea, ec) ? pc : pa);
+        else pick = a.lt(ea, ec) ? pa : (a.lt(eb, ec) ? pc : pb);
+        pivot = pick == pa ? ea : (pick == pb ? eb : ec);            // (it stays at `first` during the partition)
+        a.sync();
+        if (gl == 0) { a.set(first, pivot); a.set(pick, ef); }
+        a.sync();
+    }
+    const int64_t f = first + 1, l = last;
+    int64_t nb = 0, top = l;                                         // right stops listed, positions >= top looked at
+    int64_t na = 0, P = f, lim = l;                                  // swaps done, next left position, B_(na-1)
+    int64_t cut = -1;
+    // (statements below are selects rather than branches wherever the groups of a wave could part ways)
+    while (cut < 0) {
+        bool wrote = false;
+        while (nb < na + SS_U * G && top > f) {                      // tab[first + k] = B_k
+            E e[SS_U];
+            AASM_UNROLL
+            for (int u = 0; u < SS_U; u++) { const int64_t i = top - 1 - gl - u * G; e[u] = pivot; if (i >= f) e[u] = a.getk(i); }
+            AASM_UNROLL
+            for (int u = 0; u < SS_U; u++) keep_tuple(e[u]);             // (all loads of the round in flight together)
+            AASM_UNROLL
+            for (int u = 0; u < SS_U; u++) {
+                if (G >= AASM_WAVE && top - u * G <= f) break;
+                const int64_t i = top - 1 - gl - u * G;
+                const bool rb = i >= f && !a.lt(pivot, e[u]);
+                const uint64_t m = group_ballot<G>(rb, gbase);
+                if (rb) a.tput(first + nb + popc64(m & lanemask_lt(gl)), i);
+                nb += popc64(m);
+            }
+            top -= SS_U * G;
+            wrote = true;
+        }
+        if (wrote) a.sync();
+        E e[SS_U];
+        AASM_UNROLL
+        for (int u = 0; u < SS_U; u++) { const int64_t i = P + u * G + gl; e[u] = pivot; if (i < l) e[u] = a.get(i); }
+        AASM_UNROLL
+        for (int u = 0; u < SS_U; u++) keep_tuple(e[u]);
+        AASM_UNROLL
+        for (int u = 0; u < SS_U; u++) {
+            if (G >= AASM_WAVE && cut >= 0) break;
+            const int64_t i = P + u * G + gl;
+            cut = (cut < 0 && P + u * G >= lim) ? lim : cut;
+            const bool la = cut < 0 && i < l && !a.lt(e[u], pivot);
+            const uint64_t m = group_ballot<G>(la, gbase);
+            const int64_t kk = na + popc64(m & lanemask_lt(gl));
+            int64_t j = -1;
+            if (la && kk < nb) j = a.tget(first + kk);
+            const bool sw = la && j > i;
+            const uint64_t ms = group_ballot<G>(sw, gbase), mf = group_ballot<G>(la && !sw, gbase);
+            if (sw) { E o = a.get(j); keep_tuple(o); a.set(i, o); a.set(j, e[u]); }
+            const int top_lane = ms ? 63 - __builtin_clzll(ms) : 0;
+            const int64_t jl = G >= AASM_WAVE ? wave_bcast(j, top_lane) : wave_shfl_idx(j, gbase + top_lane);
+            lim = ms ? jl : lim;
+            na += popc64(ms);
+            const int64_t ifail = P + u * G + (ffs64(mf) - 1);
+            cut = mf ? (ifail < lim ? ifail : lim) : cut;
+        }
+        P += SS_U * G;
+    }
+    a.sync();
+    return cut;
+}
+template <class A> AASM_DEV int64_t ss_partition_wave(const A &a, int64_t first, int64_t last, int lane) { return ss_partition_group<AASM_WAVE>(a, first, last, lane); }
+
+// The introsort of n tuples at L->..[SF_PAD, SF_PAD + n) with `depth` partition levels left, by one wave; the result goes
+// to out[0..n) (record indices).  The partition phase of the introsort is a tree of independent sub-ranges - a range's
+// partition only looks at its own elements:
+//   A  ranges of SF_WMIN and more elements: one after the other, by the whole wave (ss_partition_wave);
+//   B  shorter ranges: eight at a time from a work list in LDS, 8 lanes each (the same statement), halves of more than
+//      16 elements go back on the list;
+//   C  libstdc++'s final insertion sort: an insertion sort is a stable sort, the leaf ranges (<= 16 elements, or
+//      heap-sorted at the depth limit) are ordered among themselves, and an element never moves past an equal one -
+//      so an element's final place is its position minus the greater elements among the 15 in front of it plus the
+//      smaller ones among the 15 behind it: counted per element, lane-parallel, no element moves.
+// false = work list overflow (cannot happen: pending ranges are longer than 16 elements, so never more than n / 17).
+#if defined(AASM_KPROF)
+#define SF_KP_ARG , int64_t *kpa
+#define SF_KP_PASS , kp_acc
+#define SF_KP(i) do { const int64_t t1 = (int64_t)__builtin_amdgcn_s_memtime(); kpa[i] += t1 - kpt; kpt = t1; } while (0)
+#else
+#define SF_KP_ARG
+#define SF_KP_PASS
+#define SF_KP(i) do {} while (0)
+#endif
+AASM_DEV bool sf_sort_lds(SfLds *L, int32_t n, int32_t depth0, int32_t *out, int lane SF_KP_ARG) {
+#if defined(AASM_KPROF)
+    int64_t kpt = (int64_t)__builtin_amdgcn_s_memtime();
+#endif
+    SortLdsAcc acc{L};
+    if (lane == 0) { L->af[0] = SF_PAD; L->al[0] = SF_PAD + n; L->ad[0] = depth0; L->qn = 0; L->ovf = 0; }
+    wave_lds_sync();
+    int32_t asp = n > 16 ? 1 : 0;
+    while (asp > 0) {                                                // A
+        --asp;
+        const int32_t first = uni(L->af[asp]), last = uni(L->al[asp]), depth = uni(L->ad[asp]);
+        wave_lds_sync();
+        if (last - first < SF_WMIN || depth == 0) {                  // for the lanes (B)
+            if (lane == 0) { const int32_t at = L->qn; if (at < SF_QN) { L->qf[at] = first; L->ql[at] = last; L->qd[at] = depth; L->qn = at + 1; } else L->ovf = 1; }
+            wave_lds_sync();
+            continue;
+        }
+        const int32_t cut = (int32_t)ss_partition_wave(acc, first, last, lane);
+        const int32_t f2[2] = {cut, first}, l2[2] = {last, cut};     // (the left half is taken up first, as the sequential loop does)
+        for (int t = 0; t < 2; t++)
+            if (l2[t] - f2[t] > 16) {
+                if (asp < SF_ST) { if (lane == 0) { L->af[asp] = f2[t]; L->al[asp] = l2[t]; L->ad[asp] = depth - 1; } asp++; }
+                else if (lane == 0) L->ovf = 1;
+            }
+        wave_lds_sync();
+    }
+    SF_KP(1);
+    while (!uni(L->ovf)) {                                           // B
+        const int32_t qn = uni(L->qn);
+        if (qn <= 0) break;
+        const int32_t take = qn < SF_NG ? qn : SF_NG;               // the last min(qn, #groups) entries of the list, one per group of lanes
+        const int grp = lane / SF_G, gl = lane & (SF_G - 1);
+        int32_t first = 0, last = 0, depth = 0;
+        const bool mine = grp < take;
+        if (mine) { const int32_t e = qn - 1 - grp; first = L->qf[e]; last = L->ql[e]; depth = L->qd[e]; }
+        wave_lds_sync();
+        if (lane == 0) L->qn = qn - take;
+        wave_lds_sync();
+        if (mine) {
+            if (depth == 0) { if (gl == 0) ss_heapsort(acc, first, last - first); }   // depth limit: __partial_sort(first, last, last); sorted for good
+            else {
+                const int32_t cut = (int32_t)ss_partition_group<SF_G>(acc, first, last, lane);
+                if (gl == 0) {
+                    const int32_t f2[2] = {first, cut}, l2[2] = {cut, last};
+                    for (int t = 0; t < 2; t++)
+                        if (l2[t] - f2[t] > 16) {
+                            const int32_t at = (int32_t)atomic_add(&L->qn, (int32_t)1);
+                            if (at < SF_QN) { L->qf[at] = f2[t]; L->ql[at] = l2[t]; L->qd[at] = depth - 1; }
+                            else L->ovf = 1;
+                        }
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+    SF_KP(2);
+    if (uni(L->ovf)) return false;
+    for (int32_t i = lane; i < n; i += AASM_WAVE) {                  // C
+        const int32_t p = SF_PAD + i;
+        const int64_t k0 = L->qs[p], k1 = L->qe[p];
+        int32_t rank = i;
+        const int32_t dn = i < 15 ? i : 15, up = (n - 1 - i) < 15 ? (n - 1 - i) : 15;
+        int64_t q0[15], q1[15];
+        AASM_UNROLL
+        for (int32_t d = 1; d <= 15; d++) { const int32_t j = d <= dn ? p - d : p; q0[d - 1] = L->qs[j]; q1[d - 1] = L->qe[j]; }   // (beyond the ends: the element itself, which counts for nothing)
+        AASM_UNROLL
+        for (int32_t d = 0; d < 15; d++) { keep_load(q0[d]); keep_load(q1[d]); }
+        AASM_UNROLL
+        for (int32_t d = 0; d < 15; d++) rank -= (q0[d] > k0 || (q0[d] == k0 && q1[d] > k1)) ? 1 : 0;
+        AASM_UNROLL
+        for (int32_t d = 1; d <= 15; d++) { const int32_t j = d <= up ? p + d : p; q0[d - 1] = L->qs[j]; q1[d - 1] = L->qe[j]; }
+        AASM_UNROLL
+        for (int32_t d = 0; d < 15; d++) { keep_load(q0[d]); keep_load(q1[d]); }
+        AASM_UNROLL
+        for (int32_t d = 0; d < 15; d++) rank += (q0[d] < k0 || (q0[d] == k0 && q1[d] < k1)) ? 1 : 0;
+        out[rank] = L->ix[p];
+    }
+    SF_KP(3);
+    return true;
+}
+
+// One wave per contig with duplicate keys.  N <= SF_MAX: the contig's (key, index) tuples go to LDS in input order and
+// sf_sort_lds does the rest.  A longer contig keeps its tuples in global scratch (the sorted-record arrays K1's gather
+// fills later - kb_sort_rank is done with them); the wave partitions there (ss_partition_wave, the right stops listed in
+// the range's own slice of perm) until a range fits LDS, which then finishes it.
 AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
     if (c >= w.C || !w.dupflag[c]) return;
     const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
     int32_t *perm = w.perm + b;
-    if (N > SF_MAX) {                                                // too long for LDS: one lane replays it in global memory
-        if (k.lane == 0) {
-            for (int64_t i = 0; i < N; i++) perm[i] = (int32_t)i;   // copy of the input order (:232)
-            SortGlob acc{perm, w.in_qs + gb, w.in_qe + gb};
-            ss_std_sort(acc, N, -1);
-        }
-        return;
-    }
     SfLds *L = (SfLds *)k.lds;
-    SortLdsAcc acc{L};
-    for (int64_t i = k.lane; i < N; i += AASM_WAVE) { L->qs[SF_PAD + i] = w.in_qs[gb + i]; L->qe[SF_PAD + i] = w.in_qe[gb + i]; L->ix[SF_PAD + i] = (int32_t)i; }   // input order (:232)
-    for (int64_t i = k.lane; i < SF_PAD; i += AASM_WAVE) { L->qs[i] = 0; L->qe[i] = 0; L->qs[SF_PAD + N + i] = 0; L->qe[SF_PAD + N + i] = 0; }
     int lg = 0;
     for (int64_t t = N; t > 1; t >>= 1) lg++;
-    if (k.lane == 0) { L->qf[0] = SF_PAD; L->ql[0] = (int32_t)(SF_PAD + N); L->qd[0] = 2 * lg; L->qn = 1; L->ovf = 0; }
-    wave_lds_sync();
-    while (true) {
-        const int32_t qn = uni(L->qn);
-        if (qn <= 0) break;
-        // the last min(qn, #lanes) entries of the list, one per lane
-        const int32_t take = qn < AASM_WAVE ? qn : AASM_WAVE;
-        int32_t first = 0, last = 0, depth = 0;
-        const bool mine = k.lane < take;
-        if (mine) { const int32_t e = qn - 1 - k.lane; first = L->qf[e]; last = L->ql[e]; depth = L->qd[e]; }
+    const int32_t depth0 = w.sort_depth_test > 0 ? w.sort_depth_test - 1 : 2 * lg;
+    bool ok = true;
+    KPROF_DECL;
+    KPROF_START();
+#if defined(AASM_KPROF)
+    const int64_t kp_real0 = wave_realtime();
+#endif
+    if (N <= SF_MAX) {
+        for (int64_t i = k.lane; i < N; i += AASM_WAVE) { L->qs[SF_PAD + i] = w.in_qs[gb + i]; L->qe[SF_PAD + i] = w.in_qe[gb + i]; L->ix[SF_PAD + i] = (int32_t)i; }   // input order (:232)
+        KPROF_STAMP(0);
+        ok = sf_sort_lds(L, (int32_t)N, depth0, perm, k.lane SF_KP_PASS);
+        KPROF_START();
+    } else {
+        SortGlobT g{w.s_qs + b, w.s_qe + b, w.s_orig + b, perm};
+        for (int64_t i = k.lane; i < N; i += AASM_WAVE) { g.qs[i] = w.in_qs[gb + i]; g.qe[i] = w.in_qe[gb + i]; g.ix[i] = (int32_t)i; }
+        if (k.lane == 0) { L->gf[0] = 0; L->gl[0] = (int32_t)N; L->gd[0] = depth0; }
+        wave_fence();
         wave_lds_sync();
-        if (k.lane == 0) L->qn = qn - take;
-        wave_lds_sync();
-        if (mine) {
-            if (last - first <= 16) ss_insertion_sort(acc, first, last);
-            else if (depth == 0) ss_heapsort(acc, first, last - first);     // depth limit: __partial_sort(first, last, last); sorted for good
-            else {
-                const int32_t cut = (int32_t)ss_partition_pivot(acc, first, last);
-                // halves of <= 16 elements are finished here; pending ranges are all longer, so there are never more than N / 17 of them
-                const int32_t f2[2] = {first, cut}, l2[2] = {cut, last};
-                for (int t = 0; t < 2; t++) {
-                    if (l2[t] - f2[t] <= 16) ss_insertion_sort(acc, f2[t], l2[t]);
-                    else {
-                        const int32_t at = (int32_t)atomic_add(&L->qn, (int32_t)1);
-                        if (at < SF_QN) { L->qf[at] = f2[t]; L->ql[at] = l2[t]; L->qd[at] = depth - 1; }
-                        else L->ovf = 1;
-                    }
+        int32_t gsp = 1;
+        while (gsp > 0 && ok) {
+            --gsp;
+            const int32_t first = uni(L->gf[gsp]);
+            int32_t last = uni(L->gl[gsp]), depth = uni(L->gd[gsp]);
+            wave_lds_sync();
+            bool done = false;
+            while (last - first > SF_MAX) {
+                if (depth == 0) {                                    // depth limit on a range too long for LDS: one lane heap-sorts it where it lies
+                    if (k.lane == 0) ss_heapsort(g, first, last - first);
+                    wave_fence();
+                    for (int64_t i = first + k.lane; i < last; i += AASM_WAVE) perm[i] = g.ix[i];
+                    done = true;
+                    break;
                 }
+                --depth;
+                const int32_t cut = (int32_t)ss_partition_wave(g, first, last, k.lane);
+                KPROF_STAMP(4);
+                if (gsp < SF_ST) { if (k.lane == 0) { L->gf[gsp] = cut; L->gl[gsp] = last; L->gd[gsp] = depth; } gsp++; }
+                else ok = false;
+                wave_lds_sync();
+                last = cut;
             }
+            if (done || !ok) continue;
+            const int32_t n = last - first;
+            for (int32_t i = k.lane; i < n; i += AASM_WAVE) { L->qs[SF_PAD + i] = g.qs[first + i]; L->qe[SF_PAD + i] = g.qe[first + i]; L->ix[SF_PAD + i] = g.ix[first + i]; }
+            KPROF_STAMP(0);
+            ok = sf_sort_lds(L, n, depth, perm + first, k.lane SF_KP_PASS);
+            KPROF_START();
+            wave_lds_sync();
         }
-        wave_lds_sync();
-        if (uni(L->ovf)) break;
     }
-    if (uni(L->ovf)) {                                               // work list overflow (cannot happen: pending ranges are longer than 16): sequential replay
+    if (!ok) {                                                       // (cannot happen) sequential replay from the input
+        wave_fence();
         if (k.lane == 0) {
             for (int64_t i = 0; i < N; i++) perm[i] = (int32_t)i;
-            SortGlob g{perm, w.in_qs + gb, w.in_qe + gb};
-            ss_std_sort(g, N, -1);
+            SortGlob acc{perm, w.in_qs + gb, w.in_qe + gb};
+            ss_std_sort(acc, N, w.sort_depth_test > 0 ? w.sort_depth_test - 1 : -1);
         }
-        return;
     }
-    for (int64_t i = k.lane; i < N; i += AASM_WAVE) perm[i] = L->ix[SF_PAD + i];
+#if defined(AASM_KPROF)
+    kp_acc[7] = wave_realtime() - kp_real0;                          // (100 MHz ticks, to calibrate the cycle counts)
+#endif
+    KPROF_FLUSH(w.prof_heap, c, k.lane);
 }
 
 // gather sorted SoA + parts (paf_data.cpp:248-261).  One wave per contig.

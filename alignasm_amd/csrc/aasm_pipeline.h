@@ -93,6 +93,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     w.C = C; w.R = R; w.R0 = R0;
     w.K = opts.max_paths > 0 ? opts.max_paths : 10000;
     w.nsl = opts.non_skip_linkable ? 1 : 0;
+    w.sort_depth_test = (opts.reserved[2] >> 8) & 0xff;               // test hook: depth limit of kb_sort_fix's introsort
     w.rec_off = in.ctg_rec_off; w.in_qs = in.qry_str; w.in_qe = in.qry_end; w.in_rs = in.ref_str; w.in_re = in.ref_end;
     w.in_qt = in.qry_total; w.in_chr = in.ref_chr; w.in_fwd = in.aln_fwd; w.in_mq = in.map_qul;
     w.in_rng_off = in.rec_rng_off; w.rql = in.rng_qry_l; w.rqr = in.rng_qry_r; w.rrl = in.rng_ref_l;

@@ -94,7 +94,9 @@ typedef struct aasm_opts {
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);
-                                *     bit 1: aasm_solve_batch_multi wraps device ordinals around the devices that exist  */
+                                *     bit 1: aasm_solve_batch_multi wraps device ordinals around the devices that exist;
+                                *     bits 8-15: d + 1 = the sort replay of duplicate-key contigs takes its heap sort
+                                *            fallback after d partition levels instead of 2 lg N                          */
 } aasm_opts;
 
 /* ---- output ---------------------------------------------------------------------
@@ -238,6 +240,12 @@ int64_t aasm_debug_counter(const char *name);
  * {qry, ref, anom, qul_nonzero, qul_total} tuples.  out[i] bit 0: a < b in CALC_SUM mode, bit 1: a < b in
  * QRY_SCORE mode, bit 2: a == b, bit 3: K7's node-key test, bit 4: K8's queue order (equal node / index). */
 int  aasm_debug_predicates(const int64_t *a, const int64_t *b, int64_t n, uint8_t *out, int device);
+/* Test entry for hazard B1: K1's replay of libstdc++'s std::sort (paf_data.cpp:241-246 sorts with an unstable sort, so the
+ * order of records with equal (qry_str, qry_end) is whatever that algorithm leaves) alone, on arbitrary keys.
+ * rec_off[n_contigs + 1] starts at 0; perm_out[rec_off[c] + r] = the input index, relative to contig c, that ends at
+ * sorted position r.  depth_test: 0, or d + 1 for a depth limit of d partition levels (as aasm_opts.reserved[2] bits 8-15). */
+int  aasm_debug_sort_replay(const int64_t *rec_off, int64_t n_contigs, const int64_t *qs, const int64_t *qe, int32_t *perm_out,
+                            int depth_test, int device);
 
 /* ---- host-side codec + file contract (reference: src/paf_data.cpp:19-220,
  *      src/alignasm.cpp:76-183,398-490).  Implemented in host C++.                  */

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../alignasm_amd/csrc/aasm_pipeline.h"
 
@@ -102,16 +103,21 @@ int64_t emul_debug_fetch(const char *name, void *dst, int64_t cap) {
     return (int64_t)it->second.second;
 }
 // kb_sort_fix itself (one contig, LDS form when n <= SF_MAX: work list of sub-ranges, leaf insertion sorts)
-void emul_sort_fix_kernel(int32_t *perm, int64_t n, const int64_t *qs, const int64_t *qe) {
+void emul_sort_fix_kernel2(int32_t *perm, int64_t n, const int64_t *qs, const int64_t *qe, int depth_test) {
     WS w;
     memset(&w, 0, sizeof(w));
     int64_t rec_off[2] = {0, n};
     int32_t dup = 1;
+    std::vector<int64_t> t_qs(n + 1), t_qe(n + 1);
+    std::vector<int32_t> t_ix(n + 1);
     w.C = 1; w.R0 = 0; w.rec_off = rec_off; w.dupflag = &dup; w.in_qs = qs; w.in_qe = qe; w.perm = perm;
+    w.s_qs = t_qs.data(); w.s_qe = t_qe.data(); w.s_orig = t_ix.data();
+    w.sort_depth_test = depth_test;                                  // 0: the real depth limit; d + 1: d partition levels
     alignas(16) static char lds[AASM_SORTFIX_LDS_BYTES];
     KCtx k{0, 1, 0, 1, 0, lds};
     kb_sort_fix(k, w);
 }
+void emul_sort_fix_kernel(int32_t *perm, int64_t n, const int64_t *qs, const int64_t *qe) { emul_sort_fix_kernel2(perm, n, qs, qe, 0); }
 // libstdc++ std::sort replay used by kb_sort_fix, exposed for a direct test
 void emul_std_sort_replay(int32_t *idx, int64_t n, const int64_t *qs, const int64_t *qe, int depth_override) {
     SortGlob acc{idx, qs, qe};
