@@ -24,8 +24,11 @@ python3 $R/tools/phase_probe.py --contigs 1000 --k 10000 --reps 3 2>&1 | tail -n
 python3 $R/tools/phase_probe.py --contigs 5000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_5000contigs.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktk -- python3 $R/tools/phase_probe.py --contigs 5000 --k 10000 --reps 3 > /dev/null 2> $O/ktk.err || exit 1
 cp $O/ktk/*/*kernel_stats.csv $O/${TAG}_c3_k10000_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktd -- python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --dup 3 --shuffle 1 > /dev/null 2> $O/ktd.err || exit 1
+cp $O/ktd/*/*kernel_stats.csv $O/${TAG}_c3_dup3_kernel_stats.csv
+AASM_LIB_OVERRIDE=$R/alignasm_amd/libalignasm_amd_kprof.so python3 $R/tools/sortfix_probe.py > $O/${TAG}_sort_replay_sections.txt 2>&1
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --heavy 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_heavy_tail.json
 python3 $R/tools/giant_probe.py > $O/${TAG}_giant_contigs.jsonl 2>&1
 python3 $R/tools/e2e_cli.py --contigs 5000 --k 4 > $O/${TAG}_e2e_cli.log 2>&1
-rm -rf $O/kt $O/kt5 $O/ktk $O/pmc_fetch $O/pmc_write $O/pmc_sq
+rm -rf $O/kt $O/kt5 $O/ktk $O/ktd $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
