@@ -19,12 +19,16 @@
 #include <cstring>
 #include <string_view>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <memory>
 #include <chrono>
 #include <thread>
 #include <unordered_map>
 #include <climits>
 #include <sys/stat.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -192,6 +196,54 @@ static bool edit_cs(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_st
     return true;
 }
 
+// The writers' form of the same walk.  What a re-cut keeps is one stretch of the tag: query coverage is monotone along the
+// text, only the first and the last kept ':' run can lose bases (they are rendered anew), '*' '+' '-' operations stay or go
+// whole - so the row's tag is  [:head]  +  the kept operations as they stand (ONE copy)  +  [:tail], and the walk itself
+// only adds up numbers.  `irregular` (a kept run not written the way std::to_string writes it, e.g. ":007") sends the
+// row through edit_cs, which renders every operation.
+struct CutPlan { int64_t head_keep, tail_keep; const char *v0, *v1; int32_t mat_num, aln_len; bool irregular; };
+static CsErr plan_cut(const char *cs, int64_t cs_len, bool aln_fwd, int64_t qry_str, int64_t qry_end, int64_t eq_s, int64_t eq_e,
+                      int64_t er_s, int64_t er_e, CutPlan &pl) {
+    pl.head_keep = pl.tail_keep = 0; pl.v0 = pl.v1 = nullptr; pl.mat_num = 0; pl.aln_len = 0; pl.irregular = false;
+    CsCursor c(aln_fwd, qry_str, qry_end, 0, 0);
+    int64_t q_bases = 0, r_bases = 0;
+    bool ins_clipped = false, any = false;
+    auto whole = [&](const char *text, int64_t text_len) {                     // an operation kept as it stands
+        if (pl.tail_keep) pl.irregular = true;                                 // (cannot happen: nothing is kept behind a shortened run)
+        if (!pl.v0) { pl.v0 = text; pl.v1 = text + text_len; }
+        else if (text == pl.v1) pl.v1 = text + text_len;
+        else pl.irregular = true;                                              // (cannot happen: the kept operations are neighbours)
+        any = true;
+    };
+    const CsErr te = cs_scan(cs, cs_len, [&](char t, int64_t n, const char *text, int64_t text_len) {
+        if (t == '-') {
+            if (eq_s < c.q && c.q <= eq_e) { whole(text, text_len); r_bases += n; pl.aln_len += (int32_t)n; }
+            return;
+        }
+        const int64_t lo = c.lo(n), hi = lo + n - 1;
+        const int64_t a = std::max(lo, eq_s), b = std::min(hi, eq_e);
+        c.take_q(n);
+        if (a > b) return;
+        if (t == ':') {
+            const int64_t keep = b - a + 1;
+            pl.mat_num += (int32_t)keep; pl.aln_len += (int32_t)keep; q_bases += keep; r_bases += keep;
+            if (keep == n) {
+                if (text[1] == '0') pl.irregular = true;                       // ":007" comes out as ":7"
+                whole(text, text_len);
+            } else if (!any) { pl.head_keep = keep; any = true; }
+            else if (!pl.tail_keep) pl.tail_keep = keep;
+            else pl.irregular = true;
+        } else if (t == '+') {
+            if (a != lo || b != hi) { ins_clipped = true; return; }
+            whole(text, text_len); q_bases += n; pl.aln_len += (int32_t)n;
+        } else { whole(text, text_len); q_bases += 1; r_bases += 1; pl.aln_len += 1; }
+    });
+    if (te != CS_OK) return te;
+    if (ins_clipped) return CS_E_INS_CLIP;
+    if (q_bases != eq_e - eq_s + 1 || r_bases != std::llabs(er_e - er_s) + 1) return CS_E_EDIT;
+    return CS_OK;
+}
+
 // ---- reader (alignasm.cpp:76-183) ---------------------------------------------------
 static bool parse_i64(std::string_view f, int64_t &v) {
     if (f.empty()) return false;
@@ -275,9 +327,33 @@ static int parse_text(const char *text, int64_t len, aasm_paf &paf) {
 // allocates nothing.  Anything the fast path does not recognise as a well-formed row sends the
 // whole file through parse_text(), which owns the error messages and the odd cases.
 static std::atomic<int> g_host_threads{0};
+// CPUs this process may really use: the machine's, cut to the affinity mask and to the cgroup's CPU quota (a container with
+// 16 CPUs' worth of quota on a 256-thread host: 64 busy threads there spend most of every period throttled)
+static int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+    auto quota = [&](const char *path, const char *path_period) {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return;
+        char a[64] = {0};
+        long long q = -1, per = 100000;
+        if (path_period) {                                             // cgroup v1: two files
+            if (std::fscanf(f, "%lld", &q) != 1) q = -1;
+            FILE *g = std::fopen(path_period, "r");
+            if (g) { if (std::fscanf(g, "%lld", &per) != 1) per = 100000; std::fclose(g); }
+        } else if (std::fscanf(f, "%63s %lld", a, &per) == 2 && std::strcmp(a, "max") != 0) q = std::atoll(a);   // cgroup v2: "<quota|max> <period>"
+        std::fclose(f);
+        if (q > 0 && per > 0) { const int c = (int)((q + per - 1) / per); if (c > 0 && c < n) n = c; }
+    };
+    quota("/sys/fs/cgroup/cpu.max", nullptr);
+    quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    return n;
+}
 int host_threads() {
     int n = g_host_threads.load();
-    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n <= 0) n = 1; if (n > 64) n = 64; }
+    if (n <= 0) { static const int cpus = usable_cpus(); n = cpus; if (n > 64) n = 64; }
     return n;
 }
 
@@ -647,13 +723,20 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     if (o.ctg_index < 0 || r >= paf.ctg_rec_off[contig + 1]) { err = "output element refers to a record outside its contig"; return AASM_E_INVAL; }
     const bool fwd = paf.aln_fwd[r] != 0;
     Edit ed;
+    CutPlan pl;
     const char *cs = paf.cs_pool.data() + paf.cs_off[r];
     const int64_t cs_len = paf.cs_off[r + 1] - paf.cs_off[r];
     const bool uncut = o.edited_qry_str == paf.qry_str[r] && o.edited_qry_end == paf.qry_end[r];   // not cut: the record's own cs / mat_num / aln_len (paf_data.cpp:131-136)
+    bool planned = false;
     if (uncut) { ed.mat_num = paf.mat_num[r]; ed.aln_len = paf.aln_len[r]; ed.is_cut = false; }
-    else if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
-                      o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, err))
-        return AASM_E_PARSE;
+    else {
+        const CsErr pe = plan_cut(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], o.edited_qry_str, o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, pl);
+        if (pe != CS_OK) { err = cs_err_text(pe); return AASM_E_PARSE; }
+        if (!pl.irregular) { planned = true; ed.mat_num = pl.mat_num; ed.aln_len = pl.aln_len; }
+        else if (!edit_cs(cs, cs_len, fwd, paf.qry_str[r], paf.qry_end[r], paf.mat_num[r], paf.aln_len[r], o.edited_qry_str,
+                          o.edited_qry_end, o.edited_ref_str, o.edited_ref_end, ed, err))
+            return AASM_E_PARSE;
+    }
     buf += name; buf += '\t';
     put_i64(buf, paf.qry_total[r]); buf += '\t';
     put_i64(buf, o.edited_qry_str); buf += '\t';
@@ -668,7 +751,13 @@ static int emit_line(const aasm_paf &paf, int64_t contig, const std::string &nam
     put_i64(buf, paf.map_qul[r]); buf += '\t';
     buf += o.is_alt_path ? "tp:A:S" : "tp:A:P"; buf += '\t';
     buf += "xi:Z:"; buf += paf.cord_type[r] == 0 ? "P_" : "A_"; put_i64(buf, paf.row_index[r]); buf += '\t';
-    if (uncut) buf.append(cs, (size_t)cs_len); else buf += ed.cs;
+    if (uncut) buf.append(cs, (size_t)cs_len);
+    else if (planned) {
+        buf += "cs:Z:";
+        if (pl.head_keep) { buf += ':'; put_i64(buf, pl.head_keep); }
+        if (pl.v0) buf.append(pl.v0, (size_t)(pl.v1 - pl.v0));
+        if (pl.tail_keep) { buf += ':'; put_i64(buf, pl.tail_keep); }
+    } else buf += ed.cs;
     buf += '\n';
     return AASM_OK;
 }
@@ -701,78 +790,81 @@ static int write_buffers(const char *path, const std::vector<std::string> &bufs)
     return rc;
 }
 
-// One output file, written in ROUNDS: a round is a contiguous run of contigs (a few MB of output per host thread),
-// cut into one share per thread; while the threads format round r + 1 into one set of buffers, a second set of
-// threads writes round r from the other set at offsets that are known by then (sizes of everything before it).
-// So the formatting runs beside the page-cache copy, and the buffers are a few MB each, reused, instead of one
-// fresh allocation the size of the file.  Rows leave in contig order, as process_output writes them.
+// One output file, rows in contig order (as process_output writes them), formatted AND written by T threads.  The contigs
+// are cut into chunks of about a megabyte of output; thread t takes chunks t, t + T, ...: it formats a chunk into its own
+// buffer (kept from call to call), learns the chunk's file offset from the chunk before it (the offset of chunk k + 1 is
+// known once chunk k is FORMATTED, not written) and writes the buffer itself, at once - the copy into the page cache reads
+// what its own core has just produced.  Measured on the 2-socket box (tools/write_probe2.cpp, producers of 1 GB/s each into
+// one 3 GB file): every producer writing its own chunk 14.7 GB/s at 16 threads, one writer thread taking the chunks in
+// order 7.9 (it reads lines that are dirty in other cores' caches), and the earlier form here (rounds of 4 MB per thread,
+// formatted by one set of threads and written by a second set) 3-4 GB/s.
 template <class EMIT>   // EMIT(contig, buf, err) -> rc : appends every line of one contig (contigs 0 .. C-1 of this call)
-static int append_rounds(int fd, int64_t &file_off, const char *path, int64_t C, const std::vector<int64_t> &weight_prefix, EMIT emit) {
+static int append_rounds(int fd, int64_t &file_off, const char *path, int64_t C, const std::vector<int64_t> &weight_prefix, std::vector<std::string> *bufs,
+                         int max_threads, EMIT emit) {
     const int64_t W = weight_prefix[C];
     int T = host_threads();
+    if (max_threads > 0 && T > max_threads) T = max_threads;
     if (W < (1 << 20)) T = 1;
     const auto t0 = std::chrono::steady_clock::now();
-    int64_t R = W / ((int64_t)T * ((int64_t)4 << 20)) + 1;              // ~4 MB per thread and round
-    if (R > 256) R = 256;
-    auto cut_at = [&](int64_t w) {
-        int64_t c = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), w) - weight_prefix.begin();
-        return c > C ? C : c;
-    };
-    std::vector<int64_t> rcut((size_t)R + 1, C);
-    rcut[0] = 0;
-    for (int64_t r = 1; r < R; r++) { rcut[r] = cut_at(W * r / R); if (rcut[r] < rcut[r - 1]) rcut[r] = rcut[r - 1]; }
-    std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
+    static const bool nowrite = std::getenv("AASM_IO_NOWRITE") != nullptr;   // diagnostic: format only
+    const int64_t target = (int64_t)1 << 20;
+    std::vector<int64_t> ccut(1, 0);                                  // chunk k = contigs [ccut[k], ccut[k + 1])
+    while (ccut.back() < C) {
+        int64_t c = std::lower_bound(weight_prefix.begin(), weight_prefix.end(), weight_prefix[ccut.back()] + target) - weight_prefix.begin();
+        if (c <= ccut.back()) c = ccut.back() + 1;
+        if (c > C) c = C;
+        ccut.push_back(c);
+    }
+    const int64_t NCH = (int64_t)ccut.size() - 1;
+    if (T > NCH) T = NCH > 0 ? (int)NCH : 1;
+    if (bufs[0].size() < (size_t)T) bufs[0].resize((size_t)T);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int64_t> start((size_t)NCH + 1, -1);                  // (under mu) file offset of chunk k, once chunk k - 1 is formatted
+    start[0] = file_off;
+    int64_t stop_at = NCH;                                            // (under mu) chunks from here on are not wanted any more: a row failed to format, a write failed
+    int wrc = AASM_OK;
     std::vector<std::string> errs((size_t)T);
     std::vector<int> rcs((size_t)T, AASM_OK);
-    std::vector<int64_t> off((size_t)T + 1, 0);                          // file offsets of the round being written
-    std::atomic<int> wrc{AASM_OK};
-    int64_t base = file_off;
-    int fail_rc = AASM_OK;
-    std::string fail_msg;
-    for (int64_t r = 0; r <= R && fail_rc == AASM_OK && wrc == AASM_OK; r++) {   // step r: format round r (r < R), write round r - 1 (r > 0)
-        const int fset = (int)(r & 1), wset = fset ^ 1;
-        const bool do_f = r < R, do_w = r > 0;
-        std::vector<int64_t> tcut((size_t)T + 1, 0);
-        if (do_f) {
-            const int64_t c0 = rcut[r], c1 = rcut[r + 1], w0 = weight_prefix[c0], w1 = weight_prefix[c1];
-            tcut[0] = c0; tcut[T] = c1;
-            for (int t = 1; t < T; t++) { int64_t c = cut_at(w0 + (w1 - w0) * t / T); if (c < tcut[t - 1]) c = tcut[t - 1]; if (c > c1) c = c1; tcut[t] = c; }
-        }
-        run_threads((do_f ? T : 0) + (do_w ? T : 0), [&](int id) {
-            if (do_f && id < T) {                                        // ---- format my share of round r
-                const int t = id;
-                std::string &b = bufs[fset][t];
-                b.clear();
-                const size_t want = (size_t)(weight_prefix[tcut[t + 1]] - weight_prefix[tcut[t]]) + 4096;   // the weights are byte estimates: no regrowth copies
-                if (b.capacity() < want) b.reserve(want);
-                for (int64_t c = tcut[t]; c < tcut[t + 1] && rcs[t] == AASM_OK; c++) rcs[t] = emit(c, b, errs[t]);
-            } else {                                                     // ---- write my share of round r - 1
-                const int t = do_f ? id - T : id;
-                const std::string &b = bufs[wset][t];
-                const char *q = b.data();
-                int64_t left = (int64_t)b.size(), o = off[t];
-                while (left > 0) {
-                    const ssize_t wr = ::pwrite(fd, q, (size_t)std::min<int64_t>(left, 1 << 30), (off_t)o);
-                    if (wr <= 0) { wrc = AASM_E_IO; return; }
-                    q += wr; o += wr; left -= wr;
-                }
+    std::vector<int64_t> fail_k((size_t)T, -1);
+    run_threads(T, [&](int t) {
+        std::string &b = bufs[0][t];
+        for (int64_t k = t; k < NCH; k += T) {
+            { std::lock_guard<std::mutex> lk(mu); if (k >= stop_at) break; }
+            b.clear();
+            const size_t want = (size_t)(weight_prefix[ccut[k + 1]] - weight_prefix[ccut[k]]) + 4096;   // the weights are byte estimates: no regrowth copies
+            if (b.capacity() < want) b.reserve(want);
+            int rc = AASM_OK;
+            for (int64_t c = ccut[k]; c < ccut[k + 1] && rc == AASM_OK; c++) rc = emit(c, b, errs[t]);
+            int64_t o;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (rc != AASM_OK) { rcs[t] = rc; fail_k[t] = k; if (k < stop_at) stop_at = k; cv.notify_all(); break; }
+                cv.wait(lk, [&] { return start[k] >= 0 || k > stop_at; });   // the chunk before this one: formatted yet?  (never, if an earlier chunk failed)
+                if (start[k] < 0) break;
+                o = start[k];
+                start[k + 1] = o + (int64_t)b.size();
+                cv.notify_all();
             }
-        });
-        if (do_f) {
-            for (int t = 0; t < T; t++) if (rcs[t] != AASM_OK) { fail_rc = rcs[t]; fail_msg = errs[t]; break; }   // first failing contig in file order
-            off[0] = base;
-            for (int t = 0; t < T; t++) off[t + 1] = off[t] + (int64_t)bufs[fset][t].size();
-            base = off[T];
+            const char *q = b.data();
+            int64_t left = (int64_t)b.size();
+            while (left > 0 && !nowrite) {
+                const ssize_t wr = ::pwrite(fd, q, (size_t)std::min<int64_t>(left, 1 << 30), (off_t)o);
+                if (wr <= 0) { std::lock_guard<std::mutex> lk(mu); wrc = AASM_E_IO; if (k < stop_at) stop_at = k; cv.notify_all(); break; }
+                q += wr; o += wr; left -= wr;
+            }
         }
-    }
-    int rc = fail_rc;
-    if (rc == AASM_OK && wrc != AASM_OK) rc = wrc;
-    if (fail_rc != AASM_OK) set_last_error(fail_msg);
-    else if (rc != AASM_OK) set_last_error(std::string("write to ") + path + " failed");
+    });
+    int rc = AASM_OK;
+    int64_t first = -1;
+    for (int t = 0; t < T; t++)
+        if (rcs[t] != AASM_OK && (first < 0 || fail_k[t] < first)) { first = fail_k[t]; rc = rcs[t]; set_last_error(errs[t]); }   // the first failing contig in file order
+    if (rc == AASM_OK && wrc != AASM_OK) { rc = wrc; set_last_error(std::string("write to ") + path + " failed"); }
+    const int64_t end = rc == AASM_OK ? start[NCH] : file_off;
     if (std::getenv("AASM_IO_TIMING"))
-        std::fprintf(stderr, "aasm io: %s format + write %.3f s (%.1f MB, %d threads x %lld rounds)\n", path,
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (base - file_off) / 1e6, T, (long long)R);
-    file_off = base;
+        std::fprintf(stderr, "aasm io: %s format + write %.3f s (%.1f MB, %d threads, %lld chunks)\n", path,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (end - file_off) / 1e6, T, (long long)NCH);
+    if (rc == AASM_OK) file_off = end;
     return rc;
 }
 
@@ -902,6 +994,7 @@ int aasm_paf_batch(const aasm_paf *paf, aasm_batch_in *v) {
 // get_edited_paf_data throws) or a failing write leaves no truncated .paf behind.
 struct aasm_writer {
     std::string path[3], tmp[3];
+    std::vector<std::string> bufs[3][2];  // per file: the two sets of per-thread row buffers of append_rounds (fresh buffers per call cost a page fault per 4 KB written)
     int fd[3] = {-1, -1, -1};
     int64_t off[3] = {0, 0, 0};
     int64_t next_contig = 0;
@@ -976,7 +1069,7 @@ int aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out
     auto do_main = [&]() {                                              // process_output, :407-443
         if (w->fd[0] < 0) return;
         const std::vector<int64_t> wp = bytes_prefix(out->main_off, out->main_elems, 0);
-        rcs[0] = append_rounds(w->fd[0], w->off[0], w->path[0].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
+        rcs[0] = append_rounds(w->fd[0], w->off[0], w->path[0].c_str(), C, wp, w->bufs[0], 0, [&](int64_t c, std::string &buf, std::string &err) {
             for (int64_t k = out->main_off[c]; k < out->main_off[c + 1]; k++) {
                 const int r = emit_line(*paf, contig0 + c, paf->ctg_name[contig0 + c], out->main_elems[k], buf, err);
                 if (r != AASM_OK) return r;
@@ -985,10 +1078,11 @@ int aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out
         });
         if (rcs[0] != AASM_OK) errs[0] = aasm_last_error();
     };
+    const int side_threads = std::max(1, host_threads() / 4);          // the two small files take a quarter of the threads again, beside the big one
     auto do_rest = [&]() {                                              // the two small files, beside the big one (three inodes: three write locks)
         if (w->fd[1] >= 0) {
             const std::vector<int64_t> wp = bytes_prefix(out->alt_off, out->alt_elems, 0);
-            rcs[1] = append_rounds(w->fd[1], w->off[1], w->path[1].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
+            rcs[1] = append_rounds(w->fd[1], w->off[1], w->path[1].c_str(), C, wp, w->bufs[1], side_threads, [&](int64_t c, std::string &buf, std::string &err) {
                 for (int64_t k = out->alt_off[c]; k < out->alt_off[c + 1]; k++) {
                     const int r = emit_line(*paf, contig0 + c, paf->ctg_name[contig0 + c], out->alt_elems[k], buf, err);
                     if (r != AASM_OK) return r;
@@ -1001,7 +1095,7 @@ int aasm_writer_append(aasm_writer *w, const aasm_paf *paf, const aasm_batch_out
             std::vector<int64_t> eoff((size_t)C + 1);
             for (int64_t c = 0; c <= C; c++) eoff[c] = out->all_elem_off[out->all_path_off[c]];
             const std::vector<int64_t> wp = bytes_prefix(eoff.data(), out->all_elems, 12);
-            rcs[2] = append_rounds(w->fd[2], w->off[2], w->path[2].c_str(), C, wp, [&](int64_t c, std::string &buf, std::string &err) {
+            rcs[2] = append_rounds(w->fd[2], w->off[2], w->path[2].c_str(), C, wp, w->bufs[2], side_threads, [&](int64_t c, std::string &buf, std::string &err) {
                 int32_t cnt = 0;
                 for (int64_t pth = out->all_path_off[c]; pth < out->all_path_off[c + 1]; pth++) {
                     ++cnt;
