@@ -378,6 +378,9 @@ def e2e_cli(nc, nr, seed, dense, K):
         exe = os.path.join(ROOT, "alignasm_amd", "alignasm")
         runs = []
         for _ in range(2):
+            for sfx in (".aln.paf", ".aln.alt.paf", ".aln.all.paf"):     # to NEW files both times (replacing a 3 GB file frees its page cache inside rename())
+                if os.path.exists(path[:-4] + sfx):
+                    os.remove(path[:-4] + sfx)
             t0 = time.perf_counter()
             r = subprocess.run([exe, path, "--max-paths", str(K), "--timing"], capture_output=True, text=True)
             wall = time.perf_counter() - t0

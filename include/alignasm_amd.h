@@ -255,7 +255,8 @@ int  aasm_paf_read(const char *path, aasm_paf **paf);              /* alignasm.c
 /* Host threads of the PAF reader and the output writers (row-parallel; results do not depend
  * on it).  The reference's -t/--thread (alignasm.cpp:45-49,346-352) sizes the TBB arena that
  * runs solve_ctg_read; here that work is on the GPU and -t sizes the host codec instead.
- * 0 = all hardware threads (default).  Returns the previous setting. */
+ * 0 = the CPUs this process may use - hardware threads cut to the affinity mask and the cgroup CPU
+ * quota, at most 64 (default).  Returns the previous setting. */
 int  aasm_set_host_threads(int n);
 int  aasm_paf_parse_mem(const char *text, int64_t len, aasm_paf **paf);
 /* Reader flags.  AASM_READ_DEVICE_RANGES: do not build the match ranges on the host; rows are
