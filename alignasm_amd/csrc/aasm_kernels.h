@@ -1782,6 +1782,7 @@ struct HeapLds {
     HNode ring[HEAP_RING];
     I4 bq[HEAP_QN];
     HeapStage stage;                      // keys of the vertex popped next, parked here at the end of a step
+    HNode bounce;                         // a node chased in global memory passes through here (heap_read)
 };
 static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
 struct Spine {
@@ -1794,6 +1795,7 @@ struct Spine {
 struct HeapState {
     HNode *nodes;
     HNode *ring;                   // HEAP_RING nodes of LDS, this wave's
+    HNode *bounce;                 // one node of LDS, this wave's (heap_read)
     int32_t alloc, flushed, cap;   // arena: next index; nodes below `flushed` are in global memory, [flushed, alloc) only in the ring
     int32_t ring_lo;               // nodes below it were never in this wave's ring (0, or the start of the vertex region being filled)
     bool ovf;
@@ -1801,8 +1803,17 @@ struct HeapState {
 
 AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
     NodeQ n;
-    if (a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) n = nodeq_load(&hs.ring[a & (HEAP_RING - 1)]);   // ds_read, lgkmcnt only
-    else { n = nodeq_load(&hs.nodes[a]); asm volatile("" ::: "memory"); }             // keep it a global_load (no flat access)
+    const HNode *src = &hs.ring[a & (HEAP_RING - 1)];                                  // ds_read, lgkmcnt only
+    if (!(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo)) {
+        // an old node, in global memory (a few per cent of the chase steps): it goes to LDS first, so that what the caller keeps
+        // in its spine registers has ONE kind of source - with a global load as the other one the compiler guards every later
+        // use of the spine with vmcnt(0), and the inserts wait for the next vertex's prefetch instead of running beside it
+        const NodeQ g = nodeq_load(&hs.nodes[a]);
+        asm volatile("" ::: "memory");                                                 // keep it a global_load (no flat access)
+        nodeq_store(hs.bounce, g);
+        src = hs.bounce;
+    }
+    n = nodeq_load(src);
     return n;
 }
 // node.key < key (paf_data.hpp:142-159, CALC_SUM mode) for keys that are never max() (kb_sidetrack)
@@ -1933,7 +1944,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
     const Dist *sk = w.st_cost + w.rowptr[vb];                      // the contig's compacted sidetrack keys (kb_sidetrack)
     HeapState hs;
-    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.bounce = &L->bounce; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (w.mw_flag[c]) return;                                        // wide trees: kb_heap_mw
@@ -2000,11 +2011,12 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         KPROF_STAMP(2);                                              // prefetch issue
         // ---- inserts in list order (:202-211)
         for (int32_t t = 0; t < n && !hs.ovf; t++) {
-            Dist cc;
-            if (t < HEAP_KMAX) cc = S->key[t];
-            else { cc = sk[(int64_t)so + t]; asm volatile("" ::: "memory"); }   // rows with more sidetracks than a slot holds (dense graphs).  The barrier
-                                                                     // keeps the two loads apart: merged into ONE flat load of a selected address, every insert
-                                                                     // waited for vmcnt(0) - i.e. for the next vertex's prefetch issued a moment earlier
+            if (t >= HEAP_KMAX && (t & (HEAP_KMAX - 1)) == 0) {      // a row with more sidetracks than the slot holds (dense graphs): the next HEAP_KMAX keys replace the used ones.
+                wave_lds_sync();                                     // The insert below must only ever see a key that came out of LDS: with a global load as the other source of
+                FOR_LANE(j, (n - t < HEAP_KMAX ? n - t : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t + j]; S->key[j] = kk; }   // `cc` the compiler makes EVERY insert wait for vmcnt(0),
+                wave_lds_sync();                                     // i.e. for the next vertex's prefetch issued a moment earlier
+            }
+            const Dist cc = S->key[t & (HEAP_KMAX - 1)];
             hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
         }
         KPROF_STAMP(3);                                              // inserts
@@ -2076,9 +2088,10 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 #define MW_WAVES 16                      // most waves a contig can get (the launch picks 4, 8 or 16 by how many contigs share the chip)
 struct MwLds {
     int32_t q_head, q_tail, n_done, n_total, stop, n_nodes, pad0, pad1;
+    HNode bounce[MW_WAVES];              // heap_read's slot, one per wave
     HNode ring[MW_WAVES][HEAP_RING];     // (a launch with fewer waves declares only its share)
 };
-#define AASM_MW_LDS_BYTES(waves) ((waves) * HEAP_RING * 48 + 32)
+#define AASM_MW_LDS_BYTES(waves) ((waves) * HEAP_RING * 48 + 32 + MW_WAVES * 48)
 static_assert(sizeof(MwLds) <= AASM_MW_LDS_BYTES(MW_WAVES), "LDS budget");
 
 // last position i in [0, n) with a[i] <= x (a non-decreasing, a[0] <= x)
@@ -2134,7 +2147,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     const int32_t nv = uni(ld_shared_i32(&L->n_total));
     // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
     HeapState hs;
-    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
+    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     KProfNone kp;
     int32_t u = (wv == 0) ? dest : -1, hu = -1;
