@@ -344,7 +344,12 @@ def cpu_baseline(paf, nc, K, sample):
         return n / dt, dt
 
     n = min(sample, nc)
-    rate, dt = run(n, cores)
+    usable = usable_cpus()
+    full = []                                                       # the whole sample at: every hardware thread, the CPUs the process may use, twice that
+    for t in sorted({cores, usable, min(cores, 2 * usable)}):
+        rt, dtt = run(n, t)
+        full.append((t, rt, dtt))
+    threads, rate, dt = max(full, key=lambda x: x[1])
     r1, dt1 = run(min(40, nc), 1)
     ladder = []
     for t in sorted({2, 4, 8, 16, 32, 64, 128, cores} - {1}):
@@ -354,10 +359,35 @@ def cpu_baseline(paf, nc, K, sample):
         ladder.append((t, rt))
     best = max([rate] + [r for _, r in ladder])
     stops = next((t for t, r in ladder if r >= 0.9 * best), cores)
-    return {"value": round(rate, 2), "unit": "contigs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {cores} threads, {dt:.2f} s wall",
+    return {"value": round(rate, 2), "unit": "contigs/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {threads} threads, {dt:.2f} s wall "
+                      f"(the best of {[t for t, _, _ in full]} threads on this sample; the host shows {cores} hardware threads, the process may use {usable} CPUs)",
+            "full_sample": [{"threads": t, "contigs_per_sec": round(r, 1)} for t, r, _ in full],
             "value_1t": round(r1, 2), "sample_1t": f"first {min(40, nc)} contigs on 1 thread, {dt1:.2f} s",
             "scaling": [{"threads": t, "contigs_per_sec": round(r, 1)} for t, r in ladder], "stops_scaling_at": stops}
+
+
+def usable_cpus():
+    """CPUs this process may really use: hardware threads cut to the affinity mask and the cgroup CPU quota."""
+    n = max(1, os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                    # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+        if q != "max" and int(per) > 0:
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def e2e_cli(nc, nr, seed, dense, K):
