@@ -242,3 +242,36 @@ def test_a_row_that_cannot_be_written_leaves_no_file_behind(T, tmp_path):
     T.oracle().oracle_free_out(C.byref(out))
     assert "Edited cs tag does not match edited PAF coordinates" in str(e.value) or "clipped inside a cs insertion" in str(e.value)
     assert [p.name for p in tmp_path.iterdir()] == []
+
+
+def test_writer_renders_unusual_run_lengths_like_the_reference(T, tmp_path):
+    """A kept ':' run is copied as it stands only when it is written the way std::to_string writes it; ":007" (which
+    std::from_chars accepts) has to come out as ":7" in a re-cut row and unchanged in a row that is not cut - rows of both
+    kinds, run lengths padded at the front of the tag, in the middle and at its end."""
+    import re
+    api, io = T.api(), T.io_oracle()
+    text = api.Paf.synth(30, 120, 17, dup_every=4).to_text().decode()
+    rows = []
+    for i, ln in enumerate(text.splitlines()):
+        f = ln.split("\t")
+        runs = list(re.finditer(r":(\d+)", f[-1]))
+        if runs and i % 3 != 2:
+            m = runs[(0, len(runs) // 2, len(runs) - 1)[i % 3]] if i % 2 else runs[0]
+            f[-1] = f[-1][:m.start()] + ":00" + m.group(1) + f[-1][m.end():]
+        rows.append("\t".join(f))
+    text = ("\n".join(rows) + "\n").encode()
+    st = io.read_paf(text)
+    paf = api.Paf.parse(text)
+    hb = T.io_oracle_batch(st)
+    K = 8
+    want = io.render_outputs(st, T.oracle_solve(hb, K))
+    from alignasm_amd._abi import BatchOut, Opts
+    out = BatchOut()
+    assert T.oracle().oracle_solve_batch(C.byref(hb.view), C.byref(Opts(K, 0, 0, 0, 0)), 2, C.byref(out)) == 0
+    paths = [str(tmp_path / n) for n in ("w.aln.paf", "w.aln.alt.paf", "w.aln.all.paf")]
+    paf.write_outputs(out, *paths)
+    T.oracle().oracle_free_out(C.byref(out))
+    got = [open(p, "rb").read() for p in paths]
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    tags = [ln.split(b"\t")[14] for ln in want[0].splitlines()]
+    assert any(b":00" in t for t in tags) and any(b":00" not in t for t in tags)       # uncut rows keep the padding, re-cut rows lose it
