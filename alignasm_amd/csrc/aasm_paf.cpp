@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string_view>
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include <memory>
@@ -527,7 +528,9 @@ static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf, int flags
     }
     ck[T - 1].e = len;
     for (int t = 0; t + 1 < T; t++) if (ck[t].e < ck[t].b) ck[t].e = ck[t].b;
+    const auto tr0 = std::chrono::steady_clock::now();
     run_threads(T, [&](int t) { read_pass1(text, ck[t]); });
+    const auto tr1 = std::chrono::steady_clock::now();
     std::vector<int64_t> row0(T + 1, 0), rng0(T + 1, 0), cs0(T + 1, 0);
     bool bad = false;
     for (int t = 0; t < T; t++) {
@@ -536,14 +539,24 @@ static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf, int flags
     }
     const int64_t R = row0[T];
     if (bad || R == 0 || R > INT32_MAX) return parse_text(text, len, paf);   // errors / empty input: the serial reader reports
-    paf.qry_str.resize(R); paf.qry_end.resize(R); paf.ref_str.resize(R); paf.ref_end.resize(R); paf.qry_total.resize(R); paf.ref_total.resize(R);
-    paf.ref_chr.resize(R); paf.mat_num.resize(R); paf.aln_len.resize(R); paf.row_index.resize(R);
-    paf.aln_fwd.resize(R); paf.map_qul.resize(R); paf.cord_type.resize(R);
-    paf.cs_off.resize(R + 1); paf.rec_rng_off.resize(R + 1);
+    {   // sixteen arrays to size (the per-record ones are zero-filled by resize: 0.4 GB at whole-genome scale): one thread each
+        const std::vector<std::function<void()>> jobs = {
+            [&] { paf.qry_str.resize(R); }, [&] { paf.qry_end.resize(R); }, [&] { paf.ref_str.resize(R); }, [&] { paf.ref_end.resize(R); },
+            [&] { paf.qry_total.resize(R); }, [&] { paf.ref_total.resize(R); }, [&] { paf.ref_chr.resize(R); }, [&] { paf.mat_num.resize(R); },
+            [&] { paf.aln_len.resize(R); }, [&] { paf.row_index.resize(R); }, [&] { paf.aln_fwd.resize(R); paf.map_qul.resize(R); paf.cord_type.resize(R); },
+            [&] { paf.cs_off.resize(R + 1); }, [&] { paf.rec_rng_off.resize(R + 1); },
+            [&] { if (!paf.device_ranges) { paf.rng_qry_l.resize(rng0[T]); paf.rng_qry_r.resize(rng0[T]); paf.rng_ref_l.resize(rng0[T]); } },
+            [&] { paf.cs_pool.resize(cs0[T]); }};
+        const int J = (int)jobs.size(), TJ = std::min(T, J);
+        run_threads(TJ, [&](int t) { for (int j = t; j < J; j += TJ) jobs[j](); });
+    }
     paf.cs_off[0] = 0; paf.rec_rng_off[0] = 0;
-    if (!paf.device_ranges) { paf.rng_qry_l.resize(rng0[T]); paf.rng_qry_r.resize(rng0[T]); paf.rng_ref_l.resize(rng0[T]); }
-    paf.cs_pool.resize(cs0[T]);
+    const auto tr2 = std::chrono::steady_clock::now();
     run_threads(T, [&](int t) { read_pass2(text, ck[t], paf, row0[t], rng0[t], cs0[t]); });
+    const auto tr3 = std::chrono::steady_clock::now();
+    if (std::getenv("AASM_IO_TIMING"))
+        std::fprintf(stderr, "aasm io: reader %d threads: index %.3f s, allocate %.3f s, parse + copy %.3f s (%.1f MB)\n", T, std::chrono::duration<double>(tr1 - tr0).count(),
+                     std::chrono::duration<double>(tr2 - tr1).count(), std::chrono::duration<double>(tr3 - tr2).count(), len / 1e6);
     for (int t = 0; t < T; t++) bad |= ck[t].bad;
     if (bad) { paf = aasm_paf(); return parse_text(text, len, paf); }            // (host ranges: parse_text builds them)
     // reference names numbered by first appearance in the file (chr_map, :119-123)
