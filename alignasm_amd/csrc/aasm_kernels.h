@@ -2117,6 +2117,13 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     if (k.tid == 0) w.h_cnt[c] = 0;
     if (w.status[c] != 0) return;
     if (dist_is_max(w.sp_d[vb + src])) { if (k.tid == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    const int64_t mwp_t0 = wave_realtime();                          // diagnostic build: the phases' wall time (100 MHz ticks) of wave 0
+    int64_t mwp_t1 = 0, mwp_t2 = 0, mwp_t3 = 0;
+#define MWP_STAMP(x) do { x = wave_realtime(); } while (0)
+#else
+#define MWP_STAMP(x) do {} while (0)
+#endif
     // ---- phase 0: BFS numbering (k_shortest_walks.hpp:196-214 without the inserts) + region starts
     if (wv == 0) {
         if (k.lane == 0) order[0] = dest;
@@ -2144,6 +2151,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
         store_drain();
     }
     block_barrier();
+    MWP_STAMP(mwp_t1);
     const int32_t nv = uni(ld_shared_i32(&L->n_total));
     // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
     HeapState hs;
@@ -2205,6 +2213,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     heap_flush(hs, k.lane);
     store_drain();
     block_barrier();
+    MWP_STAMP(mwp_t2);
     const int32_t stop = uni(ld_shared_i32(&L->stop));
     if (stop) { if (k.tid == 0) set_status(w, c, stop == 1 ? -5 : -6); return; }
     // ---- phase 2: compaction into the final arena, BFS order = the reference's allocation order
@@ -2223,19 +2232,38 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     const int32_t H = uni(ld_shared_i32(&L->n_nodes));
     HNode *fin = w.hnodes + w.hoff[c];
     if (H > (int32_t)(w.hoff[c + 1] - w.hoff[c])) { if (k.tid == 0) set_status(w, c, -5); return; }
-    auto translate = [&](int32_t x, int32_t i_own) -> int32_t {     // provisional index -> final index
-        if (x < 0) return x;
-        const int32_t j = (i_own >= 0 && x >= rs[i_own]) ? i_own : mw_last_le(rs, i_own >= 0 ? i_own : nv, x);
-        return fb[j] + (x - rs[j]);
+    // The region starts (the keys of every pointer translation) go to LDS when they fit in the rings' space, which is free now:
+    // a node's two pointers mostly lead into ancestors' regions, i.e. two binary searches of ~12 dependent reads each - from
+    // global memory they were 20 of the 44 ms a dense 1 000-record contig's block took (phase 1: 24).
+    int32_t *rs_l = (int32_t *)&L->ring[0][0];
+    const int nwaves = k.nthreads / AASM_WAVE;
+    const bool rs_in_lds = nv <= nwaves * (int32_t)(HEAP_RING * sizeof(HNode) / sizeof(int32_t));
+    if (rs_in_lds) for (int32_t i = k.tid; i < nv; i += k.nthreads) rs_l[i] = rs[i];
+    block_barrier();
+    auto compact = [&](const int32_t *rsk) {                        // (called once per address space of rsk, so that the LDS form reads with ds_read)
+        auto translate = [&](int32_t x, int32_t i_own) -> int32_t { // provisional index -> final index
+            if (x < 0) return x;
+            const int32_t j = (i_own >= 0 && x >= rsk[i_own]) ? i_own : mw_last_le(rsk, i_own >= 0 ? i_own : nv, x);
+            return fb[j] + (x - rsk[j]);
+        };
+        // a wave takes the regions wv, wv + nwaves, ... whole (no search for the region of a node), its lanes the nodes of a region
+        for (int32_t i = wv; i < nv; i += nwaves) {
+            const int32_t n_i = uni(used[uni(order[i])]), r0 = uni(rsk[i]), f0 = uni(fb[i]);
+            for (int32_t t = k.lane; t < n_i; t += AASM_WAVE) {
+                HNode nd = hs.nodes[r0 + t];
+                nd.left = translate(nd.left, i); nd.right = translate(nd.right, i);
+                fin[f0 + t] = nd;
+            }
+        }
+        for (int32_t i = k.tid; i < nv; i += k.nthreads) { const int32_t v = order[i]; h[v] = translate(h[v], -1); }
     };
-    for (int32_t f = k.tid; f < H; f += k.nthreads) {
-        const int32_t i = mw_last_le(fb, nv, f);
-        HNode nd = hs.nodes[rs[i] + (f - fb[i])];
-        nd.left = translate(nd.left, i); nd.right = translate(nd.right, i);
-        fin[f] = nd;
-    }
-    for (int32_t i = k.tid; i < nv; i += k.nthreads) { const int32_t v = order[i]; h[v] = translate(h[v], -1); }
+    if (rs_in_lds) compact(rs_l); else compact(rs);
     if (k.tid == 0) { w.h_cnt[c] = H; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)H); }
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+    block_barrier();
+    MWP_STAMP(mwp_t3);
+    if (k.tid == 0 && w.prof_heap) { int64_t *pp = w.prof_heap + c * 8; pp[0] = mwp_t1 - mwp_t0; pp[1] = mwp_t2 - mwp_t1; pp[2] = mwp_t3 - mwp_t2; pp[3] = H; pp[4] = nv; pp[5] = pp[6] = pp[7] = 0; }
+#endif
 }
 
 // ====================================================================================
