@@ -2478,6 +2478,7 @@ struct SelCtx {
     bool err, res_lds;
     int lane;
     char *lds;
+    char *wide;                      // the wide-window state (SelWide) behind the SelLds block, or nullptr: the launch did not declare it
     int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     int64_t kp_t0, kp_acc[8];
@@ -2514,6 +2515,11 @@ struct SelLds {
 };
 #define AASM_SEL_LDS_BYTES 7488
 static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
+// ... and of the launch for dense graphs (aasm_k9_sel_convert_w), behind it: the DP state of a window of up to ISPR_WIDE positions
+#define ISPR_WIDE 127
+struct SelWide { Dist dist[ISPR_WIDE + 1]; int32_t excl[ISPR_WIDE + 2]; int32_t vj[ISPR_WIDE + 1]; uint8_t pre[ISPR_WIDE + 1]; uint8_t reach[ISPR_WIDE + 1]; };
+#define AASM_SELW_LDS_BYTES 5392
+static_assert(sizeof(SelWide) <= AASM_SELW_LDS_BYTES, "LDS budget");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
     SelLds *L = (SelLds *)s.lds;
@@ -2680,35 +2686,113 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
 // Inside a row targets are distinct, so the lane-parallel relaxation is conflict-free and
 // the sequential source order keeps the reference's strict-`<` first-wins behaviour.
 AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
+    // Windows too wide or too dense for LDS (most of a dense graph's): the same DP on epoch-stamped global arrays, indexed by
+    // topological POSITION, over the topologically ordered copy of the CSR - a window's positions, rows and state are then
+    // consecutive memory: the stamps of 64 positions are one load (a position nobody reached costs nothing; the ones reached
+    // by a source of the same 64 are added to the mask as they are relaxed), a source's row starts at tp_ptr[position], and an
+    // edge's head position comes with the edge (by vertex id it was order[i] -> stamp -> row pointers -> heads -> positions
+    // -> state: five dependent round trips per position, 137 us per call on the dense C5 graphs).
     const WS &w = *s.w;
     const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
     const int32_t ep = ++s.epoch;
-    const int32_t pb = pos[bd];
+    const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
     s.res_lds = false;
-    if (s.lane == 0) { s.dist2[a] = dist_zero(); s.pre2[a] = -1; s.stamp[a] = ep; }
+    if (s.lane == 0) { s.dist2[pa] = dist_zero(); s.pre2[pa] = -1; s.stamp[pa] = ep; }
     wave_fence();
-    for (int32_t i = pos[a]; i < pb; i++) {
-        const int32_t u = order[i];
-        if (s.stamp[u] != ep) continue;
-        const Dist cd = s.dist2[u];
-        const int64_t r0 = w.rowptr[s.vb + u], r1 = w.rowptr[s.vb + u + 1];
-        s.n_ispr_v++; s.n_ispr_e += r1 - r0;
-        const bool u_ok = !(u == s.src || u == s.dest) && (w.v_j[s.vb + u] == wl);   // :767-773
-        for (int64_t e = r0 + s.lane; e < r1; e += AASM_WAVE) {
-            const int32_t v = w.e_col[e];
-            if (pos[v] > pb) continue;
-            if (wl_flag && v == bd && !u_ok) continue;
-            const Dist nd = dist_add(cd, edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]));
-            if (s.stamp[v] != ep || dist_lt<QRY_SCORE_MODE>(nd, s.dist2[v])) { s.dist2[v] = nd; s.pre2[v] = u; s.stamp[v] = ep; }
+    for (int32_t i0 = pa; i0 < pb; i0 += AASM_WAVE) {
+        const int32_t nchunk = (pb - i0 < AASM_WAVE) ? (pb - i0) : AASM_WAVE;
+        uint64_t reach = wave_ballot(s.lane < nchunk && s.stamp[i0 + s.lane] == ep);   // reached positions of this chunk
+        for (int32_t t = 0; t < nchunk; t++) {
+            if (!((reach >> t) & 1ull)) continue;
+            const int32_t i = i0 + t;
+            const Dist cd = s.dist2[i];
+            const int64_t r0 = uni(w.tp_ptr[s.vb + i]), r1 = uni(w.tp_ptr[s.vb + i + 1]);
+            const bool u_ok = uni(w.tp_vj[s.vb + i]) == wl;          // :767-773 (src / dest carry -1 / -2: never a whitelist match)
+            s.n_ispr_v++; s.n_ispr_e += r1 - r0;
+            for (int64_t e0 = r0; e0 < r1; e0 += AASM_WAVE) {
+                const int64_t e = e0 + s.lane;
+                int32_t tg = INT32_MAX;
+                bool upd = false;
+                if (e < r1) {
+                    tg = w.te_tgt[e];
+                    if (tg <= pb && !(wl_flag && tg == pb && !u_ok)) {
+                        const Dist nd = dist_add(cd, edge_dist(w.te_wq[e], w.te_wr[e], w.te_fl[e]));
+                        if (s.stamp[tg] != ep || dist_lt<QRY_SCORE_MODE>(nd, s.dist2[tg])) { s.dist2[tg] = nd; s.pre2[tg] = i; s.stamp[tg] = ep; upd = true; }
+                    }
+                }
+                uint64_t m = wave_ballot(upd && tg < i0 + nchunk);   // heads inside this chunk: reached from now on
+                while (m) { const int j = ffs64(m) - 1; m &= m - 1; reach |= 1ull << (wave_bcast(tg, j) - i0); }
+            }
+            wave_fence();
         }
-        wave_fence();
     }
-    if (s.stamp[bd] != ep) { s.err = true; return -1; }             // :783
-    int32_t n = 0, last = bd;
-    while (last != a) {
+    if (uni(s.stamp[pb]) != ep) { s.err = true; return -1; }        // :783
+    int32_t n = 0, last = pb;
+    while (last != pa) {
         if (n >= s.cap) { s.err = true; return -1; }
-        const int32_t pv = s.pre2[last];
-        if (s.lane == 0) { s.pathT[2 * n] = pv; s.pathT[2 * n + 1] = last; }
+        const int32_t pv = uni(s.pre2[last]);
+        if (s.lane == 0) { s.pathT[2 * n] = order[pv]; s.pathT[2 * n + 1] = (last == pb) ? bd : order[last]; }
+        n++;
+        last = pv;
+    }
+    wave_fence();
+    return n;
+}
+
+// The same DP for windows with ANY number of edges (dense graphs: a window of 30 positions has ~600 edges) - of up to 63
+// positions in every launch (the state arrays of the LDS copy serve, the copy is given up), of up to ISPR_WIDE in the launch
+// for dense graphs: the state (distance, predecessor, reached) of every window position lives in LDS, the rows are not staged at
+// all - they are one contiguous run of the topologically ordered copy and stream through the lanes 64 edges at a time; the
+// sources a block of edges belongs to (~3 of them at out-degree 21) are relaxed one after the other from registers, so a
+// source costs LDS round trips and 64 edges cost one global load.  (On global state a call took 137 us on the C5 graphs.)
+struct SelStream { Dist *dist; int32_t *excl, *vj; uint8_t *pre, *reach; };   // the state arrays of one streamed DP: X->field[i] below
+AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32_t bd, bool wl_flag, int32_t wl, int32_t pa, int32_t pb) {
+    const WS &w = *s.w;
+    const int32_t W = pb - pa;
+    const int32_t *order = w.fwd_order + s.vb;
+    s.res_lds = false;
+    wave_lds_sync();
+    const int64_t e_start = uni(w.tp_ptr[s.vb + pa]);
+    for (int32_t t = s.lane; t <= W; t += AASM_WAVE) { X->excl[t] = (int32_t)(w.tp_ptr[s.vb + pa + t] - e_start); X->reach[t] = (t == 0) ? 1 : 0; }
+    for (int32_t t = s.lane; t < W; t += AASM_WAVE) X->vj[t] = w.tp_vj[s.vb + pa + t];
+    if (s.lane == 0) { X->dist[0] = dist_zero(); X->pre[0] = 0; }
+    wave_lds_sync();
+    const int32_t T = uni(X->excl[W]);
+    int32_t t = 0;                                                   // the source whose row the stream is in
+    for (int32_t b0 = 0; b0 < T; b0 += AASM_WAVE) {
+        const int32_t idx = b0 + s.lane, bend = (T - b0 < AASM_WAVE) ? T : b0 + AASM_WAVE;
+        int32_t tg = -1, wr = 0;
+        int64_t wq = 0;
+        uint8_t fl = 0;
+        if (idx < T) {
+            const int32_t rel = w.te_tgt[e_start + idx] - pa;
+            tg = rel > W ? -1 : rel;                                 // (targets behind the window's end are never expanded and never on the path)
+            wq = w.te_wq[e_start + idx]; wr = w.te_wr[e_start + idx]; fl = w.te_fl[e_start + idx];
+        }
+        while (t < W) {
+            const int32_t r0 = uni(X->excl[t]), r1 = uni(X->excl[t + 1]);
+            if (r0 >= bend) break;                                   // the row starts behind this block
+            const int32_t e0 = r0 > b0 ? r0 : b0, e1 = r1 < bend ? r1 : bend;
+            if (e1 > e0 && uni((int32_t)X->reach[t])) {
+                const Dist cd = X->dist[t];
+                const bool to_dest_ok = !wl_flag || (uni(X->vj[t]) == wl);   // :767-773 (src / dest have vj < 0)
+                if (r0 >= b0) s.n_ispr_v++;
+                s.n_ispr_e += e1 - e0;
+                if (idx >= e0 && idx < e1 && tg >= 0 && !(tg == W && !to_dest_ok)) {
+                    const Dist nd = dist_add(cd, edge_dist(wq, wr, fl));
+                    if (!X->reach[tg] || dist_lt<QRY_SCORE_MODE>(nd, X->dist[tg])) { X->dist[tg] = nd; X->pre[tg] = (uint8_t)t; X->reach[tg] = 1; }
+                }
+                wave_lds_sync();
+            }
+            if (r1 <= bend) t++; else break;                         // (the row goes on in the next block)
+        }
+    }
+    if (!uni((int32_t)X->reach[W])) { s.err = true; return -1; }     // :783
+    int32_t n = 0, last = W;
+    while (last != 0) {
+        if (n >= s.cap) { s.err = true; return -1; }
+        const int32_t pv = uni((int32_t)X->pre[last]);
+        if (s.lane == 0) { s.pathT[2 * n] = order[pa + pv]; s.pathT[2 * n + 1] = (last == W) ? bd : order[pa + last]; }
         n++;
         last = pv;
     }
@@ -2768,10 +2852,18 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
     const int32_t W = pb - pa;
     if (W <= 0) { s.err = true; return -1; }
-    if (W > ISPR_CW) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+    if (W > ISPR_CW) {
+        if (!(s.wide && W <= ISPR_WIDE)) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+        SelWide *X = (SelWide *)s.wide;
+        const SelStream st{X->dist, X->excl, X->vj, X->pre, X->reach};
+        return sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+    }
     SPROF(s, 5);
     SelLds *L = (SelLds *)s.lds;
-    if (!(s.cw_pa >= 0 && pa >= s.cw_pa && pb <= s.cw_pa + s.cw_n) && !sel_cw_fill(s, pa, pb)) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+    if (!(s.cw_pa >= 0 && pa >= s.cw_pa && pb <= s.cw_pa + s.cw_n) && !sel_cw_fill(s, pa, pb)) {   // too many edges for the copy (which is given up: cw_pa = -1)
+        const SelStream st{L->dist, L->excl, L->vj, (uint8_t *)L->pre, L->reach};
+        return sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+    }
     const int32_t o = pa - s.cw_pa;                                  // window position t = cached position o + t
     SPROF(s, 2);                                                     // ISPR staging
     if (W == 2) {
@@ -3069,6 +3161,7 @@ AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
     s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
     s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
     s.cw_pa = -1; s.cw_n = 0;
+    s.wide = (k.lds_bytes >= (int)(AASM_SEL_LDS_BYTES + AASM_SELW_LDS_BYTES)) ? k.lds + AASM_SEL_LDS_BYTES : nullptr;
 }
 AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
     if (s.lane == 0) {

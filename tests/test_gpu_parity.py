@@ -271,3 +271,30 @@ def test_reserved_workspace_serves_the_next_solve(T):
     assert T.diff_outputs(want, res.fetch()) == []
     res.close(); db.close()
     assert api.reserve_workspace(99, 1 << 20) != 0          # no such device: an error code, not a crash
+
+
+#          contigs, records, seed, K, dense, dup_every, shuffle
+WIDE = [(4, 600, 31, 16, True, 0, False),      # C5 shape: most window DPs too dense for the 63-position LDS copy
+        (2, 1500, 7, 16, True, 0, False),      # wider windows (some beyond 255 positions: global state)
+        (6, 1000, 21, 4, False, 0, False),     # sparse: the launch is forced, every wide call is a window of 64 ... 255 positions
+        (5, 400, 5, 10000, False, 3, True),
+        (3, 300, 8, 10000, True, 0, False)]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: "c%dx%d_s%d_k%d_%s%s" % (c[0], c[1], c[2], c[3], "D" if c[4] else "S", "_dup%d" % c[5] if c[5] else ""))
+def test_wide_window_conversion_launch_matches_oracle(T, case):
+    """K9's launch with the wide-window LDS state (what dense batches get) against the oracle, and against the plain launch
+    on the same batch - outputs and the debug counters of the window DP (vertices and edges it expanded)."""
+    nc, nr, seed, K, dense, dup, shuf = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf)
+    want = T.oracle_solve(hb, K)
+    db = api.DeviceBatch(hb)
+    outs = []
+    for wide in (True, False):
+        res = db.solve(max_paths=K, sel_wide=wide)
+        outs.append(res.fetch())
+        res.close()
+    db.close()
+    assert T.diff_outputs(want, outs[0]) == []
+    assert T.diff_outputs(want, outs[1], stats=False) == []
