@@ -2158,6 +2158,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     KProfNone kp;
+    for (int i_ = 0; i_ < 8; i_++) kp.acc[i_] = 0;
     int32_t u = (wv == 0) ? dest : -1, hu = -1;
     int64_t guard = 0;
     while (true) {
@@ -2262,7 +2263,8 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     block_barrier();
     MWP_STAMP(mwp_t3);
-    if (k.tid == 0 && w.prof_heap) { int64_t *pp = w.prof_heap + c * 8; pp[0] = mwp_t1 - mwp_t0; pp[1] = mwp_t2 - mwp_t1; pp[2] = mwp_t3 - mwp_t2; pp[3] = H; pp[4] = nv; pp[5] = pp[6] = pp[7] = 0; }
+    if (k.tid == 0 && w.prof_heap) { int64_t *pp = w.prof_heap + c * 8; pp[0] = mwp_t1 - mwp_t0; pp[1] = mwp_t2 - mwp_t1; pp[2] = mwp_t3 - mwp_t2; pp[3] = H; pp[4] = nv; }
+    if (k.lane == 0 && w.prof_heap) { atomic_add(&w.prof_heap[c * 8 + 5], kp.acc[6]); atomic_add(&w.prof_heap[c * 8 + 6], kp.acc[7]); }   // chase steps served by global memory / by the ring, all waves
 #endif
 }
 
