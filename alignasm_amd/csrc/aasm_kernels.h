@@ -1710,6 +1710,78 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     t.w = t.z >= 0 ? w.sp_best[vb + t.z] : -1;
     w.tnx[gv] = t;
 }
+// The same for dense graphs (rows of tens to hundreds of edges): a wave takes AASM_WAVE consecutive rows - one contiguous run of
+// edges - in chunks of 64 edges, lanes = edges.  What is sequential per row becomes ballots: the tree edge is the lowest
+// candidate lane of the row's stretch of the chunk, unless an earlier chunk had it (seen[row]); a kept edge's place is the row's
+// count so far (cnt[row], in LDS) plus the kept lanes of its row below it.
+struct SideLds { int64_t ptr[AASM_WAVE_MAX + 1], vb[AASM_WAVE_MAX]; Dist du[AASM_WAVE_MAX]; int32_t bu[AASM_WAVE_MAX], cnt[AASM_WAVE_MAX], seen[AASM_WAVE_MAX]; };
+#define AASM_SIDE_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + AASM_WAVE_MAX * (8 + 32 + 12) + 16)
+static_assert(sizeof(SideLds) <= AASM_SIDE_LDS_BYTES, "LDS budget");
+AASM_DEV void kb_sidetrack_w(const KCtx &k, const WS &w) {          // wave per AASM_WAVE vertices
+    SideLds *L = (SideLds *)k.lds;
+    const int64_t row0 = k.bid * AASM_WAVE;
+    if (row0 >= w.VT) return;
+    const int32_t nrows = (int32_t)((w.VT - row0 < AASM_WAVE) ? (w.VT - row0) : AASM_WAVE);
+    for (int32_t t = k.lane; t <= nrows; t += AASM_WAVE) L->ptr[t] = w.rowptr[row0 + t];
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) {
+        L->vb[t] = w.voff[w.v_ctg[row0 + t]]; L->du[t] = w.sp_d[row0 + t]; L->bu[t] = w.sp_best[row0 + t]; L->cnt[t] = 0; L->seen[t] = 0;
+    }
+    wave_lds_sync();
+    const int64_t seg0 = L->ptr[0], seg1 = L->ptr[nrows];
+    bool bad = false;
+    int32_t bad_row = 0;
+    for (int64_t c0 = seg0; c0 < seg1; c0 += AASM_WAVE) {
+        const int64_t e = c0 + k.lane;
+        const bool act = e < seg1;
+        int32_t row = 0, hv = -1;
+        Dist cc = dist_zero();
+        bool keepable = false, cand = false;
+        if (act) {
+            int32_t lo = 0, hi = nrows;                              // ptr[lo] <= e < ptr[hi]
+            while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L->ptr[mid] <= e) lo = mid; else hi = mid; }
+            row = lo;
+            hv = w.e_col[e];
+            const Dist dv = w.sp_d[L->vb[row] + hv];
+            if (!dist_is_max(dv)) {                                  // :204-205
+                keepable = true;
+                cc = dist_sub(dist_add(edge_dist(w.e_wq[e], w.e_wr[e], w.e_fl[e]), dv), L->du[row]);
+                cand = hv == L->bu[row] && dist_eq(cc, dist_zero());
+            }
+        }
+        // my row's stretch of this chunk: lanes [ls, le)
+        const int64_t ps = act ? L->ptr[row] : 0, pe = act ? L->ptr[row + 1] : 0;
+        const int ls = ps > c0 ? (int)(ps - c0) : 0, le = (pe - c0 < AASM_WAVE) ? (int)(pe - c0) : AASM_WAVE;
+        const uint64_t rowmask = act ? (lanemask_lt(le) & ~lanemask_lt(ls)) : 0ull;
+        const uint64_t mc = wave_ballot(cand) & rowmask;
+        const bool tree = cand && L->seen[row] == 0 && (ffs64(mc) - 1) == k.lane;   // :207-210: the first such edge of the list
+        const bool kept = keepable && !tree;
+        const uint64_t mk = wave_ballot(kept) & rowmask;
+        const int32_t base = act ? L->cnt[row] : 0;
+        wave_lds_sync();                                             // every lane has read seen[] / cnt[] of the chunk's rows
+        if (kept) {
+            const Dist du = L->du[row];
+            if (!dist_is_max(du) && cc.qry + cc.ref < 0) { bad = true; bad_row = row; }
+            cc.pad = hv;
+            w.st_cost[ps + base + popc64(mk & lanemask_lt(k.lane))] = cc;
+        }
+        if (act && k.lane == ls) {                                   // the first lane of a row's stretch books for the row
+            if (mc) L->seen[row] = 1;
+            L->cnt[row] = base + popc64(mk);
+        }
+        wave_lds_sync();
+    }
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) {
+        w.st_n[row0 + t] = L->cnt[t];
+        const int64_t vb = L->vb[t];
+        I4 j;                                                        // the next four vertices along best[] (as kb_sidetrack)
+        j.x = L->bu[t];
+        j.y = j.x >= 0 ? w.sp_best[vb + j.x] : -1;
+        j.z = j.y >= 0 ? w.sp_best[vb + j.y] : -1;
+        j.w = j.z >= 0 ? w.sp_best[vb + j.z] : -1;
+        w.tnx[row0 + t] = j;
+    }
+    if (bad) w.status[w.v_ctg[row0 + bad_row]] = -6;                 // must not happen (see kb_sidetrack)
+}
 // K7 pre-pass 2, thread per vertex u: what the heap wave reads per vertex, 32 bytes:
 //   vhdr  = {so, #keys, #children, first child}          so = start of u's keys, relative to the contig's first edge
 //   vhdr2 = {child-list start (2 words), so(first child), #keys(first child)}
