@@ -32,7 +32,6 @@ struct KCtx {
     int64_t nblocks;
     int lane;         // tid % AASM_WAVE
     char *lds;        // per-block LDS scratch (AASM_LDS_BYTES), 16-byte aligned
-    int lds_bytes = 0; // how much of it this launch declared (kernels with an optional larger working set look at it)
 };
 #define AASM_LDS_BYTES 6144   // 6 KB per single-wave block -> 26 blocks per CU by LDS
 

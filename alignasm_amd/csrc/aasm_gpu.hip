@@ -38,7 +38,7 @@ namespace aasm {
     __global__ void __launch_bounds__(TPB, WAVES) name(WS w) {                                    \
         __shared__ __attribute__((aligned(16))) char smem[BYTES];                             \
         KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
-               (int)(threadIdx.x & 63), smem, (int)(BYTES)};                                  \
+               (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }
 AASM_DEF_KERNEL(aasm_k0_cs_ranges, KN_CS_RANGES, 256)
@@ -78,7 +78,6 @@ AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
 AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
 AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES, 5)
-AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert_w, KN_SEL_CONVERT_W, 64, AASM_SEL_LDS_BYTES + AASM_SELW_LDS_BYTES, 2)
 AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k9_topo_fill, KN_TOPO_FILL, 64)
@@ -419,7 +418,7 @@ struct GpuBackend {
             L(KN_CHILDREN, aasm_k7_children)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
-            L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_CONVERT_W, aasm_k9_sel_convert_w) L(KN_SEL_FINAL, aasm_k9_sel_final)
+            L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L
             default: break;
         }

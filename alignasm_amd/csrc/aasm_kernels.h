@@ -17,6 +17,7 @@
 // contig's topological order, and the lanes fan out over the adjacency row of the
 // vertex being processed (distinct targets per row -> conflict-free read-modify-write).
 #pragma once
+#include <cstddef>
 #include "aasm_dev.h"
 
 namespace aasm {
@@ -2580,7 +2581,6 @@ struct SelCtx {
     bool err, res_lds;
     int lane;
     char *lds;
-    char *wide;                      // the wide-window state (SelWide) behind the SelLds block, or nullptr: the launch did not declare it
     int64_t n_ispr_e, n_ispr_v, n_path_e, n_out_e;   // byte-model counters
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     int64_t kp_t0, kp_acc[8];
@@ -2617,11 +2617,11 @@ struct SelLds {
 };
 #define AASM_SEL_LDS_BYTES 7488
 static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
-// ... and of the launch for dense graphs (aasm_k9_sel_convert_w), behind it: the DP state of a window of up to ISPR_WIDE positions
+// A window DP of 64 ... ISPR_WIDE positions keeps its state in the same bytes: it OVERLAYS the front of the block (the LDS copy of
+// the CSR and the narrow DP's arrays, 5 632 bytes - the copy is given up for the call), so it needs no launch of its own.
 #define ISPR_WIDE 127
 struct SelWide { Dist dist[ISPR_WIDE + 1]; int32_t excl[ISPR_WIDE + 2]; int32_t vj[ISPR_WIDE + 1]; uint8_t pre[ISPR_WIDE + 1]; uint8_t reach[ISPR_WIDE + 1]; };
-#define AASM_SELW_LDS_BYTES 5392
-static_assert(sizeof(SelWide) <= AASM_SELW_LDS_BYTES, "LDS budget");
+static_assert(sizeof(SelWide) <= offsetof(SelLds, res), "the wide DP state must end before the result / path-window arrays");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
     SelLds *L = (SelLds *)s.lds;
@@ -2799,6 +2799,7 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
     const int32_t ep = ++s.epoch;
     const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
     s.res_lds = false;
+    SPROF(s, 5);
     if (s.lane == 0) { s.dist2[pa] = dist_zero(); s.pre2[pa] = -1; s.stamp[pa] = ep; }
     wave_fence();
     for (int32_t i0 = pa; i0 < pb; i0 += AASM_WAVE) {
@@ -2838,12 +2839,12 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
         last = pv;
     }
     wave_fence();
+    SPROF(s, 7);                                                     // (diagnostic build: the global-state DP's share)
     return n;
 }
 
-// The same DP for windows with ANY number of edges (dense graphs: a window of 30 positions has ~600 edges) - of up to 63
-// positions in every launch (the state arrays of the LDS copy serve, the copy is given up), of up to ISPR_WIDE in the launch
-// for dense graphs: the state (distance, predecessor, reached) of every window position lives in LDS, the rows are not staged at
+// The same DP for windows with ANY number of edges (dense graphs: a window of 30 positions has ~600 edges) and up to ISPR_WIDE
+// positions (the LDS copy is given up for the call: its arrays, or the SelWide overlay, hold the state): the state (distance, predecessor, reached) of every window position lives in LDS, the rows are not staged at
 // all - they are one contiguous run of the topologically ordered copy and stream through the lanes 64 edges at a time; the
 // sources a block of edges belongs to (~3 of them at out-degree 21) are relaxed one after the other from registers, so a
 // source costs LDS round trips and 64 edges cost one global load.  (On global state a call took 137 us on the C5 graphs.)
@@ -2853,6 +2854,7 @@ AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32
     const int32_t W = pb - pa;
     const int32_t *order = w.fwd_order + s.vb;
     s.res_lds = false;
+    SPROF(s, 5);
     wave_lds_sync();
     const int64_t e_start = uni(w.tp_ptr[s.vb + pa]);
     for (int32_t t = s.lane; t <= W; t += AASM_WAVE) { X->excl[t] = (int32_t)(w.tp_ptr[s.vb + pa + t] - e_start); X->reach[t] = (t == 0) ? 1 : 0; }
@@ -2899,6 +2901,7 @@ AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32
         last = pv;
     }
     wave_fence();
+    SPROF(s, 4);                                                     // (diagnostic build: the streamed DP's share)
     return n;
 }
 
@@ -2955,8 +2958,9 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     const int32_t W = pb - pa;
     if (W <= 0) { s.err = true; return -1; }
     if (W > ISPR_CW) {
-        if (!(s.wide && W <= ISPR_WIDE)) return sel_ispr_generic(s, a, bd, wl_flag, wl);
-        SelWide *X = (SelWide *)s.wide;
+        if (W > ISPR_WIDE) return sel_ispr_generic(s, a, bd, wl_flag, wl);
+        SelWide *X = (SelWide *)s.lds;                               // over the LDS copy and the narrow DP's arrays
+        s.cw_pa = -1;
         const SelStream st{X->dist, X->excl, X->vj, X->pre, X->reach};
         return sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
     }
@@ -3263,7 +3267,6 @@ AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
     s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
     s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
     s.cw_pa = -1; s.cw_n = 0;
-    s.wide = (k.lds_bytes >= (int)(AASM_SEL_LDS_BYTES + AASM_SELW_LDS_BYTES)) ? k.lds + AASM_SEL_LDS_BYTES : nullptr;
 }
 AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
     if (s.lane == 0) {

@@ -24,7 +24,7 @@ enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
-    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL, KN_SEL_CONVERT_W
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -71,7 +71,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_TOPO_FILL: kb_topo_fill(k, w); break;
         case KN_SEL_PLAN: kb_sel_plan(k, w); break;
         case KN_SEL_PLANFILL: kb_sel_planfill(k, w); break;
-        case KN_SEL_CONVERT: case KN_SEL_CONVERT_W: kb_sel_convert(k, w); break;
+        case KN_SEL_CONVERT: kb_sel_convert(k, w); break;
         case KN_SEL_FINAL: kb_sel_final(k, w); break;
         default: break;
     }
@@ -333,11 +333,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             A(cv_dist2, Dist, SV, "cv_dist2"); A(cv_pre2, int32_t, SV, "cv_pre2"); AZ(cv_stamp, int32_t, SV, "cv_stamp");
             CHECK_ALLOC();
             be.phase_begin(AASM_PH_SELECT);
-            // dense graphs with few conversions in flight (giant contigs: the chain of one conversion is what counts): the launch with the
-            // wide-window LDS state - window DPs of 64 ... 127 positions stay in LDS, at 12 instead of 20 waves per CU.  A batch that fills
-            // the chip is faster in the plain launch (C5 share: 14.9 against 15.6 ms).  reserved[0] bit 5 forces it (tests)
-            const bool wide = (sz.ET > 6 * sz.VT && NCONV <= 3072) || (opts.reserved[0] & 32);
-            be.launch(wide ? KN_SEL_CONVERT_W : KN_SEL_CONVERT, NCONV, AASM_WAVE, w);
+            be.launch(KN_SEL_CONVERT, NCONV, AASM_WAVE, w);
             be.phase_end(AASM_PH_SELECT);
         }
         be.phase_begin(AASM_PH_FINAL);

@@ -90,8 +90,7 @@ typedef struct aasm_opts {
                                 * [0] bit 0: force the sequential selection kernel; bit 1: build every contig's heaps with the
                                 *            several-waves-per-contig kernel; bit 2: none of them (default: by graph density);
                                 *            bit 3: K8 on the d-ary heap queue (cross-check of the default sorted-front / sorted-runs queue);
-                                *            bit 4: K8 with the 40-entry front it takes for batches of more than 3 584 contigs;
-                                *            bit 5: K9's conversions in the launch with the wide-window LDS state (dense graphs get it by themselves)
+                                *            bit 4: K8 with the 40-entry front it takes for batches of more than 3 584 contigs
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);

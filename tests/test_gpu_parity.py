@@ -274,27 +274,18 @@ def test_reserved_workspace_serves_the_next_solve(T):
 
 
 #          contigs, records, seed, K, dense, dup_every, shuffle
-WIDE = [(4, 600, 31, 16, True, 0, False),      # C5 shape: most window DPs too dense for the 63-position LDS copy
-        (2, 1500, 7, 16, True, 0, False),      # wider windows (some beyond 255 positions: global state)
-        (6, 1000, 21, 4, False, 0, False),     # sparse: the launch is forced, every wide call is a window of 64 ... 255 positions
-        (5, 400, 5, 10000, False, 3, True),
+WIDE = [(4, 600, 31, 16, True, 0, False),      # C5 shape: most window DPs too dense for the 63-position LDS copy (streamed rows)
+        (2, 1500, 7, 16, True, 0, False),      # wider windows: 64 ... 127 positions on the LDS overlay, beyond that global state
         (3, 300, 8, 10000, True, 0, False)]
 
 
 @pytest.mark.parametrize("case", WIDE, ids=lambda c: "c%dx%d_s%d_k%d_%s%s" % (c[0], c[1], c[2], c[3], "D" if c[4] else "S", "_dup%d" % c[5] if c[5] else ""))
-def test_wide_window_conversion_launch_matches_oracle(T, case):
-    """K9's launch with the wide-window LDS state (what dense batches get) against the oracle, and against the plain launch
-    on the same batch - outputs and the debug counters of the window DP (vertices and edges it expanded)."""
+def test_wide_and_dense_window_dps_match_oracle(T, case):
+    """K9's three window-DP forms beside the LDS copy (rows streamed over LDS state for <= 63 and for <= 127 positions, global
+    state beyond) on dense graphs, where they carry most of the work: outputs and intermediates against the oracle."""
     nc, nr, seed, K, dense, dup, shuf = case
     api = T.api()
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf)
     want = T.oracle_solve(hb, K)
-    db = api.DeviceBatch(hb)
-    outs = []
-    for wide in (True, False):
-        res = db.solve(max_paths=K, sel_wide=wide)
-        outs.append(res.fetch())
-        res.close()
-    db.close()
-    assert T.diff_outputs(want, outs[0]) == []
-    assert T.diff_outputs(want, outs[1], stats=False) == []
+    got = api.solve_batch(hb, max_paths=K)
+    assert T.diff_outputs(want, got) == []
