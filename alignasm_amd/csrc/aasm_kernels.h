@@ -2349,12 +2349,19 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
             return fb[j] + (x - rsk[j]);
         };
         // a wave takes the regions wv, wv + nwaves, ... whole (no search for the region of a node), its lanes the nodes of a region
-        for (int32_t i = wv; i < nv; i += nwaves) {
-            const int32_t n_i = uni(used[uni(order[i])]), r0 = uni(rsk[i]), f0 = uni(fb[i]);
-            for (int32_t t = k.lane; t < n_i; t += AASM_WAVE) {
-                HNode nd = hs.nodes[r0 + t];
-                nd.left = translate(nd.left, i); nd.right = translate(nd.right, i);
-                fin[f0 + t] = nd;
+        for (int32_t ib = wv; ib < nv; ib += nwaves * AASM_WAVE) {  // (the sizes and final starts of its next 64 regions: two loads, not two per region)
+            const int32_t i_l = ib + k.lane * nwaves;
+            int32_t n_l = 0, f_l = 0;
+            if (i_l < nv) { n_l = used[order[i_l]]; f_l = fb[i_l]; }
+            for (int32_t q = 0; q < AASM_WAVE; q++) {
+                const int32_t i = ib + q * nwaves;
+                if (i >= nv) break;
+                const int32_t n_i = wave_bcast(n_l, q), f0 = wave_bcast(f_l, q), r0 = uni(rsk[i]);
+                for (int32_t t = k.lane; t < n_i; t += AASM_WAVE) {
+                    HNode nd = hs.nodes[r0 + t];
+                    nd.left = translate(nd.left, i); nd.right = translate(nd.right, i);
+                    fin[f0 + t] = nd;
+                }
             }
         }
         for (int32_t i = k.tid; i < nv; i += k.nthreads) { const int32_t v = order[i]; h[v] = translate(h[v], -1); }
