@@ -2884,16 +2884,22 @@ AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32
             const int32_t r0 = uni(X->excl[t]), r1 = uni(X->excl[t + 1]);
             if (r0 >= bend) break;                                   // the row starts behind this block
             const int32_t e0 = r0 > b0 ? r0 : b0, e1 = r1 < bend ? r1 : bend;
-            if (e1 > e0 && uni((int32_t)X->reach[t])) {
-                const Dist cd = X->dist[t];
-                const bool to_dest_ok = !wl_flag || (uni(X->vj[t]) == wl);   // :767-773 (src / dest have vj < 0)
-                if (r0 >= b0) s.n_ispr_v++;
-                s.n_ispr_e += e1 - e0;
-                if (idx >= e0 && idx < e1 && tg >= 0 && !(tg == W && !to_dest_ok)) {
-                    const Dist nd = dist_add(cd, edge_dist(wq, wr, fl));
-                    if (!X->reach[tg] || dist_lt<QRY_SCORE_MODE>(nd, X->dist[tg])) { X->dist[tg] = nd; X->pre[tg] = (uint8_t)t; X->reach[tg] = 1; }
+            if (e1 > e0) {
+                // the source's state and - the heads are in registers - the state of every head of the block, in ONE LDS round trip
+                const int32_t tgc = tg >= 0 ? tg : 0;
+                Dist cd = X->dist[t], td = X->dist[tgc];
+                int32_t sr = X->reach[t], tr = X->reach[tgc], svj = X->vj[t];
+                keep_load(cd.qry); keep_load(td.qry); keep_load(sr); keep_load(tr); keep_load(svj);
+                if (uni(sr)) {
+                    const bool to_dest_ok = !wl_flag || (uni(svj) == wl);    // :767-773 (src / dest have vj < 0)
+                    if (r0 >= b0) s.n_ispr_v++;
+                    s.n_ispr_e += e1 - e0;
+                    if (idx >= e0 && idx < e1 && tg >= 0 && !(tg == W && !to_dest_ok)) {
+                        const Dist nd = dist_add(cd, edge_dist(wq, wr, fl));
+                        if (!tr || dist_lt<QRY_SCORE_MODE>(nd, td)) { X->dist[tg] = nd; X->pre[tg] = (uint8_t)t; X->reach[tg] = 1; }
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
             }
             if (r1 <= bend) t++; else break;                         // (the row goes on in the next block)
         }
