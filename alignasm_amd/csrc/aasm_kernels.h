@@ -82,6 +82,7 @@ struct WS {
     uint8_t *notalt;
     int32_t *mark_time;                               // per sorted record: first conversion ordinal that marked it
     // ---- parallel conversions (one wave per converted path)
+    int32_t *plan_kk;                    // [C * 2 * SEL_PLAN_KEEP] {walk, kind} of a contig's first conversions, from kb_sel_plan to kb_sel_planfill
     int32_t *nconv, *cv_ctg, *cv_k, *cv_ord, *cv_kind, *cv_szr, *cv_szv, *cv_n, *cv_err, *cv_path, *cv_pre2, *cv_stamp;
     int64_t *conv_off, *cv_roff, *cv_voff, *cv_cov;
     OutElem *cv_out;
@@ -3207,18 +3208,21 @@ AASM_DEV bool sel_has_graph(const WS &w, int64_t c) {
 // prefix of paths equal to the best one (:1596-1611); alt candidates are the paths with fewer
 // anomalies (:1613-1649), visited in index order because the "best ratio so far" is sequential.
 // fill == false only counts; fill == true writes the conversion records at conv_off[c].
+#define SEL_PLAN_KEEP 64
 AASM_DEV int32_t sel_plan_wave(const KCtx &k, const WS &w, int64_t c, bool fill) {
     const int32_t found = w.kfound[c];
     const Dist *kd = w.kd + c * (int64_t)w.K;
     const Dist mind = kd[0];
     const int64_t j0 = fill ? w.conv_off[c] : 0;
     const int32_t N = (int32_t)(w.rec_off[c + 1] - w.rec_off[c]), V = w.ctgV[c];
-    auto put = [&](int32_t ord, int32_t kidx, int32_t kind) {
+    int32_t *keep = w.plan_kk + c * (int64_t)(2 * SEL_PLAN_KEEP);
+    auto put = [&](int32_t ord, int32_t kidx, int32_t kind) {       // the counting pass remembers the first SEL_PLAN_KEEP, the filling pass writes the records
+        if (!fill) { if (ord < SEL_PLAN_KEEP) { keep[2 * ord] = kidx; keep[2 * ord + 1] = kind; } return; }
         const int64_t j = j0 + ord;
         w.cv_ctg[j] = (int32_t)c; w.cv_k[j] = kidx; w.cv_ord[j] = ord; w.cv_kind[j] = kind; w.cv_szr[j] = N + 2; w.cv_szv[j] = V;
     };
     int32_t n = 0;
-    if (fill && k.lane == 0) put(0, 0, 0);
+    if (k.lane == 0) put(0, 0, 0);
     n = 1;
     for (int32_t base = 1; base < found; base += AASM_WAVE) {       // tie run
         const int32_t idx = base + k.lane;
@@ -3226,7 +3230,7 @@ AASM_DEV int32_t sel_plan_wave(const KCtx &k, const WS &w, int64_t c, bool fill)
         const bool eq = in && dist_sel_equal(mind, kd[idx]);
         const uint64_t m = wave_ballot(eq), full = wave_ballot(in);
         const int lead = (~m == 0ull) ? 64 : (ffs64(~m) - 1);
-        if (fill && k.lane < lead) put(n + k.lane, idx, 1);
+        if (k.lane < lead) put(n + k.lane, idx, 1);
         n += lead;
         if (lead < popc64(full)) break;
     }
@@ -3256,7 +3260,7 @@ AASM_DEV int32_t sel_plan_wave(const KCtx &k, const WS &w, int64_t c, bool fill)
                     int32_t kind = -1;
                     if (ans_idx == -1 || up * ans_down < down * ans_up) { ans_up = up; ans_down = down; ans_idx = i; ans_d = dd; kind = 2; }
                     else if (dist_sel_equal(dd, ans_d)) kind = 3;
-                    if (kind >= 0) { if (fill && k.lane == 0) put(n, i, kind); n++; }
+                    if (kind >= 0) { if (k.lane == 0) put(n, i, kind); n++; }
                 }
             }
         }
@@ -3270,7 +3274,16 @@ AASM_DEV void kb_sel_plan(const KCtx &k, const WS &w) {             // one wave 
 }
 AASM_DEV void kb_sel_planfill(const KCtx &k, const WS &w) {         // one wave per contig
     const int64_t c = k.bid;
-    if (sel_has_graph(w, c)) sel_plan_wave(k, w, c, true);
+    if (!sel_has_graph(w, c)) return;
+    const int32_t n = w.nconv[c];
+    if (n > SEL_PLAN_KEEP) { sel_plan_wave(k, w, c, true); return; } // (more conversions than the counting pass kept: walk the K distances again)
+    const int32_t N = (int32_t)(w.rec_off[c + 1] - w.rec_off[c]), V = w.ctgV[c];
+    const int32_t *keep = w.plan_kk + c * (int64_t)(2 * SEL_PLAN_KEEP);
+    const int64_t j0 = w.conv_off[c];
+    for (int32_t t = k.lane; t < n; t += AASM_WAVE) {
+        const int64_t j = j0 + t;
+        w.cv_ctg[j] = (int32_t)c; w.cv_k[j] = keep[2 * t]; w.cv_ord[j] = t; w.cv_kind[j] = keep[2 * t + 1]; w.cv_szr[j] = N + 2; w.cv_szv[j] = V;
+    }
 }
 
 AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {

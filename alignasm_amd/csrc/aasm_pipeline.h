@@ -300,7 +300,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     // sequential one-wave-per-contig kernel when the per-conversion scratch would not fit
     // (tie-heavy inputs at large K) or when opts.reserved[0] bit 0 asks for it (tests).
     A(mark_time, int32_t, R, "mark_time");
-    AZ(nconv, int32_t, C, "nconv"); A(conv_off, int64_t, C + 1, "conv_off");
+    AZ(nconv, int32_t, C, "nconv"); A(conv_off, int64_t, C + 1, "conv_off"); A(plan_kk, int32_t, C * 2 * SEL_PLAN_KEEP, "plan_kk");
     CHECK_ALLOC();
     be.fill_byte(w.mark_time, 0x7F, sizeof(int32_t) * (size_t)R);
     bool sequential = (opts.reserved[0] & 1) != 0;
