@@ -118,7 +118,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -921,6 +921,7 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
     if (unconn) atomic_add(&w.counters[CNT_UNCONN], (int64_t)1);
 }
 
+#define REV_ORD_MAXV 12288               // most vertices of a contig that kb_rev_fill_ord can count in LDS
 AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread per contig
     const int64_t c = k.bid * k.nthreads + k.tid;
     if (c >= w.C) return;
@@ -933,6 +934,7 @@ AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread pe
         return;
     }
     w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
+    if (N + P + 2 > REV_ORD_MAXV) atomic_max_i64(&w.counters[CNT_MAXV], N + P + 2);   // (kb_rev_fill_ord keeps a counter per vertex of a contig in LDS)
     if (N > 4096) atomic_max_i64(&w.counters[CNT_MAXN], N);         // longest contig of the batch (K8 picks its queue form by it; short ones need not report)
 }
 
@@ -1267,6 +1269,69 @@ AASM_DEV void kb_rev_fill_w(const KCtx &k, const WS &w) {           // wave per 
         const int32_t cur = atomic_add(&w.rcur[vb + hv], (int32_t)1);
         w.r_e[rp + cur] = (int32_t)(e - L->eb[lo]);
         w.tmp_pk[rp + cur] = pack_in_edge(u, w.e_wq[e], w.e_wr[e], w.e_fl[e]);
+    }
+}
+
+// Dense batches whose contigs have at most REV_ORD_MAXV vertices: the in-lists come out IN ORDER from one pass per contig, so
+// there is nothing to put in order afterwards (kb_rev_place: an entry's rank among its list, 2.4 ms on the C5 share; the atomics
+// of kb_rev_fill_w 2.2).  One wave per contig walks the contig's edges in edge order, 64 per step; an edge's place in its head's
+// in-list is the number of edges with that head so far: a counter per vertex in LDS plus - heads are distinct inside a row -
+// nothing else, if the rows of a step take their turns one after the other (a step of 64 edges holds ~3 rows at out-degree 21).
+#define REV_ORD_U 4
+struct RevOrdLds { int64_t ptr[AASM_WAVE_MAX + 1]; uint16_t cnt[REV_ORD_MAXV]; };
+#define AASM_REVO_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REV_ORD_MAXV * 2)
+static_assert(sizeof(RevOrdLds) <= AASM_REVO_LDS_BYTES, "LDS budget");
+AASM_DEV void kb_rev_fill_ord(const KCtx &k, const WS &w) {         // one wave per contig
+    RevOrdLds *L = (RevOrdLds *)k.lds;
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    const int64_t vb = w.voff[c], e_base = w.rowptr[vb];
+    for (int64_t t = k.lane; t < V; t += AASM_WAVE) L->cnt[t] = 0;
+    for (int64_t row0 = 0; row0 < V; row0 += AASM_WAVE) {            // tiles of 64 rows: their edges are one contiguous run
+        const int32_t nrows = (int32_t)((V - row0 < AASM_WAVE) ? (V - row0) : AASM_WAVE);
+        wave_lds_sync();
+        for (int32_t t = k.lane; t <= nrows; t += AASM_WAVE) L->ptr[t] = w.rowptr[vb + row0 + t];
+        wave_lds_sync();
+        const int64_t seg0 = L->ptr[0], seg1 = L->ptr[nrows];
+        for (int64_t g0 = seg0; g0 < seg1; g0 += REV_ORD_U * AASM_WAVE) {   // REV_ORD_U steps of 64 edges per pair of global round trips
+            int32_t rows[REV_ORD_U], hvs[REV_ORD_U], wrs[REV_ORD_U];
+            int64_t rps[REV_ORD_U], wqs[REV_ORD_U];
+            uint8_t fls[REV_ORD_U];
+            AASM_UNROLL
+            for (int u = 0; u < REV_ORD_U; u++) {
+                const int64_t e = g0 + u * AASM_WAVE + k.lane;
+                rows[u] = 0; hvs[u] = 0; wrs[u] = 0; wqs[u] = 0; fls[u] = 0;
+                if (e < seg1) {
+                    int32_t lo = 0, hi = nrows;                      // ptr[lo] <= e < ptr[hi]
+                    while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L->ptr[mid] <= e) lo = mid; else hi = mid; }
+                    rows[u] = lo;
+                    hvs[u] = w.e_col[e]; wqs[u] = w.e_wq[e]; wrs[u] = w.e_wr[e]; fls[u] = w.e_fl[e];
+                }
+            }
+            AASM_UNROLL
+            for (int u = 0; u < REV_ORD_U; u++) { rps[u] = 0; if (g0 + u * AASM_WAVE + k.lane < seg1) rps[u] = w.rptr[vb + hvs[u]]; }
+            AASM_UNROLL
+            for (int u = 0; u < REV_ORD_U; u++) {
+                const int64_t c0 = g0 + u * AASM_WAVE, e = c0 + k.lane;
+                if (c0 >= seg1) break;
+                const bool act = e < seg1;
+                const int32_t row = rows[u], hv = hvs[u];
+                // the rows of this step, first to last: the lanes of a row have distinct heads
+                const int32_t row_first = uni(row), row_last = wave_bcast(row, (int)((seg1 - c0 < AASM_WAVE ? seg1 - c0 : AASM_WAVE) - 1));
+                for (int32_t r = row_first; r <= row_last; r++) {
+                    if (act && row == r) {
+                        const int32_t at = L->cnt[hv];
+                        L->cnt[hv] = (uint16_t)(at + 1);
+                        const int64_t pos = rps[u] + at;
+                        w.r_e[pos] = (int32_t)(e - e_base);
+                        const I4 rec = pack_in_edge((int32_t)(row0 + row), wqs[u], wrs[u], fls[u]);
+                        w.tmp_pk[pos] = rec; w.r_pk[pos] = rec;      // (short lists reach r_pk through kb_rev_hdr's register sort - a no-op here -, long ones are read there directly)
+                    }
+                    wave_lds_sync();
+                }
+            }
+        }
     }
 }
 

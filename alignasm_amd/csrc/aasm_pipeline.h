@@ -22,7 +22,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
@@ -45,6 +45,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_REV_FILL_W: kb_rev_fill_w(k, w); break;
+        case KN_REV_FILL_ORD: kb_rev_fill_ord(k, w); break;
         case KN_SORT_ROWS_REV: kb_rev_place(k, w); break;
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep<AASM_WAVE>(k, w); break;
@@ -194,7 +195,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         CHECK_ALLOC();
         be.launch(KN_ROW_COUNT, cdiv(VT, 256), 256, w);
         be.scan_i32(w.deg, VT, w.rowptr);
-        const int64_t ET = be.read_i64(w.rowptr + VT);
+        int64_t et_mv[2];
+        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV}, et_mv);
+        const int64_t ET = et_mv[0], MAXV_OVER = et_mv[1];            // (MAXV_OVER: 0, or the largest contig of more than REV_ORD_MAXV vertices)
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
         AZ(indeg, int32_t, VT, "indeg");
@@ -208,9 +211,12 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
-        if (ET > 6 * VT) be.launch(KN_REV_FILL_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
-        else be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
-        be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        if (ET > 6 * VT && MAXV_OVER == 0) be.launch(KN_REV_FILL_ORD, C, AASM_WAVE, w);   // dense, no giant contig: the in-lists in order from one pass per contig
+        else {
+            if (ET > 6 * VT) be.launch(KN_REV_FILL_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
+            else be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
+            be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+        }
         A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
         A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
         CHECK_ALLOC();
