@@ -1113,7 +1113,10 @@ AASM_DEV void emit_edge(const WS &w, int64_t e, int64_t vb, int32_t col, int64_t
 // fills rows: each lane owns one vertex of a 64-vertex tile (short rows); rows longer than
 // LONG_ROW are then written cooperatively by the whole wave (coalesced, ballot compaction).
 #define AASM_LONG_ROW 16
-AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane, int nl) {
+#define AASM_MID_ROW 96
+// G lanes (the whole wave, or 16 of it for rows of up to a few dozen edges: four rows at a time) work on the row; lane = 0 .. G - 1
+template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane, int gbase) {
+    const int nl = G;
     // segments: [dest][pairs][disjoint][next]; lanes stride over each segment
     int64_t e = e0;
     if (r.kind == 1) {                                              // src (:552-561)
@@ -1136,7 +1139,7 @@ AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane,
     for (int64_t t0 = 0; t0 < r.ovn; t0 += nl) {
         const int64_t t = t0 + lane;
         const bool ok = t < r.ovn && pair_edge_ok(w, r, t);
-        const uint64_t m = wave_ballot(ok);
+        const uint64_t m = group_ballot<G>(ok, gbase);
         if (ok) {
             const int64_t s = r.ov0 + t, pos = e + popc64(m & lanemask_lt(lane));
             int64_t wq; int32_t wr; uint8_t fl;
@@ -1166,7 +1169,7 @@ AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 
     const bool small = act && d > 0 && d <= AASM_LONG_ROW;
     const bool big = act && d > AASM_LONG_ROW;
 #if defined(AASM_HOST_EMUL)
-    if (small || big) fill_row_part(w, r, w.rowptr[gv], 0, 1);
+    if (small || big) fill_row_part<1>(w, r, w.rowptr[gv], 0, 0);
 #else
     // short rows: run with a single logical lane (ballot of a lone lane is its own bit)
     if (small) {
@@ -1199,14 +1202,30 @@ AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 
             }
         }
     }
-    // long rows: all 64 lanes cooperate on one row at a time
-    uint64_t bigmask = wave_ballot(big);
+    // rows of 17 ... AASM_MID_ROW edges (most rows of a dense graph): four at a time, 16 lanes each
+    uint64_t midmask = wave_ballot(big && d <= AASM_MID_ROW);
+    while (midmask) {
+        int src = -1;
+        AASM_UNROLL
+        for (int g = 0; g < 4; g++) {
+            const int sg = midmask ? ffs64(midmask) - 1 : -1;
+            if (midmask) midmask &= midmask - 1;
+            if ((k.lane >> 4) == g) src = sg;
+        }
+        if (src >= 0) {
+            const int64_t gv2 = k.bid * AASM_WAVE + src;
+            const RowPlan r2 = plan_row(w, gv2);
+            fill_row_part<16>(w, r2, w.rowptr[gv2], k.lane & 15, k.lane & ~15);
+        }
+    }
+    // longer rows: all 64 lanes cooperate on one row at a time
+    uint64_t bigmask = wave_ballot(big && d > AASM_MID_ROW);
     while (bigmask) {
         const int src = ffs64(bigmask) - 1;
         bigmask &= bigmask - 1;
         const int64_t gv2 = k.bid * AASM_WAVE + src;
         const RowPlan r2 = plan_row(w, gv2);
-        fill_row_part(w, r2, w.rowptr[gv2], k.lane, AASM_WAVE);
+        fill_row_part<AASM_WAVE>(w, r2, w.rowptr[gv2], k.lane, 0);
     }
 #endif
 }
