@@ -62,10 +62,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 def kernel_bytes(st):
     """Algorithmic bytes per launch for the five heavy kernels (DESIGN.md 'Byte model')."""
     V, E, H = st["n_vertices"], st["n_edges"], st["n_heap_nodes"]
+    dense = E > 6 * V                                               # (the pipeline's own rule: wide SP trees get the several-waves heap kernel)
     return {
         "sptree": ("aasm_k6_rev_sweep", 24 * E + 2 * 40 * V),
         "fwd": ("aasm_k5_fwd_sweep", 24 * E + 2 * 8 * V),
-        "heap": ("aasm_k7_heap", 24 * E + 40 * V + 24 * H),
+        "heap": ("aasm_k7_heap_mw" if dense else "aasm_k7_heap", 24 * E + 40 * V + 24 * H),
         "enum": ("aasm_k8_enum", 64 * st["pq_pushes"] + 40 * st["n_paths_found"]),
         "select": ("aasm_k9_sel_convert", 24 * st["ispr_edges"] + 40 * st["ispr_vertices"] + 8 * st["path_edges"] + 40 * st["out_elems"]),
     }
