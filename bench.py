@@ -304,13 +304,13 @@ def main():
 
 def pmc_traffic(workload, not_profiled_shape, kernel):
     """HBM traffic of the dominant kernel from the committed OFFLINE rocprofv3 --pmc passes
-    (profiles/rNN_c3_pmc_fetch_write.json, newest round: one pass per counter, --kernel-trace only).
+    (profiles/rNN_<workload>_pmc_fetch_write.json, newest round: one pass per counter, --kernel-trace only).
     FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half
     the bytes of a wide (16 B/lane) coalesced stream and is uncalibrated for other widths; these
     kernels gather 4-48 B per access, so the raw value is reported and the x2 figure is given
     as the upper bound.  Only attached when the run IS the profiled workload."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_c3_pmc_fetch_write.json")))
-    if not_profiled_shape or workload != "c3" or not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_%s_pmc_fetch_write.json" % workload)))
+    if not_profiled_shape or not files:
         return None
     path = files[-1]
     data = json.load(open(path))

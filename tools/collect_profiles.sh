@@ -15,9 +15,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 python3 $R/tools/pmc_summary.py $O/${TAG}_c3_pmc_fetch_write.json $O/pmc_fetch $O/pmc_write
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_sq.err || exit 1
 python3 $R/tools/pmc_summary.py $O/${TAG}_c3_pmc_sq.json $O/pmc_sq
-python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --cpu-sample 200 > $O/${TAG}_c5_bench_1gpu_share.json 2> $O/c5.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -- python3 $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/kt5.err || exit 1
 cp $O/kt5/*/*kernel_stats.csv $O/${TAG}_c5_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc5_fetch -- python3 $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc5_fetch.err || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc5_write -- python3 $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc5_write.err || exit 1
+python3 $R/tools/pmc_summary.py $O/${TAG}_c5_pmc_fetch_write.json $O/pmc5_fetch $O/pmc5_write
+cp $O/${TAG}_c5_pmc_fetch_write.json $R/profiles/          # (bench.py reads roofline.traffic from profiles/)
+python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --cpu-sample 200 > $O/${TAG}_c5_bench_1gpu_share.json 2> $O/c5.err || exit 1
 for n in 250 625 1000 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --dup 3 --shuffle 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_dup3_shuffled.json
 python3 $R/tools/phase_probe.py --contigs 1000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_1000contigs.json
@@ -30,5 +34,5 @@ AASM_LIB_OVERRIDE=$R/alignasm_amd/libalignasm_amd_kprof.so python3 $R/tools/sort
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --heavy 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_heavy_tail.json
 python3 $R/tools/giant_probe.py > $O/${TAG}_giant_contigs.jsonl 2>&1
 python3 $R/tools/e2e_cli.py --contigs 5000 --k 4 > $O/${TAG}_e2e_cli.log 2>&1
-rm -rf $O/kt $O/kt5 $O/ktk $O/ktd $O/pmc_fetch $O/pmc_write $O/pmc_sq
+rm -rf $O/kt $O/kt5 $O/ktk $O/ktd $O/pmc5_fetch $O/pmc5_write $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
