@@ -277,7 +277,7 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
     Dist *kd = w.kd + c * (int64_t)K;
     int32_t *klast = w.klast + c * (int64_t)K;
     I4 *kcand = w.kcand + 2 * c * (3 * (int64_t)K + 1);
-    const HNode *nodes = w.hnodes + w.hoff[c];
+    const HNode *nodes = heap_arena(w, c);
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
     EnumQT<FMAX> q;

@@ -28,6 +28,7 @@ struct WS {
     int64_t C, R, R0, S, VT, ET;
     int32_t K, nsl;
     int32_t avg_sidetracks;              // mean #sidetracks per contig of the batch (K7's wave priority)
+    int32_t mw_compact;                  // 1: kb_heap_mw moves its nodes to the final arena (debug runs: arena indices as the reference allocates them); 0: they stay where they were built
     int32_t sort_depth_test;             // 0; tests: kb_sort_fix starts its introsort with (this - 1) partition levels instead of 2 lg N
     // ---- input batch (device), original record order; rec_off already points at the chunk
     const int64_t *rec_off, *in_qs, *in_qe, *in_rs, *in_re, *in_qt, *in_rng_off, *rql, *rqr, *rrl;
@@ -1925,11 +1926,11 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     for (int64_t t = I + 1; t > 1; t >>= 1) lg++;
     int64_t cap = I * (lg + 2) + 8;
     if (cap > 0x7fffff00) cap = 0x7fffff00;                          // arena indices are int32: a contig that really needs more ends with status AASM_E_OVERFLOW (kb_heap)
-    w.hcap_cnt[c] = (int32_t)cap;
     w.mw_lg[c] = lg + 2;
     // dense / high-multiplicity graphs (tens of sidetracks per vertex, a wide SP tree): several waves per contig
     w.mw_flag[c] = (w.mw_mode == 1 || (w.mw_mode == 0 && I >= 6 * V && V >= 128)) ? 1 : 0;
     w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
+    w.hcap_cnt[c] = (w.mw_flag[c] && !w.mw_compact) ? 0 : (int32_t)cap;   // (a several-waves contig whose nodes stay in the provisional arena needs no final one)
     if (w.mw_flag[c]) atomic_add(&w.counters[CNT_MW], (int64_t)1);
 }
 
@@ -1987,6 +1988,10 @@ struct HeapState {
     bool ovf;
 };
 
+// where K8 and K9 find a contig's heap nodes: the final arena, or - a contig built by several waves, outside debug runs - the
+// provisional one: its regions lie in BFS order of the vertices and a region is filled in allocation order, so the order of the
+// indices there IS the reference's allocation order (all that K8's tie-break asks of an index); only the indices have gaps
+AASM_DEV const HNode *heap_arena(const WS &w, int64_t c) { return (w.mw_flag[c] && !w.mw_compact) ? w.hprov + w.mw_off[c] : w.hnodes + w.hoff[c]; }
 AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
     NodeQ n;
     const HNode *src = &hs.ring[a & (HEAP_RING - 1)];                                  // ds_read, lgkmcnt only
@@ -2417,6 +2422,10 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     }
     block_barrier();
     const int32_t H = uni(ld_shared_i32(&L->n_nodes));
+    if (!w.mw_compact) {                                             // the nodes stay where they are (heap_arena): roots and child pointers are provisional indices already
+        if (k.tid == 0) { w.h_cnt[c] = H; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)H); }
+        return;
+    }
     HNode *fin = w.hnodes + w.hoff[c];
     if (H > (int32_t)(w.hoff[c + 1] - w.hoff[c])) { if (k.tid == 0) set_status(w, c, -5); return; }
     // The region starts (the keys of every pointer translation) go to LDS when they fit in the rings' space, which is free now:
@@ -2604,7 +2613,7 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
     I4 *kcand = w.kcand + 2 * c * (3 * K + 1);                       // {heap node, predecessor, qry_score} of candidate `cur` (the key carries the sum)
     Pq8 q; q.g = w.pq + c * w.pq_stride; q.l = (PqK *)k.lds; q.n = 0; q.pc_idx = -1;
     static_assert(PQ8_LDS_N * sizeof(PqK) <= AASM_ENUM_LDS_BYTES, "LDS budget");
-    const HNode *nodes = w.hnodes + w.hoff[c];
+    const HNode *nodes = heap_arena(w, c);
     const int32_t *h = w.h_root + vb;
     const int32_t src = (int32_t)(V - 2);
     const bool L0 = k.lane == 0;
@@ -2814,7 +2823,7 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     const int64_t K = w.K;
     if (kidx < 0 || kidx >= w.kfound[s.c]) return 0;
     const I4 *kcand = w.kcand + 2 * s.c * (3 * K + 1);
-    const HNode *nodes = w.hnodes + w.hoff[s.c];
+    const HNode *nodes = heap_arena(w, s.c);
     int32_t ns = 0;
     int32_t cur = w.klast[s.c * K + kidx];
     while (cur != -1) {                                             // sidetrack chain, newest first

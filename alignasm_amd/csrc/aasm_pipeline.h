@@ -256,6 +256,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
         A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off");
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
+        w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
         CHECK_ALLOC();
         be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
