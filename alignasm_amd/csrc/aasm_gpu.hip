@@ -1142,6 +1142,9 @@ int aasm_solve_batch_multi(const aasm_batch_in *in, const aasm_opts *opts, int n
                 aasm_opts od = o;
                 od.device = wrap ? (o.device + d) % ndev : o.device + d;
                 std::memset(&parts[d], 0, sizeof(parts[d]));
+                static std::mutex turn[16];                              // (a context holds ONE result: a wrapped shard solves and fetches before the next one starts)
+                std::unique_lock<std::mutex> lk(turn[od.device & 15], std::defer_lock);
+                if (wrap) lk.lock();
                 rcs[d] = solve_range(in, cut[d], cut[d + 1], od, &parts[d]);
                 if (rcs[d] != AASM_OK) errs[d] = aasm_last_error();
             });
