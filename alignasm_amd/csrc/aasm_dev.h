@@ -48,10 +48,6 @@ AASM_DEV void wave_lds_sync() {}
 AASM_DEV void block_barrier() {}
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return *p; }
 AASM_DEV void wave_sleep() {}
-AASM_DEV int32_t ld_agent_i32(const int32_t *p) { return *p; }
-AASM_DEV void st_agent_i32(int32_t *p, int32_t v) { *p = v; }
-AASM_DEV void release_agent() {}
-AASM_DEV void acquire_agent() {}
 AASM_DEV int64_t wave_realtime() { return 0; }
 template <class T> AASM_DEV void keep_load(T &) {}
 AASM_DEV void store_drain() {}
@@ -96,13 +92,6 @@ AASM_DEV void block_barrier() { __syncthreads(); }
 // a word another wave of the SAME workgroup may have just stored (global memory): workgroup-scope load
 AASM_DEV int32_t ld_shared_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 AASM_DEV void wave_sleep() { __builtin_amdgcn_s_sleep(2); }
-// hand-offs between WORKGROUPS (other CUs, other XCDs: their L1s and L2s are not ours): the flag or counter is read and written
-// at agent scope; the producer's payload is released before the flag (L2 write-back), the consumer acquires after its poll has
-// matched (L1 invalidate) and only then reads the payload with plain loads
-AASM_DEV int32_t ld_agent_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-AASM_DEV void st_agent_i32(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-AASM_DEV void release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-AASM_DEV void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // a loaded value is wanted HERE, in a register: keeps the compiler from sinking the load into a later branch (a second round trip)
 template <class T> AASM_DEV void keep_load(T &x) { asm volatile("" : "+v"(x)); }
 AASM_DEV int64_t wave_realtime() { return (int64_t)__builtin_amdgcn_s_memrealtime(); }   // constant 100 MHz counter

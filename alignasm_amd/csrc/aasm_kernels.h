@@ -112,9 +112,6 @@ struct WS {
     int32_t *mw_cap;                     // per contig: provisional capacity (0 for the one-wave class)
     int32_t *mw_order, *mw_rs, *mw_fb;   // per BFS position: vertex, region start, final base
     int32_t *mw_rsv, *mw_used;           // per vertex: region start, nodes used
-    int32_t *mw_list, *mw_ctl;           // the contigs of the several-waves class (any order); per contig: MwCtl of the team form
-    int32_t *mw_sorted;                  // the same contigs, the ones with the most sidetrack work first (the helpers' order)
-    int32_t mw_team, mw_n;               // kb_heap_mwt: workgroups per contig (its own + helpers); contigs of the class
     I4 *tnx;                             // next four vertices along best[] (kb_sidetrack) ...
     int32_t *tnx16;                      // ... and the next sixteen (kb_heap_hdr): path recovery reads one 64-byte record per sixteen tree edges
     I4 *rvh;                             // K6: per-vertex in-list header, 3 words (see kb_rev_hdr)
@@ -122,7 +119,7 @@ struct WS {
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_MWV, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
@@ -1934,7 +1931,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.mw_flag[c] = (w.mw_mode == 1 || (w.mw_mode == 0 && I >= 6 * V && V >= 128)) ? 1 : 0;
     w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
     w.hcap_cnt[c] = (w.mw_flag[c] && !w.mw_compact) ? 0 : (int32_t)cap;   // (a several-waves contig whose nodes stay in the provisional arena needs no final one)
-    if (w.mw_flag[c]) { w.mw_list[atomic_add(&w.counters[CNT_MW], (int64_t)1)] = (int32_t)c; atomic_max_i64(&w.counters[CNT_MWV], V); }
+    if (w.mw_flag[c]) atomic_add(&w.counters[CNT_MW], (int64_t)1);
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
@@ -2280,9 +2277,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 //            ancestor's region: binary search over the region starts).
 // The result is bit-identical to the one-wave kernel's, arena indices included.
 #define MW_WAVES 16                      // most waves a contig can get (the launch picks 4, 8 or 16 by how many contigs share the chip)
-struct MwCtl { int32_t q_head, q_tail, n_done, n_total, stop, n_nodes, pad0, pad1; };   // the ticket queue's counters
 struct MwLds {
-    MwCtl ctl;
+    int32_t q_head, q_tail, n_done, n_total, stop, n_nodes, pad0, pad1;
     HNode bounce[MW_WAVES];              // heap_read's slot, one per wave
     HNode ring[MW_WAVES][HEAP_RING];     // (a launch with fewer waves declares only its share)
 };
@@ -2296,73 +2292,11 @@ AASM_DEV int32_t mw_last_le(const int32_t *a, int32_t n, int32_t x) {
     return lo;
 }
 
-// phase 0: BFS numbering (k_shortest_walks.hpp:196-214 without the inserts) + region starts, by one wave; returns the tree's size
-AASM_DEV int32_t mw_number_tree(const KCtx &k, const WS &w, int64_t c) {
-    const int64_t V = w.ctgV[c], vb = w.voff[c];
-    const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
-    int32_t *order = w.mw_order + vb, *rs = w.mw_rs + vb, *rsv = w.mw_rsv + vb, *used = w.mw_used + vb;
-    const int32_t dest = (int32_t)(V - 1), per_insert = w.mw_lg[c];
-    if (k.lane == 0) order[0] = dest;
-    wave_fence();
-    int32_t n = 1, head = 0, rbase = 0;
-    while (head < n) {
-        const int32_t chunk = (n - head < AASM_WAVE) ? (n - head) : AASM_WAVE;
-        int32_t v = -1, nch = 0, nin = 0;
-        int64_t c0 = 0;
-        if (k.lane < chunk) {
-            v = order[head + k.lane];
-            const I4 a = vh[v], b = vh2[v];
-            nin = a.y; nch = a.z;
-            c0 = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
-        }
-        const int32_t capv = nin * per_insert, cincl = wave_incl_add(capv), nincl = wave_incl_add(nch);
-        if (k.lane < chunk) { rs[head + k.lane] = rbase + cincl - capv; rsv[v] = rbase + cincl - capv; used[v] = 0; }
-        for (int32_t j = 0; j < nch; j++) order[n + (nincl - nch) + j] = w.cval[c0 + j];   // children in ascending id (:191-194)
-        rbase += wave_bcast(cincl, AASM_WAVE - 1);
-        n += wave_bcast(nincl, AASM_WAVE - 1);
-        head += chunk;
-        wave_fence();
-    }
-    return n;
-}
-
-// the helpers' order: the contigs of the class by their node bound, largest first (rank by counting: the class is a few thousand at most)
-AASM_DEV void kb_mw_rank(const KCtx &k, const WS &w) {               // thread per contig of the class
-    const int64_t i = k.bid * k.nthreads + k.tid;
-    if (i >= w.mw_n) return;
-    const int32_t ci = w.mw_list[i], key = w.mw_cap[ci];
-    int32_t r = 0;
-    for (int64_t j = 0; j < w.mw_n; j++) { const int32_t cj = w.mw_list[j], kj = w.mw_cap[cj]; r += (kj > key || (kj == key && cj < ci)) ? 1 : 0; }
-    w.mw_sorted[r] = ci;
-}
-
-// the team form's first launch: one wave per contig of the class numbers its tree and sets the queue's counters (global memory)
-AASM_DEV void kb_heap_mw_prep(const KCtx &k, const WS &w) {
-    const int64_t c = w.mw_list[k.bid];
-    const int64_t V = w.ctgV[c], vb = w.voff[c];
-    MwCtl *ctl = (MwCtl *)(w.mw_ctl + c * 8);
-    int32_t n = 0;
-    if (w.status[c] == 0) {
-        if (dist_is_max(w.sp_d[vb + (V - 2)])) { if (k.lane == 0) set_status(w, c, -6); }   // :188-189: no path (must not happen)
-        else n = mw_number_tree(k, w, c);
-    }
-    if (k.lane == 0) { ctl->q_head = 0; ctl->q_tail = 0; ctl->n_done = 0; ctl->n_total = n; ctl->stop = 0; ctl->n_nodes = 0; ctl->pad0 = 0; ctl->pad1 = 0; w.h_cnt[c] = 0; }
-}
-
-// TEAM: mw_team workgroups per contig (a lone giant contig would otherwise have ONE CU's 16 waves).  The queue's counters live in
-// global memory, every hand-off crosses CUs and XCDs (agent-scope release before the entries appear, acquire after a ticket is
-// served), the nodes stay in the provisional arena (no phase 2; never in debug runs), and waves that find nothing leave when
-// n_done says so - nobody waits FOR a wave, so workgroups that become resident late only find less to do.
-template <bool TEAM> AASM_DEV int32_t mw_ld(const int32_t *p) { if constexpr (TEAM) return ld_agent_i32(p); else return ld_shared_i32(p); }
-template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   // MW_WAVES waves per workgroup
-    // team: the grid is every contig's OWN workgroup first, then rounds of helpers, each round heaviest contig first - workgroups
-    // start in grid order as slots come free, so the slots of the contigs that finish early go to the ones with the most left to do
-    const int64_t c = !TEAM ? k.bid : (k.bid < w.mw_n) ? (int64_t)w.mw_list[k.bid] : (int64_t)w.mw_sorted[(k.bid - w.mw_n) % w.mw_n];
-    const int tb = !TEAM ? 0 : (k.bid < w.mw_n) ? 0 : 1 + (int)((k.bid - w.mw_n) / w.mw_n);   // 0: the contig's own workgroup
+AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES waves per contig
+    const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0 || !w.mw_flag[c]) return;
     MwLds *L = (MwLds *)k.lds;
-    MwCtl *ctl = TEAM ? (MwCtl *)(w.mw_ctl + c * 8) : &L->ctl;
     const int64_t vb = w.voff[c];
     const int wv = k.tid / AASM_WAVE;                                // this wave
     int32_t *h = w.h_root + vb, *q = w.bq + vb;
@@ -2371,11 +2305,9 @@ template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   
     int32_t *order = w.mw_order + vb, *rs = w.mw_rs + vb, *fb = w.mw_fb + vb, *rsv = w.mw_rsv + vb, *used = w.mw_used + vb;
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     const int32_t per_insert = w.mw_lg[c];
-    if (!TEAM) {
-        if (k.tid == 0) w.h_cnt[c] = 0;
-        if (w.status[c] != 0) return;
-        if (dist_is_max(w.sp_d[vb + src])) { if (k.tid == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
-    }
+    if (k.tid == 0) w.h_cnt[c] = 0;
+    if (w.status[c] != 0) return;
+    if (dist_is_max(w.sp_d[vb + src])) { if (k.tid == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     const int64_t mwp_t0 = wave_realtime();                          // diagnostic build: the phases' wall time (100 MHz ticks) of wave 0
     int64_t mwp_t1 = 0, mwp_t2 = 0, mwp_t3 = 0;
@@ -2383,47 +2315,58 @@ template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   
 #else
 #define MWP_STAMP(x) do {} while (0)
 #endif
-    // ---- phase 0: BFS numbering + region starts (the team form: done by kb_heap_mw_prep, the launch before)
-    if (!TEAM) {
-        if (wv == 0) {
-            const int32_t n = mw_number_tree(k, w, c);
-            if (k.lane == 0) { ctl->n_total = n; ctl->q_head = 0; ctl->q_tail = 0; ctl->n_done = 0; ctl->stop = 0; ctl->n_nodes = 0; }
-            store_drain();
+    // ---- phase 0: BFS numbering (k_shortest_walks.hpp:196-214 without the inserts) + region starts
+    if (wv == 0) {
+        if (k.lane == 0) order[0] = dest;
+        wave_fence();
+        int32_t n = 1, head = 0, rbase = 0;
+        while (head < n) {
+            const int32_t chunk = (n - head < AASM_WAVE) ? (n - head) : AASM_WAVE;
+            int32_t v = -1, nch = 0, nin = 0;
+            int64_t c0 = 0;
+            if (k.lane < chunk) {
+                v = order[head + k.lane];
+                const I4 a = vh[v], b = vh2[v];
+                nin = a.y; nch = a.z;
+                c0 = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+            }
+            const int32_t capv = nin * per_insert, cincl = wave_incl_add(capv), nincl = wave_incl_add(nch);
+            if (k.lane < chunk) { rs[head + k.lane] = rbase + cincl - capv; rsv[v] = rbase + cincl - capv; used[v] = 0; }
+            for (int32_t j = 0; j < nch; j++) order[n + (nincl - nch) + j] = w.cval[c0 + j];   // children in ascending id (:191-194)
+            rbase += wave_bcast(cincl, AASM_WAVE - 1);
+            n += wave_bcast(nincl, AASM_WAVE - 1);
+            head += chunk;
+            wave_fence();
         }
-        block_barrier();
+        if (k.lane == 0) { L->n_total = n; L->q_head = 0; L->q_tail = 0; L->n_done = 0; L->stop = 0; L->n_nodes = 0; }
+        store_drain();
     }
+    block_barrier();
     MWP_STAMP(mwp_t1);
-    const int32_t nv = TEAM ? uni(ctl->n_total) : uni(ld_shared_i32(&ctl->n_total));
-    if (TEAM && nv == 0) return;                                     // (status set, or no path)
-    if (TEAM) {
-        // a helper joins only a contig whose own workgroup runs (whatever order the workgroups start in, nobody holds a slot waiting
-        // for a workgroup that has none) and has work left
-        if (tb == 0) { if (k.tid == 0) st_agent_i32(&ctl->pad0, 1); }
-        else if (!uni(ld_agent_i32(&ctl->pad0)) || uni(ld_agent_i32(&ctl->n_done)) >= nv) return;
-    }
+    const int32_t nv = uni(ld_shared_i32(&L->n_total));
     // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
     HeapState hs;
     hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     KProfNone kp;
     for (int i_ = 0; i_ < 8; i_++) kp.acc[i_] = 0;
-    int32_t u = (wv == 0 && tb == 0) ? dest : -1, hu = -1, built = 0;
+    int32_t u = (wv == 0) ? dest : -1, hu = -1;
     int64_t guard = 0;
     while (true) {
-        if (uni(mw_ld<TEAM>(&ctl->stop))) break;
+        if (uni(ld_shared_i32(&L->stop))) break;
         if (u < 0) {                                                 // nothing of its own left: a ticket for the shared queue
             int32_t s = 0;
-            if (k.lane == 0) s = atomic_add(&ctl->q_head, (int32_t)1);
+            if (k.lane == 0) s = atomic_add(&L->q_head, (int32_t)1);
             s = wave_bcast(s, 0);
             const int64_t wait_t0 = wave_realtime();
             while (true) {
-                if (uni(mw_ld<TEAM>(&ctl->stop)) || uni(mw_ld<TEAM>(&ctl->n_done)) >= nv) { u = -2; break; }
-                const int32_t e = (s < V) ? uni(mw_ld<TEAM>(&q[s])) : -1;
-                if (e >= 0) { if (TEAM) acquire_agent(); u = e; hu = uni(ld_shared_i32(&h[u])); break; }   // (team: the heap it inherits was built on another CU)
+                if (uni(ld_shared_i32(&L->stop)) || uni(ld_shared_i32(&L->n_done)) >= nv) { u = -2; break; }
+                const int32_t e = (s < V) ? uni(ld_shared_i32(&q[s])) : -1;
+                if (e >= 0) { u = e; hu = uni(ld_shared_i32(&h[u])); break; }
                 // (never: every wait ends with an entry or with n_done == nv.)  Bounded by wall time, not by a spin count: a wave may
                 // rightly wait for as long as the others work on a path-like part of the tree, but 30 s without its ticket being
                 // served means a publishing wave is gone, and the launch ends with AASM_E_INTERNAL instead of sitting for minutes
-                if ((++guard & 1023) == 0 && wave_realtime() - wait_t0 > (int64_t)30 * 100000000) { u = -2; if (k.lane == 0) { if (TEAM) st_agent_i32(&ctl->stop, 2); else ctl->stop = 2; } break; }
+                if ((++guard & 1023) == 0 && wave_realtime() - wait_t0 > (int64_t)30 * 100000000) { u = -2; if (k.lane == 0) L->stop = 2; break; }
                 wave_sleep();
             }
             if (u == -2) break;
@@ -2443,36 +2386,27 @@ template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   
                 hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
             }
         }
-        if (hs.ovf) { if (k.lane == 0) { if (TEAM) st_agent_i32(&ctl->stop, 1); else ctl->stop = 1; } break; }
+        if (hs.ovf) { if (k.lane == 0) L->stop = 1; break; }
         heap_flush(hs, k.lane);
-        built += hs.alloc - r0;
         if (k.lane == 0) { used[u] = hs.alloc - r0; h[u] = hu; }     // (the inherited root this word carried has been read)
         // children adopt the heap (:213): the first one stays with this wave, the others go to whoever waits
         if (nch >= 2) {
             for (int32_t t = 1 + k.lane; t < nch; t += AASM_WAVE) h[w.cval[c0 + t]] = hu;
-            if (TEAM) release_agent(); else store_drain();           // nodes, roots: in the shared cache (team: in memory) before the entries appear
+            store_drain();                                           // nodes, roots: in the shared cache before the entries appear
             int32_t at = 0;
-            if (k.lane == 0) at = atomic_add(&ctl->q_tail, nch - 1);
+            if (k.lane == 0) at = atomic_add(&L->q_tail, nch - 1);
             at = wave_bcast(at, 0);
-            for (int32_t t = 1 + k.lane; t < nch; t += AASM_WAVE) { if (TEAM) st_agent_i32(&q[at + t - 1], w.cval[c0 + t]); else q[at + t - 1] = w.cval[c0 + t]; }
+            for (int32_t t = 1 + k.lane; t < nch; t += AASM_WAVE) q[at + t - 1] = w.cval[c0 + t];
         }
         store_drain();
-        if (k.lane == 0) atomic_add(&ctl->n_done, (int32_t)1);
+        if (k.lane == 0) atomic_add(&L->n_done, (int32_t)1);
         u = (nch > 0) ? fc : -1;
     }
     heap_flush(hs, k.lane);
     store_drain();
-    if (TEAM) {                                                      // every wave for itself: its share of the node count, the status
-        const int32_t stop = uni(ld_agent_i32(&ctl->stop));
-        if (k.lane == 0) {
-            if (stop) set_status(w, c, stop == 1 ? -5 : -6);
-            else if (built) { atomic_add(&w.h_cnt[c], built); atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)built); }
-        }
-        return;
-    }
     block_barrier();
     MWP_STAMP(mwp_t2);
-    const int32_t stop = uni(ld_shared_i32(&ctl->stop));
+    const int32_t stop = uni(ld_shared_i32(&L->stop));
     if (stop) { if (k.tid == 0) set_status(w, c, stop == 1 ? -5 : -6); return; }
     // ---- phase 2: compaction into the final arena, BFS order = the reference's allocation order
     if (wv == 0) {
@@ -2483,11 +2417,11 @@ template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   
             if (i < nv) fb[i] = carry + incl - x;
             carry += wave_bcast(incl, AASM_WAVE - 1);
         }
-        if (k.lane == 0) ctl->n_nodes = carry;
+        if (k.lane == 0) L->n_nodes = carry;
         store_drain();
     }
     block_barrier();
-    const int32_t H = uni(ld_shared_i32(&ctl->n_nodes));
+    const int32_t H = uni(ld_shared_i32(&L->n_nodes));
     if (!w.mw_compact) {                                             // the nodes stay where they are (heap_arena): roots and child pointers are provisional indices already
         if (k.tid == 0) { w.h_cnt[c] = H; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)H); }
         return;
@@ -2535,8 +2469,6 @@ template <bool TEAM> AASM_DEV void kb_heap_mw_t(const KCtx &k, const WS &w) {   
     if (k.lane == 0 && w.prof_heap) { atomic_add(&w.prof_heap[c * 8 + 5], kp.acc[6]); atomic_add(&w.prof_heap[c * 8 + 6], kp.acc[7]); }   // chase steps served by global memory / by the ring, all waves
 #endif
 }
-AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) { kb_heap_mw_t<false>(k, w); }
-AASM_DEV void kb_heap_mwt(const KCtx &k, const WS &w) { kb_heap_mw_t<true>(k, w); }
 
 // ====================================================================================
 // K8  k-walk enumeration (k_shortest_walks.hpp:217-249)

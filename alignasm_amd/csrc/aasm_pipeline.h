@@ -23,7 +23,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_HEAP_MW_PREP, KN_MW_RANK, KN_HEAP_MWT, KN_HEAP_MWT8, KN_HEAP_MWT16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -59,9 +59,6 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
         case KN_HEAP: kb_heap(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
-        case KN_HEAP_MW_PREP: kb_heap_mw_prep(k, w); break;
-        case KN_MW_RANK: kb_mw_rank(k, w); break;
-        case KN_HEAP_MWT: case KN_HEAP_MWT8: case KN_HEAP_MWT16: kb_heap_mwt(k, w); break;
 #if defined(AASM_HOST_EMUL)
         case KN_ENUM: case KN_ENUM_S: case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
 #else
@@ -257,7 +254,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP_PREP);
         A(ccnt, int32_t, VT, "ccnt"); A(cval, int32_t, ET, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
-        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted");
+        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off");
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
         w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
@@ -269,26 +266,13 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
         be.scan_i32(w.mw_cap, C, w.mw_off);
-        int64_t hh[5];
-        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_MWV}, hh);
+        int64_t hh[4];
+        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN}, hh);
         const int64_t HT = hh[0], HTM = hh[1], NMW = HTM > 0 ? hh[2] : 0;
         sz.HT = HT;
         w.avg_sidetracks = (int32_t)std::min<int64_t>((ET - VT + C) / (C > 0 ? C : 1), INT32_MAX);
         A(hnodes, HNode, HT, "hnodes"); A(h_root, int32_t, VT, "h_root"); A(bq, int32_t, VT, "bq");
         A(hprov, HNode, HTM, "hprov");
-        // Team form (kb_heap_mwt): a contig's own workgroup plus helper workgroups that start, heaviest contig first, in the slots of
-        // the contigs that finish early (block times of a dense batch differ by 1.7x: mean 25 ms, longest 42).  Used when the class
-        // fills the chip (otherwise every contig has 16 waves already, and a dense contig's build time then is the insert chain along
-        // its deepest branch, which more waves do not shorten: DESIGN.md s7) and is small enough to rank by counting;
-        // opts.reserved[0] bits 8-15 (tests, probes): that many workgroups per contig, 1 = never.  Not in debug runs (they compact).
-        int mw_team = 1;
-        if (HTM > 0 && !w.mw_compact) {
-            const int forced = (opts.reserved[0] >> 8) & 0xff;
-            if (forced) mw_team = forced;
-            else if (NMW * 16 > 6144 && NMW <= 8192) mw_team = 4;
-        }
-        w.mw_team = mw_team; w.mw_n = (int32_t)NMW;
-        A(mw_ctl, int32_t, mw_team > 1 ? C * 8 : 0, "mw_ctl");
         A(mw_order, int32_t, VT, "mw_order"); A(mw_rs, int32_t, VT, "mw_rs"); A(mw_fb, int32_t, VT, "mw_fb"); A(mw_rsv, int32_t, VT, "mw_rsv"); A(mw_used, int32_t, VT, "mw_used");
         CHECK_ALLOC();
         be.fill_ff(w.h_root, sizeof(int32_t) * (size_t)VT);
@@ -297,12 +281,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
         // contigs of the wide-tree class (kb_heap skips them): 16, 8 or 4 waves each, by how many of them share the chip's ~8 k wave slots
-        if (HTM > 0 && mw_team > 1) {                                // (numbering and the helpers' order first, in launches of their own)
-            const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4;
-            be.launch(KN_MW_RANK, cdiv(NMW, 256), 256, w);
-            be.launch(KN_HEAP_MW_PREP, NMW, AASM_WAVE, w);
-            be.launch(mw == 16 ? KN_HEAP_MWT16 : mw == 8 ? KN_HEAP_MWT8 : KN_HEAP_MWT, NMW * mw_team, AASM_WAVE * mw, w);
-        } else if (HTM > 0) { const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4; be.launch(mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW, C, AASM_WAVE * mw, w); }
+        if (HTM > 0) { const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4; be.launch(mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW, C, AASM_WAVE * mw, w); }
         be.phase_end(AASM_PH_HEAP);
 
         // ---- K8 enumeration

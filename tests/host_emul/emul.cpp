@@ -54,7 +54,7 @@ struct EmuBackend {
     static int nthreads_emul(int kn, int nthreads) {
         switch (kn) {
             case KN_SORT_FIX: case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_REV_FILL_W: case KN_REV_FILL_ORD: case KN_SIDETRACK_W:
-            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_REV_SWEEP_G: case KN_FWD_SWEEP_G: case KN_HEAP: case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: case KN_HEAP_MW_PREP: case KN_HEAP_MWT: case KN_HEAP_MWT8: case KN_HEAP_MWT16: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
+            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_REV_SWEEP_G: case KN_FWD_SWEEP_G: case KN_HEAP: case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
                 return 1;
             default: return nthreads;
         }

@@ -34,9 +34,6 @@ def test_outputs_and_intermediates(T, case):
     got = T.emul_solve(hb, K, nsl)
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
-    # the team form (several workgroups per contig, counters in global memory, numbering in a launch of its own): outputs
-    got = T.emul_solve(hb, K, nsl, heap_waves="all", heap_team=3)
-    assert T.diff_outputs(want, got) == []
     assert want["stats"]["n_internal_errors"] == 0
 
 
