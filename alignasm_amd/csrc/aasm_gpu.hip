@@ -72,6 +72,7 @@ AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw, KN_HEAP_MW, 256, AASM_MW_LDS_BYTES(4), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw8, KN_HEAP_MW8, 512, AASM_MW_LDS_BYTES(8), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw16, KN_HEAP_MW16, 1024, AASM_MW_LDS_BYTES(16), 4)
+AASM_DEF_KERNEL(aasm_k7_mw_rank, KN_MW_RANK, 256)
 AASM_DEF_KERNEL_LDS(aasm_k8_enum, KN_ENUM, 64, AASM_ENUM2_LDS_BYTES, 4)
 AASM_DEF_KERNEL_LDS(aasm_k8_enum_s, KN_ENUM_S, 64, AASM_ENUM2_LDS_BYTES_F(EQ_FSMALL), 5)
 AASM_DEF_KERNEL_LDS(aasm_k8_enum_heap, KN_ENUM_HEAP, 64, AASM_ENUM_LDS_BYTES, 2)
@@ -417,7 +418,7 @@ struct GpuBackend {
             L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord)
             L(KN_SORT_ROWS_REV, aasm_k6_rev_place) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
             L(KN_CHILDREN, aasm_k7_children)
-            L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
+            L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
             L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L

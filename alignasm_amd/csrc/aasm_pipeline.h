@@ -23,7 +23,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -59,6 +59,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
         case KN_HEAP: kb_heap(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
+        case KN_MW_RANK: kb_mw_rank(k, w); break;
 #if defined(AASM_HOST_EMUL)
         case KN_ENUM: case KN_ENUM_S: case KN_ENUM_HEAP: kb_enum_heap(k, w); break;
 #else
@@ -254,7 +255,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP_PREP);
         A(ccnt, int32_t, VT, "ccnt"); A(cval, int32_t, ET, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
-        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off");
+        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted");
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
         w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
@@ -281,7 +282,23 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
         // contigs of the wide-tree class (kb_heap skips them): 16, 8 or 4 waves each, by how many of them share the chip's ~8 k wave slots
-        if (HTM > 0) { const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4; be.launch(mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW, C, AASM_WAVE * mw, w); }
+        w.mw_n = (int32_t)NMW; w.mw_base = -1;
+        if (HTM > 0) {
+            const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4;
+            const int kn = mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW;
+            // One block per contig of the class, the contig with the largest node bound first: block times of a dense batch go with the
+            // node count (C5 share: mean 25 ms, longest 42), and in input order the heavy ones land on the CUs as they come - clumps of them
+            // share a CU's issue slots and the launch ends with such a clump.  Largest first deals every CU a spread of weights and
+            // starts the longest chains first: C5 share 35.5 -> 30.0 ms, 700 contigs 27.3 -> 25.5, 400 x 1 500 records 25.1 -> 22.8.
+            // opts.reserved[0] bits 8-15 == 1 (probes): input order, a block per contig of the batch.
+            const bool by_list = ((opts.reserved[0] >> 8) & 0xff) != 1 && NMW >= 2 && NMW <= 8192;   // (ranked by counting: NMW^2 compares)
+            if (by_list) {
+                be.launch(KN_MW_RANK, cdiv(NMW, 256), 256, w);
+                w.mw_base = 0;
+                be.launch(kn, NMW, AASM_WAVE * mw, w);
+                w.mw_base = -1;
+            } else be.launch(kn, C, AASM_WAVE * mw, w);
+        }
         be.phase_end(AASM_PH_HEAP);
 
         // ---- K8 enumeration

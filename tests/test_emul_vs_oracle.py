@@ -34,6 +34,8 @@ def test_outputs_and_intermediates(T, case):
     got = T.emul_solve(hb, K, nsl)
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+    got = T.emul_solve(hb, K, nsl, heap_waves="all", heap_input_order=True)   # (default: largest node bound first, a block per contig of the class)
+    assert T.diff_outputs(want, got) == []
     assert want["stats"]["n_internal_errors"] == 0
 
 

@@ -244,6 +244,20 @@ def test_multiwave_heaps_with_fewer_waves_per_contig(T, nc):
     assert T.diff_outputs(want, got) == []
 
 
+def test_multiwave_heaps_launch_order_does_not_matter(T):
+    """By default the contigs of the several-waves class are launched largest node bound first, a block per contig of the
+    class (kb_mw_rank); input order with a block per contig of the batch is the other form.  A mixed dense / sparse batch of
+    contigs of very different sizes: both equal the oracle."""
+    api = T.api()
+    hb = T.synth(40, 300, 4242, dense=True, heavy_tail=True, dup_every=5)
+    want = T.oracle_solve(hb, 16)
+    for input_order in (False, True):
+        got = api.solve_batch(hb, max_paths=16, heap_input_order=input_order)
+        assert T.diff_outputs(want, got) == [], input_order
+        got = api.solve_batch(hb, max_paths=16, heap_waves="all", heap_input_order=input_order)
+        assert T.diff_outputs(want, got) == [], input_order
+
+
 # ---- K7, one wave per contig (kb_heap) forced on every contig, the dense ones included (by default those go to
 # kb_heap_mw): both kernels must leave the same arena
 @pytest.mark.parametrize("case", [CASES[2], CASES[5], CASES[9], CASES[13]], ids=_id)
