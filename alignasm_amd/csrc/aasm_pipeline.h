@@ -284,14 +284,15 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // contigs of the wide-tree class (kb_heap skips them): 16, 8 or 4 waves each, by how many of them share the chip's ~8 k wave slots
         w.mw_n = (int32_t)NMW; w.mw_base = -1;
         if (HTM > 0) {
-            const int mw = NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4;
+            const int hook = (opts.reserved[0] >> 8) & 0xff;         // probes: 1 = input order; 4 / 8 / 16 = that many waves per contig
+            const int mw = (hook == 4 || hook == 8 || hook == 16) ? hook : NMW * 16 <= 6144 ? 16 : NMW * 8 <= 6144 ? 8 : 4;
             const int kn = mw == 16 ? KN_HEAP_MW16 : mw == 8 ? KN_HEAP_MW8 : KN_HEAP_MW;
             // One block per contig of the class, the contig with the largest node bound first: block times of a dense batch go with the
             // node count (C5 share: mean 25 ms, longest 42), and in input order the heavy ones land on the CUs as they come - clumps of them
             // share a CU's issue slots and the launch ends with such a clump.  Largest first deals every CU a spread of weights and
             // starts the longest chains first: C5 share 35.5 -> 30.0 ms, 700 contigs 27.3 -> 25.5, 400 x 1 500 records 25.1 -> 22.8.
             // opts.reserved[0] bits 8-15 == 1 (probes): input order, a block per contig of the batch.
-            const bool by_list = ((opts.reserved[0] >> 8) & 0xff) != 1 && NMW >= 2 && NMW <= 8192;   // (ranked by counting: NMW^2 compares)
+            const bool by_list = hook != 1 && NMW >= 2 && NMW <= 8192;   // (ranked by counting: NMW^2 compares)
             if (by_list) {
                 be.launch(KN_MW_RANK, cdiv(NMW, 256), 256, w);
                 w.mw_base = 0;

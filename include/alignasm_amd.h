@@ -91,8 +91,9 @@ typedef struct aasm_opts {
                                 *            several-waves-per-contig kernel; bit 2: none of them (default: by graph density);
                                 *            bit 3: K8 on the d-ary heap queue (cross-check of the default sorted-front / sorted-runs queue);
                                 *            bit 4: K8 with the 40-entry front it takes for batches of more than 3 584 contigs
-                                *            bits 8-15 == 1: the several-waves heap kernel launched in input order, a block per contig of
-                                *            the batch (default: a block per contig of its class, largest node bound first)
+                                *            bits 8-15: 1 = the several-waves heap kernel launched in input order, a block per contig of
+                                *            the batch (default: a block per contig of its class, largest node bound first); 4 / 8 / 16 =
+                                *            that many waves per contig of the class (default: by how many contigs share the chip)
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);
