@@ -6,7 +6,7 @@ import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import aasm_testlib as T
 api = T.api()
-rnd = random.Random(20261004)
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)   # second argument: another seed
 n = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 120):
     nc = rnd.randint(2, 6); nr = rnd.choice([60, 130, 260, 400, 650, 900]); seed = rnd.randint(1, 10 ** 6)
