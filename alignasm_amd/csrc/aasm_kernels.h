@@ -113,6 +113,7 @@ struct WS {
     int32_t *mw_order, *mw_rs, *mw_fb;   // per BFS position: vertex, region start, final base
     int32_t *mw_rsv, *mw_used;           // per vertex: region start, nodes used
     int32_t *mw_list, *mw_sorted;        // the contigs of the several-waves class: in any order; by node bound, largest first
+    int32_t *mw_key;                     // the node bounds, in mw_list's order
     int32_t mw_n, mw_base;               // contigs of the class; kb_heap_mw by list (mw_base >= 0): block b builds mw_sorted[mw_base + b]
     I4 *tnx;                             // next four vertices along best[] (kb_sidetrack) ...
     int32_t *tnx16;                      // ... and the next sixteen (kb_heap_hdr): path recovery reads one 64-byte record per sixteen tree edges
@@ -1933,7 +1934,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.mw_flag[c] = (w.mw_mode == 1 || (w.mw_mode == 0 && I >= 6 * V && V >= 128)) ? 1 : 0;
     w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
     w.hcap_cnt[c] = (w.mw_flag[c] && !w.mw_compact) ? 0 : (int32_t)cap;   // (a several-waves contig whose nodes stay in the provisional arena needs no final one)
-    if (w.mw_flag[c]) w.mw_list[atomic_add(&w.counters[CNT_MW], (int64_t)1)] = (int32_t)c;
+    if (w.mw_flag[c]) { const int64_t slot = atomic_add(&w.counters[CNT_MW], (int64_t)1); w.mw_list[slot] = (int32_t)c; w.mw_key[slot] = (int32_t)cap; }
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
@@ -2299,9 +2300,17 @@ AASM_DEV int32_t mw_last_le(const int32_t *a, int32_t n, int32_t x) {
 AASM_DEV void kb_mw_rank(const KCtx &k, const WS &w) {               // thread per contig of the class
     const int64_t i = k.bid * k.nthreads + k.tid;
     if (i >= w.mw_n) return;
-    const int32_t ci = w.mw_list[i], key = w.mw_cap[ci];
+    const int32_t ci = w.mw_list[i], key = w.mw_key[i];
     int32_t r = 0;
-    for (int64_t j = 0; j < w.mw_n; j++) { const int32_t cj = w.mw_list[j], kj = w.mw_cap[cj]; r += (kj > key || (kj == key && cj < ci)) ? 1 : 0; }
+    int64_t j = 0;
+    for (; j + 8 <= w.mw_n; j += 8) {                                // (keys and ids side by side in slot order: eight independent pairs of loads per round)
+        int32_t kj[8], cj[8];
+        AASM_UNROLL
+        for (int u = 0; u < 8; u++) { kj[u] = w.mw_key[j + u]; cj[u] = w.mw_list[j + u]; }
+        AASM_UNROLL
+        for (int u = 0; u < 8; u++) r += (kj[u] > key || (kj[u] == key && cj[u] < ci)) ? 1 : 0;
+    }
+    for (; j < w.mw_n; j++) { const int32_t kj = w.mw_key[j], cj = w.mw_list[j]; r += (kj > key || (kj == key && cj < ci)) ? 1 : 0; }
     w.mw_sorted[r] = ci;
 }
 

@@ -255,7 +255,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_begin(AASM_PH_HEAP_PREP);
         A(ccnt, int32_t, VT, "ccnt"); A(cval, int32_t, ET, "cval");
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
-        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted");
+        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted"); A(mw_key, int32_t, C, "mw_key");
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
         w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
@@ -292,7 +292,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             // share a CU's issue slots and the launch ends with such a clump.  Largest first deals every CU a spread of weights and
             // starts the longest chains first: C5 share 35.5 -> 30.0 ms, 700 contigs 27.3 -> 25.5, 400 x 1 500 records 25.1 -> 22.8.
             // opts.reserved[0] bits 8-15 == 1 (probes): input order, a block per contig of the batch.
-            const bool by_list = hook != 1 && NMW >= 2 && NMW <= 8192;   // (ranked by counting: NMW^2 compares)
+            const bool by_list = hook != 1 && NMW >= 2 && NMW <= 32768;  // (ranked by counting: NMW^2 compares)
             if (by_list) {
                 be.launch(KN_MW_RANK, cdiv(NMW, 256), 256, w);
                 w.mw_base = 0;
