@@ -491,12 +491,12 @@ template <class A> AASM_DEV int64_t ss_partition_pivot(const A &a, int64_t first
     }
     return lo;
 }
-template <class A> AASM_DEV void ss_std_sort(const A &a, int64_t n, int depth_override) {
+// (st_first / st_last / st_depth: 72 entries each, the caller's - the kernel lends LDS it no longer needs, so that this cold
+// path costs the kernel no scratch memory)
+template <class A> AASM_DEV void ss_std_sort(const A &a, int64_t n, int depth_override, int64_t *st_first, int64_t *st_last, int32_t *st_depth) {
     if (n <= 0) return;
     int lg = 0;
     for (int64_t t = n; t > 1; t >>= 1) lg++;
-    int64_t st_first[72], st_last[72];
-    int st_depth[72];
     int sp = 0;
     st_first[0] = 0; st_last[0] = n; st_depth[0] = depth_override >= 0 ? depth_override : 2 * lg;
     sp = 1;
@@ -777,7 +777,7 @@ AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {
         if (k.lane == 0) {
             for (int64_t i = 0; i < N; i++) perm[i] = (int32_t)i;
             SortGlob acc{perm, w.in_qs + gb, w.in_qe + gb};
-            ss_std_sort(acc, N, w.sort_depth_test > 0 ? w.sort_depth_test - 1 : -1);
+            ss_std_sort(acc, N, w.sort_depth_test > 0 ? w.sort_depth_test - 1 : -1, L->qs, L->qe, L->ix);   // (the LDS copy is free by now)
         }
     }
 #if defined(AASM_KPROF)

@@ -121,6 +121,8 @@ void emul_sort_fix_kernel(int32_t *perm, int64_t n, const int64_t *qs, const int
 // libstdc++ std::sort replay used by kb_sort_fix, exposed for a direct test
 void emul_std_sort_replay(int32_t *idx, int64_t n, const int64_t *qs, const int64_t *qe, int depth_override) {
     SortGlob acc{idx, qs, qe};
-    ss_std_sort(acc, n, depth_override);
+    int64_t st_first[72], st_last[72];
+    int32_t st_depth[72];
+    ss_std_sort(acc, n, depth_override, st_first, st_last, st_depth);
 }
 }
