@@ -1894,7 +1894,8 @@ AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
         I4 *o = (I4 *)(w.tnx16 + 16 * gv);
         I4 j = w.tnx[gv];
         o[0] = j;
-        for (int t = 1; t < 4; t++) { j = (j.w >= 0) ? w.tnx[vb + j.w] : neg; o[t] = j; }
+        AASM_UNROLL
+        for (int t = 1; t < 4; t++) { const int32_t nx = j.w; j = neg; if (nx >= 0) j = w.tnx[vb + nx]; o[t] = j; }   // (a select between two structs would go through scratch memory)
     }
     for (int64_t t0 = c0; t0 < c1; t0 += 4) {                        // four children per round (their two gathers each issued together)
         int32_t ch[4], sn[4];
