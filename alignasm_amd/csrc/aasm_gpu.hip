@@ -25,9 +25,17 @@ namespace aasm {
 // ------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------
+// XCD-aware block -> work mapping (w.xcd_map): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own, so
+// block b takes work item (b % 8) * (G / 8) + b / 8 - every XCD walks ONE contiguous eighth of the work, and neighbouring items
+// (vertices of one contig, conversions of one contig) meet in one L2 instead of eight
+__device__ inline int64_t xcd_bid(int64_t b, int64_t g, int on) {
+    if (!on || g < 64) return b;
+    const int64_t g8 = g & ~(int64_t)7;
+    return b < g8 ? (b & 7) * (g8 >> 3) + (b >> 3) : b;
+}
 #define AASM_DEF_KERNEL(name, KN, TPB)                                                        \
     __global__ void __launch_bounds__(TPB) name(WS w) {                                       \
-        KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
+        KCtx k{(int)threadIdx.x, (int)blockDim.x, xcd_bid((int64_t)blockIdx.x, (int64_t)gridDim.x, w.xcd_map), (int64_t)gridDim.x,    \
                (int)(threadIdx.x & 63), nullptr};                                             \
         run_kernel_body(KN, k, w);                                                            \
     }
@@ -37,7 +45,7 @@ namespace aasm {
 #define AASM_DEF_KERNEL_LDS(name, KN, TPB, BYTES, WAVES)                                      \
     __global__ void __launch_bounds__(TPB, WAVES) name(WS w) {                                    \
         __shared__ __attribute__((aligned(16))) char smem[BYTES];                             \
-        KCtx k{(int)threadIdx.x, (int)blockDim.x, (int64_t)blockIdx.x, (int64_t)gridDim.x,    \
+        KCtx k{(int)threadIdx.x, (int)blockDim.x, xcd_bid((int64_t)blockIdx.x, (int64_t)gridDim.x, w.xcd_map), (int64_t)gridDim.x,    \
                (int)(threadIdx.x & 63), smem};                                                \
         run_kernel_body(KN, k, w);                                                            \
     }

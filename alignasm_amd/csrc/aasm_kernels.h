@@ -28,6 +28,7 @@ struct WS {
     int64_t C, R, R0, S, VT, ET;
     int32_t K, nsl;
     int32_t avg_sidetracks;              // mean #sidetracks per contig of the batch (K7's wave priority)
+    int32_t xcd_map;                     // kernels take their work items XCD by XCD (aasm_gpu.hip)
     int32_t mw_compact;                  // 1: kb_heap_mw moves its nodes to the final arena (debug runs: arena indices as the reference allocates them); 0: they stay where they were built
     int32_t sort_depth_test;             // 0; tests: kb_sort_fix starts its introsort with (this - 1) partition levels instead of 2 lg N
     // ---- input batch (device), original record order; rec_off already points at the chunk

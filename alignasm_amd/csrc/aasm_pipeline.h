@@ -97,6 +97,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     w.C = C; w.R = R; w.R0 = R0;
     w.K = opts.max_paths > 0 ? opts.max_paths : 10000;
     w.nsl = opts.non_skip_linkable ? 1 : 0;
+    w.xcd_map = (opts.reserved[0] & 32) ? 0 : 1;                      // (bit 5, probes: blocks take work items in grid order)
     w.sort_depth_test = (opts.reserved[2] >> 8) & 0xff;               // test hook: depth limit of kb_sort_fix's introsort
     w.rec_off = in.ctg_rec_off; w.in_qs = in.qry_str; w.in_qe = in.qry_end; w.in_rs = in.ref_str; w.in_re = in.ref_end;
     w.in_qt = in.qry_total; w.in_chr = in.ref_chr; w.in_fwd = in.aln_fwd; w.in_mq = in.map_qul;
@@ -296,7 +297,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             if (by_list) {
                 be.launch(KN_MW_RANK, cdiv(NMW, 256), 256, w);
                 w.mw_base = 0;
-                be.launch(kn, NMW, AASM_WAVE * mw, w);
+                { const int32_t xm = w.xcd_map; w.xcd_map = 0; be.launch(kn, NMW, AASM_WAVE * mw, w); w.xcd_map = xm; }   // (its order is its own)
                 w.mw_base = -1;
             } else be.launch(kn, C, AASM_WAVE * mw, w);
         }

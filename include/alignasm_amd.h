@@ -91,6 +91,7 @@ typedef struct aasm_opts {
                                 *            several-waves-per-contig kernel; bit 2: none of them (default: by graph density);
                                 *            bit 3: K8 on the d-ary heap queue (cross-check of the default sorted-front / sorted-runs queue);
                                 *            bit 4: K8 with the 40-entry front it takes for batches of more than 3 584 contigs
+                                *            bit 5: workgroups take their work items in grid order (default: XCD by XCD, aasm_gpu.hip)
                                 *            bits 8-15: 1 = the several-waves heap kernel launched in input order, a block per contig of
                                 *            the batch (default: a block per contig of its class, largest node bound first); 4 / 8 / 16 =
                                 *            that many waves per contig of the class (default: by how many contigs share the chip)
