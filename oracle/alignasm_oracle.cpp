@@ -44,6 +44,7 @@
 #include <map>
 #include <queue>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <tuple>
 #include <unordered_map>
@@ -338,6 +339,7 @@ struct Debug {
     std::map<std::string, std::vector<int64_t>> arr;
 };
 thread_local Debug *g_dbg = nullptr;
+thread_local bool g_stop_after_k8 = false;   // oracle_time_prefix: return where the reference prefix library ends (paf_data.cpp:738)
 
 struct SolveCounters {
     int64_t V = 0, P = 0, E = 0, heap_nodes = 0, paths_found = 0, paths_converted = 0;
@@ -701,6 +703,7 @@ void solve_ctg_read(const std::vector<Rec> &paf_ctg_data_original, int64_t MAX_P
         A["heap_root"] = solver.h;
     }
 
+    if (g_stop_after_k8) return;
     if (k_path_distances.empty()) { cnt.internal_err++; return; }           // :732 assert
 
     std::unordered_map<int64_t, bool> not_alt_vertex_map;                   // :739-740
@@ -1025,6 +1028,31 @@ int oracle_debug_solve(const aasm_batch_in *in, const aasm_opts *opts, int64_t c
     g_dbg = nullptr;
     return AASM_OK;
 }
+// Wall seconds of K1 ... K8 only (the stretch oracle/_ref/libaasm_ref_prefix.so holds of the REAL function), contigs
+// [c0, c1), one contig per task: the like-for-like partner of refp_time_batch (ref_prefix_driver.cpp).
+double oracle_time_prefix(const aasm_batch_in *in, int64_t c0, int64_t c1, int n_threads, int nsl, int64_t K) {
+    if (!in || c0 < 0 || c1 > in->n_contigs || c0 > c1) return -1.0;
+    if (n_threads < 1) n_threads = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int t) {
+        g_stop_after_k8 = true;
+        std::vector<Rec> recs;
+        CtgResult r;
+        for (int64_t c = c0 + t; c < c1; c += n_threads) {
+            load_contig(in, c, recs);
+            if (!recs.empty()) solve_ctg_read(recs, K, nsl != 0, r.main, r.alt, r.all, r.cnt);
+        }
+        g_stop_after_k8 = false;
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 int64_t oracle_debug_size(const char *name) {
     auto it = g_debug_store.arr.find(name);
     return it == g_debug_store.arr.end() ? -1 : (int64_t)it->second.size();

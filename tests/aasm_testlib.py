@@ -21,6 +21,8 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos.so")
 REF_MONO_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_algos_mono.so")
 REF_CS_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_cs.so")
+REF_PREFIX_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_prefix.so")
+REF_PREFIX_MONO_SO = os.path.join(ROOT, "oracle", "_ref", "libaasm_ref_prefix_mono.so")
 EMUL_SO = os.path.join(ROOT, "tests", "host_emul", "libaasm_emul.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -81,6 +83,85 @@ def ref_cs():
         lib.ref_cs_edit.restype = C.c_int64
         _cache["rcs"] = lib
     return _cache["rcs"]
+
+
+def ref_prefix(mono=True):
+    """oracle/_ref/libaasm_ref_prefix[_mono].so: the REAL solve_ctg_read() from the sort through the k-walk distances
+    (paf_data.cpp:223-738 = K1 ... K8) with its locals copied out, or None where it was not built."""
+    key = "rpm" if mono else "rp"
+    path = REF_PREFIX_MONO_SO if mono else REF_PREFIX_SO
+    if key not in _cache:
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.refp_debug_size.restype = C.c_int64
+        lib.refp_debug_copy.restype = C.c_int64
+        lib.refp_time_batch.restype = C.c_double
+        _cache[key] = lib
+    return _cache[key]
+
+
+# the arrays the reference prefix and the oracle both record (same names, same meaning)
+PREFIX_NAMES = ("perm", "part_idx", "vtx_i", "vtx_j", "pair_pe_q", "pair_pe_r", "pair_st_q", "pair_st_r", "csr_rowptr", "csr_col",
+                "csr_w_qry", "csr_w_ref", "csr_w_anom", "csr_w_qnz", "csr_w_qtot", "anom_dis_dest", "sp_d_qry", "sp_d_ref",
+                "sp_d_anom", "sp_d_qnz", "sp_d_qtot", "sp_best", "rev_order", "fwd_order", "kd_qry", "kd_ref", "kd_anom",
+                "kd_qnz", "kd_qtot", "heap_nodes", "heap_key_qry", "heap_left", "heap_right", "heap_u", "heap_v", "heap_rank", "heap_root")
+# what only the reference prefix records
+PREFIX_EXTRA = ("parts", "pair_ovidx_i", "pair_ovidx_j", "n_index_entries", "csr_w_calcsum", "src_dest", "anom_dis", "heap_key_ref",
+                "heap_key_anom", "heap_key_qnz", "heap_key_qtot", "heap_addr", "k_last", "k_prev", "k_node", "path_off", "path_u",
+                "path_v", "path_w_qry", "path_w_ref", "ctg_sorted_index", "vtx_index_mismatch")
+
+
+def ref_prefix_debug(hb: HostBatch, contig, nsl=False, n_paths=0, mono=True, names=None):
+    """Locals of the REAL solve_ctg_read() at paf_data.cpp:738 for ONE contig (K is the reference's own 10 000)."""
+    lib = ref_prefix(mono)
+    rc = lib.refp_debug_solve(C.byref(hb.view), C.c_int64(contig), 1 if nsl else 0, C.c_int64(n_paths))
+    assert rc == 0, rc
+    out = {}
+    for n in (names or PREFIX_NAMES + PREFIX_EXTRA):
+        sz = lib.refp_debug_size(n.encode())
+        if sz < 0:
+            continue
+        a = np.zeros(sz, np.int64)
+        lib.refp_debug_copy(n.encode(), _P(a), C.c_int64(sz))
+        out[n] = a
+    return out
+
+
+class RefPrefixVectors:
+    """tests/golden/ref_prefix.npz: input batches + what the REAL solve_ctg_read() prefix computed from them
+    (recorded by tests/golden/make_ref_prefix.py from oracle/_ref/libaasm_ref_prefix_mono.so)."""
+
+    def __init__(self, path=None):
+        self.z = np.load(path or os.path.join(GOLDEN, "ref_prefix.npz"))
+        self.tags = [str(t) for t in self.z["tags"]]
+
+    def batch(self, tag):
+        """-> (HostBatch, nsl, all 10 000 distances recorded?)"""
+        A = {}
+        pre = f"{tag}/in/"
+        for k in self.z.files:
+            if k.startswith(pre):
+                name = k[len(pre):]
+                a = self.z[k]
+                if name.endswith("~d"):
+                    name, a = name[:-2], np.cumsum(a.astype(np.int64))
+                A[name] = a
+        A["rng_qry_r"] = A["rng_qry_l"].astype(np.int64) + A.pop("rng_qry_r~len")
+        return HostBatch(A), bool(self.z[f"{tag}/nsl"][0]), bool(self.z[f"{tag}/full"][0])
+
+    def contig(self, tag, c):
+        """The PREFIX_NAMES arrays of contig c (int64), + "kfound" = how many distances the reference found."""
+        out = {}
+        pre = f"{tag}/c{c}/"
+        for k in self.z.files:
+            if k.startswith(pre):
+                name = k[len(pre):]
+                a = self.z[k].astype(np.int64)
+                if name.endswith("~b"):
+                    name, a = name[:-2], np.where(a > 0, np.arange(len(a)) - a, -1)
+                out[name] = a
+        return out
 
 
 _cs_buf = {}
@@ -276,8 +357,11 @@ HNODE_DT = np.dtype([("kq", np.int64), ("kr", np.int64), ("ka", np.int32), ("kn"
                      ("left", np.int32), ("right", np.int32), ("u", np.int32), ("v", np.int32)])
 
 
-def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None):
-    """Compare per-contig intermediates of a product/emulation run with the oracle.
+def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None, expect=None):
+    """Compare per-contig intermediates of a product/emulation run with the oracle - or, with
+    `expect(c)` (a dict of the PREFIX_NAMES arrays: vectors recorded from the REAL reference's
+    solve_ctg_read() prefix, or that library live), with the reference itself.  The reference always
+    runs K = 10 000; a run at a smaller K is compared with the first K distances.
 
     `fetch(name, dtype)` returns the batch-level workspace array `name`.
     Returns a list of (contig, what) mismatches.
@@ -304,7 +388,11 @@ def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None):
         b, N = int(rec_off[c]), int(rec_off[c + 1] - rec_off[c])
         if N <= 1:
             continue
-        o = oracle_debug(hb, c, K, nsl)
+        o = expect(c) if expect is not None else oracle_debug(hb, c, K, nsl)
+        if expect is not None and len(o["kd_qry"]) > K:
+            o = dict(o)
+            for k in ("kd_qry", "kd_ref", "kd_anom", "kd_qnz", "kd_qtot"):
+                o[k] = o[k][:K]
 
         def chk(what, a, bexp):
             if not np.array_equal(np.asarray(a, np.int64), np.asarray(bexp, np.int64)):
@@ -334,10 +422,11 @@ def diff_intermediates(hb, fetch, K=10000, nsl=False, contigs=None):
         chk("rev_order", rev_order[vb:vb + V], o["rev_order"])
         chk("fwd_order", fwd_order[vb:vb + V], o["fwd_order"])
         nf = int(kfound[c])
-        chk("kfound", [nf], [len(o["kd_qry"])])
-        kk = kd[c * K:c * K + nf]
+        ncmp = len(o["kd_qry"])                                        # a recorded list may be cut short ("kfound" = its full length)
+        chk("kfound", [nf], [min(K, int(o["kfound"][0]))] if "kfound" in o else [ncmp])
+        kk = kd[c * K:c * K + min(nf, ncmp)]
         for f, k in (("qry", "kd_qry"), ("ref", "kd_ref"), ("anom", "kd_anom"), ("qnz", "kd_qnz"), ("qtot", "kd_qtot")):
-            chk(k, kk[f], o[k])
+            chk(k, kk[f], o[k][:len(kk)])
         chk("heap_count", [h_cnt[c]], o["heap_nodes"])
         hn = hnodes[int(hoff[c]):int(hoff[c]) + int(h_cnt[c])]
         chk("heap_key_qry", hn["kq"], o["heap_key_qry"]); chk("heap_left", hn["left"], o["heap_left"]); chk("heap_right", hn["right"], o["heap_right"])
