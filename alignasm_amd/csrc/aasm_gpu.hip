@@ -2,7 +2,7 @@
 //
 // * one named __global__ per pipeline kernel (bodies: aasm_kernels.h), so rocprofv3
 //   --kernel-trace shows `aasm_k6_rev_sweep` etc.;
-// * exclusive scans (count -> offsets) as three small kernels;
+// * exclusive scans (count -> offsets): ONE launch each, single pass with decoupled look-back (aasm_scan_chain);
 // * a per-device arena: device memory is carved by bump allocation out of a few large
 //   hipMalloc blocks that persist across solves (no hipMalloc in the steady state);
 // * everything is enqueued on ONE HIP stream per device context; HIP events bracket each
@@ -64,7 +64,7 @@ AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
 AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_w, KN_REV_FILL_W, 64, AASM_REVF_LDS_BYTES, 8)
-AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_ord, KN_REV_FILL_ORD, 64, AASM_REVO_LDS_BYTES, 4)
+AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_ord, KN_REV_FILL_ORD, 64, AASM_REVO_LDS_BYTES, 2)   // 25 KB of LDS per block: 6 blocks per CU, i.e. at most 2 waves per SIMD
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_place, KN_SORT_ROWS_REV, 64, AASM_REVP_LDS_BYTES, 4)
 AASM_DEF_KERNEL(aasm_k6_rev_hdr, KN_REV_HDR, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_sweep, KN_REV_SWEEP, 64, AASM_REV_LDS_BYTES, 8)
@@ -211,12 +211,14 @@ __global__ void __launch_bounds__(64) aasm_sssp_dijkstra_kernel(int64_t n_graphs
 #define SCAN_AGG 1ull
 #define SCAN_PREFIX 2ull
 #define SCAN_HDR 2                           // words ahead of the tile words: ticket, #tiles done
+#define SCAN_STALL_S 10                      // look-back gives up after this many seconds without a published predecessor
+#define SCAN_STALL_SLOT 63                   // word of DevCtx::pinned (host-pinned, device-visible) the stalled lane raises
 __device__ __forceinline__ int64_t scan_wave_incl(int64_t x, int lane) {
     for (int d = 1; d < 64; d <<= 1) { const int64_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
     return x;
 }
 template <class T>
-__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t n, int64_t *out, unsigned long long *scr, int64_t nt) {
+__global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t n, int64_t *out, unsigned long long *scr, int64_t nt, int64_t *stall_flag) {
     __shared__ int64_t sh_wave[SCAN_TPB / 64];
     __shared__ int64_t sh_prefix;
     __shared__ unsigned long long sh_tile;
@@ -244,7 +246,23 @@ __global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t
             for (;;) {
                 const int64_t mine = j - lane;
                 unsigned long long x = SCAN_PREFIX << 62;            // (tiles before the first one: an empty prefix)
-                if (mine >= 0) do { x = __hip_atomic_load(&words[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 62) == 0);
+                if (mine >= 0) {
+                    // a predecessor publishes within microseconds (it took its ticket before this tile did); the guard is for a
+                    // scratch buffer left dirty by an aborted launch: after SCAN_STALL_S seconds the lane gives up, raises the
+                    // host-visible flag (the host turns it into AASM_E_HIP at its next wait) and the launch drains
+                    int64_t polls = 0, t0 = 0;
+                    do {
+                        x = __hip_atomic_load(&words[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((x >> 62) == 0 && (++polls & 4095) == 0) {
+                            const int64_t now = wave_realtime();
+                            if (t0 == 0) t0 = now;
+                            else if (now - t0 > (int64_t)SCAN_STALL_S * 100000000) {
+                                __hip_atomic_store(stall_flag, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                x = SCAN_PREFIX << 62;
+                            }
+                        }
+                    } while ((x >> 62) == 0);
+                }
                 const uint64_t pm = __ballot((x >> 62) == SCAN_PREFIX);
                 const int stop = pm ? __ffsll((long long)pm) - 1 : 64;   // nearest tile that knows its prefix
                 int64_t val = (lane <= stop) ? (int64_t)(x & ((1ull << 62) - 1)) : 0;
@@ -286,7 +304,8 @@ struct DevCtx {
     int64_t *d_scratch2 = nullptr;      // scan tile sums of the side stream
     size_t d_scratch2_cap = 0;
     std::vector<ArenaBlock> blocks;
-    int64_t *pinned = nullptr;          // host-pinned scalar read-back buffer
+    int64_t *pinned = nullptr;          // host-pinned scalar read-back buffer (word SCAN_STALL_SLOT: raised by a scan whose look-back stalled)
+    int64_t *pinned_dev = nullptr;      // the same buffer as the device addresses it
     char *stage[2] = {nullptr, nullptr};   // host-pinned staging chunks of the result fetch (created on first use)
     int64_t *d_scratch = nullptr;       // scan tile sums
     size_t d_scratch_cap = 0;
@@ -339,7 +358,9 @@ static int ctx_init(int device) {
         if ((e = hipEventCreate(cx.timing_event(i))) != hipSuccess) return fail("hipEventCreate", e);
         cx.n_events_made++;
     }
-    if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t))) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void **)&cx.pinned, 64 * sizeof(int64_t), hipHostMallocMapped)) != hipSuccess) return fail("hipHostMalloc", e);
+    std::memset(cx.pinned, 0, 64 * sizeof(int64_t));
+    if ((e = hipHostGetDevicePointer((void **)&cx.pinned_dev, cx.pinned, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
     cx.events = true;
     cx.device = device;
     cx.ready = true;
@@ -392,6 +413,14 @@ struct GpuBackend {
         return p;
     }
     bool failed() const { return fail; }
+    bool test_dirty_scan = false;
+    // a scan's look-back gave up (aasm_scan_chain): every later size is garbage - fail the solve before anything is sized by it
+    bool scan_stalled() {
+        if (!cx.pinned[SCAN_STALL_SLOT]) return false;
+        if (!fail) set_last_error("scan look-back stalled (scratch words left dirty by an aborted launch?)");
+        fail = true;
+        return true;
+    }
     bool oom() const { return out_of_memory; }
     // zero fills of arrays that sit back to back in the arena (the AZ(...) runs of the pipeline) are merged into one
     // memset: a request only extends the pending span; whatever touches the stream next issues it first
@@ -450,7 +479,8 @@ struct GpuBackend {
             if (e == hipSuccess) e = hipMemsetAsync(scr, 0, scr_cap * 8, stream);   // (the scan kernel leaves the words zero again)
             if (e != hipSuccess) { scr = nullptr; scr_cap = 0; hip_fail("hipMalloc(scan)", e); return; }
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_chain<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, (unsigned long long *)scr, nt);
+        if (test_dirty_scan && nt > 1) { (void)hipMemsetAsync(scr, 1, 1, stream); test_dirty_scan = false; }   // ticket counter = 1: tile 0 never runs
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(aasm_scan_chain<T>), dim3((unsigned)nt), dim3(SCAN_TPB), 0, stream, in, n, out, (unsigned long long *)scr, nt, cx.pinned_dev + SCAN_STALL_SLOT);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) hip_fail("scan launch", e);
     }
@@ -463,6 +493,7 @@ struct GpuBackend {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         g_n_stream_syncs++;
         if (e != hipSuccess) { hip_fail("scalar read-back", e); return 0; }
+        if (scan_stalled()) return 0;
         return cx.pinned[0];
     }
     // several scalars, ONE wait: the copies queue up behind the kernels that produce them
@@ -477,6 +508,7 @@ struct GpuBackend {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         g_n_stream_syncs++;
         if (e != hipSuccess) { hip_fail("scalar read-back", e); return; }
+        if (scan_stalled()) return;
         for (i = 0; i < n; i++) out[i] = cx.pinned[i];
     }
     void d2h(void *dst, const void *src, size_t n) {
@@ -485,6 +517,7 @@ struct GpuBackend {
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) hip_fail("hipMemcpy D2H", e);
+        scan_stalled();
     }
     void h2d(void *dst, const void *src, size_t n) {
         flush_zero();
@@ -526,12 +559,14 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     res->device = cx.device; res->stream = stream;
     std::memset(&res->stats, 0, sizeof(res->stats));
     if (timing) hipEventRecord(cx.ev_t0, stream);
+    be->test_dirty_scan = (opts.reserved[2] & 4) != 0;              // test hook: the next scan finds a ticket counter an aborted launch left behind
     int rc = run_pipeline(*be, dev_in, opts, res->w, res->sz);
     be->flush_zero();
     if (timing) hipEventRecord(cx.ev_t1, stream);
     be->join();
     hipError_t e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipStreamSynchronize(cx.side);
+    be->scan_stalled();
     if (rc == AASM_OK && be->failed()) rc = be->oom() ? AASM_E_NOMEM : AASM_E_HIP;
     if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }
     if (rc == AASM_E_PARSE) {
@@ -544,6 +579,7 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
         (void)hipDeviceSynchronize();
         if (cx.d_scratch) (void)hipMemset(cx.d_scratch, 0, cx.d_scratch_cap * 8);
         if (cx.d_scratch2) (void)hipMemset(cx.d_scratch2, 0, cx.d_scratch2_cap * 8);
+        cx.pinned[SCAN_STALL_SLOT] = 0;
         (void)hipGetLastError();
     }
     if (rc != AASM_OK) { delete res; return rc; }

@@ -584,108 +584,123 @@ static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf, int flags
 }
 
 // ---- --alt merge (alignasm.cpp:186-332) ------------------------------------------------
-// Rows of the second PAF are re-alignments of sub-contig pieces named "<contig>:<start>-<end>".
-// Each row is shifted back into contig coordinates; inside a group (same contig, same start)
-// every row whose aln_len / piece_length exceeds ALT_BASELINE is appended to the contig, and
-// if none does, the row with the best ratio is appended when the group ends.
+// Rows of the second PAF are re-alignments of sub-contig pieces named "<contig>:<start>-<end>"; a row moves back into
+// contig coordinates by start - 1.  What the reference's streaming loop amounts to, and how it is done here:
+//   1. every row becomes an AltRec (coordinates shifted, match ranges built) - scan_alt_rows, stops at the first bad row;
+//   2. a PIECE is a maximal run of consecutive rows with one (contig name, shift); pieces are found on the row list;
+//   3. of a piece, the rows whose aln_len / piece_length exceeds the baseline join their contig, in row order; a piece
+//      without such a row contributes its first row of maximal positive ratio instead (and a piece whose ratios are all
+//      <= 0 a zeroed record, as the reference's value-initialised PafReadData, :243,:314);
+//   4. a joining row carries the qry_total of its contig's last record at the time it was read (:269-274): the contig's
+//      own, unless a zeroed record went in before it.
 struct AltRec {
-    int64_t qs, qe, rs, re, qtot, rtot;
-    int32_t chr, mat, aln, row;
-    uint8_t fwd, mq;
+    int64_t qs = 0, qe = 0, rs = 0, re = 0, qtot = 0, rtot = 0;
+    int32_t chr = 0, mat = 0, aln = 0, row = 0;
+    uint8_t fwd = 0, mq = 0, type = 0;             // type: TYPE_ALT for a real row, TYPE_MAIN (0) for the zeroed record
     std::string cs;
     std::vector<int64_t> ql, qr, rl;
+    int32_t ctg = 0;                               // contig the piece name resolves to (unknown names: 0, operator[] at :269)
+    int64_t shift = 0;                             // start - 1 of the piece
+    std::string_view piece;                        // contig part of the piece name (points into the alt text)
+    double ratio = 0;                              // aln_len / piece length (:316)
 };
 
-static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aasm_paf &paf) {
-    const int64_t C = paf.n_contigs();
-    std::unordered_map<std::string, int32_t> chr_map, paf_map;
-    for (size_t i = 0; i < paf.chr_name.size(); i++) chr_map.emplace(paf.chr_name[i], (int32_t)i);
-    for (int64_t c = 0; c < C; c++) paf_map[paf.ctg_name[c]] = (int32_t)c;          // last index wins (:136)
-    std::vector<std::vector<AltRec>> added(C);
+// "<name>:<start>-<end>" -> (name, start - 1); the reference's parseString (:209-233)
+static bool split_piece_name(std::string_view q, std::string_view &name, int64_t &shift, std::string &err) {
+    const size_t colon = q.find(':');
+    if (colon == std::string_view::npos) { err = "Invalid input string format"; return false; }
+    name = q.substr(0, colon);
+    size_t dash = q.find('-', colon + 1);
+    if (dash == std::string_view::npos) dash = q.size();
+    int64_t start;
+    if (!parse_i64(q.substr(colon + 1, dash - colon - 1), start)) { err = "Error parsing number"; return false; }
+    shift = start - 1;
+    return true;
+}
+
+static int scan_alt_rows(const char *text, int64_t len, aasm_paf &paf, std::unordered_map<std::string, int32_t> &chr_map,
+                         const std::unordered_map<std::string_view, int32_t> &ctg_of, std::vector<AltRec> &rows) {
     std::vector<std::string_view> f;
-    // per-contig qry_total of the LAST record (the reference copies it from .back(), :267-272)
-    auto last_qtot = [&](int32_t c) -> int64_t {
-        if (!added[c].empty()) return added[c].back().qtot;
-        return paf.qry_total[paf.ctg_rec_off[c + 1] - 1];
-    };
-    std::string tar_real;
-    int64_t tar_off = -1;
-    bool tar_flag = false, tar_init = false;
-    double tar_ratio = 0;
-    AltRec ratio_max;
-    int32_t ratio_max_ctg = 0;
-    auto flush_group = [&]() {                                                      // :244-252
-        if (!tar_init || tar_flag) return;
-        auto it = paf_map.find(tar_real);
-        added[it == paf_map.end() ? 0 : it->second].push_back(ratio_max);
-        (void)ratio_max_ctg;
-    };
-    int32_t row = 0;
-    int64_t p = 0;
-    while (p < len) {
+    for (int64_t p = 0; p < len;) {
         const char *nl = (const char *)std::memchr(text + p, '\n', len - p);
-        int64_t e = nl ? (nl - text) : len, le = e;
+        const int64_t e = nl ? (nl - text) : len;
+        int64_t le = e;
         if (le > p && text[le - 1] == '\r') le--;
-        if (le > p) {
-            f.clear();
-            int64_t st = p;
-            for (int64_t i = p; i <= le; i++)
-                if (i == le || text[i] == '\t') { f.emplace_back(text + st, i - st); st = i + 1; }
-            if (f.size() < 12) { paf.error = "alt PAF row " + std::to_string(row) + " has fewer than 12 columns"; return AASM_E_PARSE; }
-            std::string qry_chr(f[0]), ref_chr(f[5]);
-            auto ci = chr_map.find(ref_chr);
-            int32_t chr_id;
-            if (ci == chr_map.end()) { chr_id = (int32_t)paf.chr_name.size(); chr_map.emplace(ref_chr, chr_id); paf.chr_name.push_back(ref_chr); }
-            else chr_id = ci->second;
-            // parseString (:209-233): "<name>:<start>-<end>" -> (name, start - 1)
-            size_t colon = qry_chr.find(':');
-            if (colon == std::string::npos) { paf.error = "Invalid input string format"; return AASM_E_PARSE; }
-            std::string real = qry_chr.substr(0, colon);
-            size_t dash = qry_chr.find('-', colon + 1);
-            if (dash == std::string::npos) dash = qry_chr.size();
-            int64_t second;
-            if (!parse_i64(std::string_view(qry_chr).substr(colon + 1, dash - colon - 1), second)) { paf.error = "Error parsing number"; return AASM_E_PARSE; }
-            const int64_t qry_offset = second - 1;
-            auto pm = paf_map.find(real);
-            const int32_t ctg = pm == paf_map.end() ? 0 : pm->second;               // operator[] default (:267)
-            int64_t qtot_piece, qs, qe, rtot, rs, re, mq, mat, aln;
-            if (!parse_i64(f[1], qtot_piece) || !parse_i64(f[2], qs) || !parse_i64(f[3], qe) || !parse_i64(f[6], rtot) ||
-                !parse_i64(f[7], rs) || !parse_i64(f[8], re) || !parse_i64(f[9], mat) || !parse_i64(f[10], aln) || !parse_i64(f[11], mq)) {
-                paf.error = "alt PAF row " + std::to_string(row) + ": non-numeric field";
-                return AASM_E_PARSE;
-            }
-            AltRec r;
-            r.qtot = last_qtot(ctg);
-            r.qs = qs + qry_offset; r.qe = qe + qry_offset - 1;                       // :273-275
-            r.rtot = rtot; r.rs = rs; r.re = re - 1;
-            r.chr = chr_id;
-            r.fwd = (!f[4].empty() && f[4][0] == '+') ? 1 : 0;
-            if (!r.fwd) std::swap(r.rs, r.re);
-            r.mq = (uint8_t)mq;
-            std::string_view cs;
-            for (size_t i = 12; i < f.size(); i++)
-                if (f[i].size() >= 5 && f[i].substr(0, 5) == "cs:Z:") { cs = f[i]; break; }
-            if (cs.empty()) { paf.error = "Missing cs:Z tag in alternative PAF record for query '" + qry_chr + "'"; return AASM_E_PARSE; }
-            r.cs.assign(cs.data(), cs.size());
-            r.mat = (int32_t)mat; r.aln = (int32_t)aln; r.row = row;
-            std::string err;
-            if (match_ranges(cs.data(), (int64_t)cs.size(), r.fwd != 0, r.qs, r.qe, r.rs, r.re, &r.ql, &r.qr, &r.rl, err) < 0) {
-                paf.error = err + " (alt row " + std::to_string(row) + ")";
-                return AASM_E_PARSE;
-            }
-            if (!tar_init || tar_off != qry_offset || tar_real != real) {           // :305-314
-                flush_group();
-                tar_init = true; tar_flag = false; tar_ratio = 0; tar_off = qry_offset; tar_real = real;
-                ratio_max = AltRec();
-            }
-            const double aln_ratio = (double)aln / (double)qtot_piece;                // :316
-            if (aln_ratio > tar_ratio) { tar_ratio = aln_ratio; ratio_max = r; }
-            if (aln_ratio > ALT_BASELINE) { added[ctg].push_back(r); tar_flag = true; }   // :323-327
-            row++;
-        }
+        const int64_t b = p;
         p = e + 1;
+        if (le == b) continue;
+        f.clear();
+        for (int64_t i = b, st = b; i <= le; i++)
+            if (i == le || text[i] == '\t') { f.emplace_back(text + st, i - st); st = i + 1; }
+        const int32_t row = (int32_t)rows.size();
+        if (f.size() < 12) { paf.error = "alt PAF row " + std::to_string(row) + " has fewer than 12 columns"; return AASM_E_PARSE; }
+        AltRec r;
+        r.row = row; r.type = 1;
+        std::string ref_name(f[5]);
+        auto ci = chr_map.find(ref_name);
+        if (ci == chr_map.end()) { ci = chr_map.emplace(ref_name, (int32_t)paf.chr_name.size()).first; paf.chr_name.push_back(ref_name); }
+        r.chr = ci->second;
+        if (!split_piece_name(f[0], r.piece, r.shift, paf.error)) return AASM_E_PARSE;
+        auto ct = ctg_of.find(r.piece);
+        r.ctg = ct == ctg_of.end() ? 0 : ct->second;
+        int64_t piece_len, qs, qe, re, mq, mat, aln;
+        if (!parse_i64(f[1], piece_len) || !parse_i64(f[2], qs) || !parse_i64(f[3], qe) || !parse_i64(f[6], r.rtot) ||
+            !parse_i64(f[7], r.rs) || !parse_i64(f[8], re) || !parse_i64(f[9], mat) || !parse_i64(f[10], aln) || !parse_i64(f[11], mq)) {
+            paf.error = "alt PAF row " + std::to_string(row) + ": non-numeric field";
+            return AASM_E_PARSE;
+        }
+        r.qs = qs + r.shift; r.qe = qe + r.shift - 1;                               // closed interval in contig coordinates (:275-277)
+        r.re = re - 1;
+        r.fwd = (!f[4].empty() && f[4][0] == '+') ? 1 : 0;
+        if (!r.fwd) std::swap(r.rs, r.re);
+        r.mq = (uint8_t)mq; r.mat = (int32_t)mat; r.aln = (int32_t)aln;
+        r.ratio = (double)aln / (double)piece_len;
+        std::string_view cs;
+        for (size_t i = 12; i < f.size() && cs.empty(); i++)
+            if (f[i].substr(0, 5) == "cs:Z:") cs = f[i];
+        if (cs.empty()) { paf.error = "Missing cs:Z tag in alternative PAF record for query '" + std::string(f[0]) + "'"; return AASM_E_PARSE; }
+        r.cs.assign(cs.data(), cs.size());
+        std::string err;
+        if (match_ranges(cs.data(), (int64_t)cs.size(), r.fwd != 0, r.qs, r.qe, r.rs, r.re, &r.ql, &r.qr, &r.rl, err) < 0) {
+            paf.error = err + " (alt row " + std::to_string(row) + ")";
+            return AASM_E_PARSE;
+        }
+        rows.push_back(std::move(r));
     }
-    flush_group();
+    return AASM_OK;
+}
+
+static int merge_alt_text(const char *text, int64_t len, double baseline, aasm_paf &paf) {
+    const int64_t C = paf.n_contigs();
+    std::unordered_map<std::string, int32_t> chr_map;
+    for (size_t i = 0; i < paf.chr_name.size(); i++) chr_map.emplace(paf.chr_name[i], (int32_t)i);
+    std::unordered_map<std::string_view, int32_t> ctg_of;
+    for (int64_t c = 0; c < C; c++) ctg_of[paf.ctg_name[c]] = (int32_t)c;           // a repeated name resolves to its last contig (:136)
+    std::vector<AltRec> rows;
+    if (int rc = scan_alt_rows(text, len, paf, chr_map, ctg_of, rows)) return rc;
+
+    std::vector<std::vector<AltRec>> added(C);
+    std::vector<int64_t> qtot_now(C);                                               // qry_total of each contig's last record so far
+    for (int64_t c = 0; c < C; c++) qtot_now[c] = paf.qry_total[paf.ctg_rec_off[c + 1] - 1];
+    for (size_t g0 = 0, g1; g0 < rows.size(); g0 = g1) {
+        for (g1 = g0 + 1; g1 < rows.size() && rows[g1].shift == rows[g0].shift && rows[g1].piece == rows[g0].piece;) g1++;
+        const int32_t c = rows[g0].ctg;
+        size_t over = 0, top = g1;                                                  // rows above the baseline; first row of the largest positive ratio
+        for (size_t i = g0; i < g1; i++) {
+            rows[i].qtot = qtot_now[c];
+            if (rows[i].ratio > baseline) over++;
+            if (rows[i].ratio > (top == g1 ? 0.0 : rows[top].ratio)) top = i;
+        }
+        if (over) {
+            for (size_t i = g0; i < g1; i++)
+                if (rows[i].ratio > baseline) added[c].push_back(std::move(rows[i]));
+        } else if (top != g1) {
+            added[c].push_back(std::move(rows[top]));
+        } else {
+            added[c].emplace_back();                                                // every ratio <= 0: the zeroed record
+            qtot_now[c] = 0;
+        }
+    }
     // rebuild the flat arrays: every contig = its main records followed by the appended ones
     aasm_paf n;
     n.ctg_name = paf.ctg_name; n.chr_name = paf.chr_name; n.has_cs = paf.has_cs; n.device_ranges = paf.device_ranges;
@@ -706,7 +721,7 @@ static int merge_alt_text(const char *text, int64_t len, double ALT_BASELINE, aa
             n.qry_str.push_back(a.qs); n.qry_end.push_back(a.qe); n.ref_str.push_back(a.rs); n.ref_end.push_back(a.re);
             n.qry_total.push_back(a.qtot); n.ref_total.push_back(a.rtot); n.ref_chr.push_back(a.chr);
             n.mat_num.push_back(a.mat); n.aln_len.push_back(a.aln); n.row_index.push_back(a.row);
-            n.cord_type.push_back(1); n.aln_fwd.push_back(a.fwd); n.map_qul.push_back(a.mq);   // TYPE_ALT (:302)
+            n.cord_type.push_back(a.type); n.aln_fwd.push_back(a.fwd); n.map_qul.push_back(a.mq);   // TYPE_ALT (:302)
             n.cs_pool.insert(n.cs_pool.end(), a.cs.begin(), a.cs.end()); n.cs_off.push_back((int64_t)n.cs_pool.size());
             if (!paf.device_ranges) {
                 n.rng_qry_l.insert(n.rng_qry_l.end(), a.ql.begin(), a.ql.end()); n.rng_qry_r.insert(n.rng_qry_r.end(), a.qr.begin(), a.qr.end());

@@ -94,6 +94,23 @@ def test_hip_failure_is_reported_not_retried_as_out_of_memory(T):
     assert T.diff_outputs(want, api.solve_batch(hb, max_paths=8)) == []
 
 
+def test_stalled_scan_look_back_ends_in_an_error_not_a_hang(T):
+    """aasm_scan_chain's look-back waits for predecessors that took their ticket earlier; a ticket counter left behind by an
+    aborted launch (test hook: opts.reserved[2] bit 2 dirties it ahead of the first scan) means a predecessor that never
+    publishes.  The lanes give up after SCAN_STALL_S seconds, raise a host-visible flag, the launch drains, the solve
+    returns AASM_E_HIP before anything is sized by the scan - and the context is clean for the next solve."""
+    import time
+    api = T.api()
+    hb = T.synth(60, 100, 3)                                       # 6 000 records: the first scan has two tiles
+    t0 = time.time()
+    with pytest.raises(api.AlignasmError) as e:
+        api.solve_batch(hb, max_paths=8, test_dirty_scan=True)
+    assert e.value.code == -3 and "look-back stalled" in str(e.value), str(e.value)
+    assert time.time() - t0 < 60
+    want = T.oracle_solve(hb, 8)
+    assert T.diff_outputs(want, api.solve_batch(hb, max_paths=8)) == []
+
+
 def test_cold_arena_takes_few_device_allocations(T):
     """The workspace arena grows by doubling: a cold solve of a batch that needs GBs takes a handful of
     hipMalloc calls, a warm one none."""

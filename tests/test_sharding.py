@@ -119,3 +119,20 @@ def test_cost_model_sees_graph_density(T):
     mixed["rec_rng_off"] = np.concatenate([a["rec_rng_off"], b["rec_rng_off"][1:] + a["rec_rng_off"][-1]])
     cuts = shard.partition_contigs(HostBatch(mixed), 2)
     assert cuts == [0, 2, 16]
+
+
+def test_bench_without_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start the two ranks itself (it used to run ONE rank and
+    label the line n_gpus 1).  No GPU here, so the ranks end with the product's no-CPU-fallback message - which proves both
+    were started through torch.distributed.run - and the exit code is handed on."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AASM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--contigs", "4", "--recs", "20",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert "without a launcher" in r.stderr and "--nproc-per-node=2" in r.stderr
+    import alignasm_amd
+    if alignasm_amd.device_count() < 1:
+        assert r.returncode != 0
+        assert r.stderr.count("no CPU fallback") >= 2, r.stderr[-1500:]
