@@ -87,6 +87,8 @@ AASM_DEF_KERNEL_LDS(aasm_k8_enum_heap, KN_ENUM_HEAP, 64, AASM_ENUM_LDS_BYTES, 2)
 AASM_DEF_KERNEL_LDS(aasm_k9_select, KN_SELECT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_plan, KN_SEL_PLAN, 64)
 AASM_DEF_KERNEL(aasm_k9_sel_planfill, KN_SEL_PLANFILL, 64)
+AASM_DEF_KERNEL_LDS(aasm_k9_sel_recover, KN_SEL_RECOVER, 64, AASM_SELREC_LDS_BYTES, 8)
+AASM_DEF_KERNEL(aasm_k9_sel_classify, KN_SEL_CLASSIFY, 256)
 AASM_DEF_KERNEL_LDS(aasm_k9_sel_convert, KN_SEL_CONVERT, 64, AASM_SEL_LDS_BYTES, 5)
 AASM_DEF_KERNEL(aasm_k9_sel_final, KN_SEL_FINAL, 64)
 AASM_DEF_KERNEL(aasm_k9_topo_count, KN_TOPO_COUNT, 256)
@@ -457,7 +459,7 @@ struct GpuBackend {
             L(KN_CHILDREN, aasm_k7_children)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
-            L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
+            L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_RECOVER, aasm_k9_sel_recover) L(KN_SEL_CLASSIFY, aasm_k9_sel_classify) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L
             default: break;
         }

@@ -85,7 +85,7 @@ struct WS {
     int32_t *mark_time;                               // per sorted record: first conversion ordinal that marked it
     // ---- parallel conversions (one wave per converted path)
     int32_t *plan_kk;                    // [C * 2 * SEL_PLAN_KEEP] {walk, kind} of a contig's first conversions, from kb_sel_plan to kb_sel_planfill
-    int32_t *nconv, *cv_ctg, *cv_k, *cv_ord, *cv_kind, *cv_szr, *cv_szv, *cv_n, *cv_err, *cv_path, *cv_pre2, *cv_stamp;
+    int32_t *nconv, *cv_ctg, *cv_k, *cv_ord, *cv_kind, *cv_szr, *cv_szv, *cv_n, *cv_err, *cv_path, *cv_pre2, *cv_stamp, *cv_la;
     int64_t *conv_off, *cv_roff, *cv_voff, *cv_cov;
     OutElem *cv_out;
     Dist *cv_dist2;
@@ -2692,16 +2692,26 @@ AASM_DEV void kb_enum_heap(const KCtx &k, const WS &w) {            // one wave 
 // K9  path recovery, upgrade, conversion, selection
 //     (k_shortest_walks.hpp:254-290; paf_data.cpp:750-921,1489-1649)
 // ====================================================================================
+#if defined(AASM_HOST_EMUL)
+static int64_t g_k9_stat[64];                  // emulation-only step statistics of the upgrade loop (tools/k9_steps.py)
+#define K9STAT(i, n) (g_k9_stat[i] += (n))
+#else
+#define K9STAT(i, n) do {} while (0)
+#endif
 struct SelCtx {
     const WS *w;
     int64_t c, b, N, V, vb, cap;     // cap = N + 2 edge pairs per path buffer
     int32_t src, dest;
     int32_t *pathA, *pathB, *pathT, *pre2, *stamp;
     Dist *dist2;
-    OutElem *cur;                    // where sel_convert leaves its elements
-    int32_t epoch, last_head;
+    OutElem *cur;                    // where the conversion leaves its elements
+    int64_t *cls;                    // per edge of pathA {position of its head, v_j << 2 | flags} (sel_classify_edge); lives in the bytes of `cur` until the elements are written
+    int32_t epoch, last_head, last_pos;   // last_pos: topological position of last_head (-1: not known)
+    int32_t res_ppos;                // after a window DP: position of the result's last-but-one vertex
     int32_t *out_dst;
-    int32_t out_n, out_flushed, pa_base;
+    int32_t out_n, out_flushed;
+    int32_t pa_base, pa_n;           // device: edges pa_base .. pa_base + pa_n - 1 of pathA are in the lanes' registers ...
+    int32_t wu, wv, wpv, wvf;        // ... lane t: edge pa_base + t = (wu, wv), position of its head, v_j << 2 | flags
     int32_t cw_pa, cw_n;             // the LDS copy of the topologically ordered CSR: first position (-1: none) and how many (sel_cw_fill)
     bool err, res_lds;
     int lane;
@@ -2717,14 +2727,15 @@ struct SelCtx {
 #define SPROF(s, i) do {} while (0)
 #endif
 
-// ---- LDS working set of kb_select ----------------------------------------------------
+// ---- LDS working set of the conversion kernels ------------------------------------------
 // vmcnt is in-order over loads and stores, so a global store directly ahead of a dependent
-// global load costs a full store round trip.  The selection therefore keeps its small
-// intermediate lists in LDS: the ISPR window + result, a 64-edge read window over the
-// recovered path and a 64-edge write buffer that is flushed by one coalesced store.
+// global load costs a full store round trip.  The conversion therefore keeps its small
+// intermediate lists in LDS: a 64-edge write buffer that is flushed by one coalesced store (first in the
+// block: kb_sel_recover needs nothing else), the window DP's cache + state + result.
 #define ISPR_MAX_E 192
 #define SEL_WIN 64
 struct SelLds {
+    int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
     int64_t wq[ISPR_MAX_E];
     int32_t wr[ISPR_MAX_E];
     int8_t tgt[ISPR_MAX_E];
@@ -2734,19 +2745,16 @@ struct SelLds {
     int8_t pre[64];
     uint8_t reach[64];
     int32_t res[2 * 64];           // ISPR result edges (u, v), reverse order
-    int32_t pa_win[2 * SEL_WIN];   // read window over pathA
-    int32_t pa_vj[SEL_WIN];        // v_j of each window edge's head
-    uint8_t pa_sg[SEL_WIN];        // ... and whether it is a single-record vertex (v_i == v_j): bit 0; bit 1: the ISPR over this edge
-                                   //     and the next one is decided without running it (see sel_pa_get)
-    int32_t pb_buf[2 * SEL_WIN];   // write buffer in front of pathA / pathB
 };
-#define AASM_SEL_LDS_BYTES 7488
+#define AASM_SEL_LDS_BYTES 6656
+#define AASM_SELREC_LDS_BYTES 512
 static_assert(sizeof(SelLds) <= AASM_SEL_LDS_BYTES, "LDS budget");
-// A window DP of 64 ... ISPR_WIDE positions keeps its state in the same bytes: it OVERLAYS the front of the block (the LDS copy of
-// the CSR and the narrow DP's arrays, 5 632 bytes - the copy is given up for the call), so it needs no launch of its own.
+static_assert(offsetof(SelLds, wq) == AASM_SELREC_LDS_BYTES, "kb_sel_recover allocates the write buffer alone");
+// A window DP of 64 ... ISPR_WIDE positions keeps its state in the same bytes: it OVERLAYS the block from the cache on (the LDS copy of
+// the CSR and the narrow DP's arrays - the copy is given up for the call), so it needs no launch of its own.
 #define ISPR_WIDE 127
 struct SelWide { Dist dist[ISPR_WIDE + 1]; int32_t excl[ISPR_WIDE + 2]; int32_t vj[ISPR_WIDE + 1]; uint8_t pre[ISPR_WIDE + 1]; uint8_t reach[ISPR_WIDE + 1]; };
-static_assert(sizeof(SelWide) <= offsetof(SelLds, res), "the wide DP state must end before the result / path-window arrays");
+static_assert(offsetof(SelLds, wq) + sizeof(SelWide) <= offsetof(SelLds, res), "the wide DP state must end before the result array");
 
 AASM_DEV void sel_out_flush(SelCtx &s) {
     SelLds *L = (SelLds *)s.lds;
@@ -2757,89 +2765,34 @@ AASM_DEV void sel_out_flush(SelCtx &s) {
     wave_lds_sync();
 }
 AASM_DEV void sel_out_begin(SelCtx &s, int32_t *dst) { s.out_dst = dst; s.out_n = 0; s.out_flushed = 0; }
-AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v) {
+// append edge (u, v); pos_v = topological position of v (-1: not known)
+AASM_DEV void sel_push(SelCtx &s, int32_t u, int32_t v, int32_t pos_v) {
     SelLds *L = (SelLds *)s.lds;
     if (s.out_n >= s.cap) { s.err = true; return; }
     const int32_t slot = s.out_n - s.out_flushed;
     if (s.lane == 0) { L->pb_buf[2 * slot] = u; L->pb_buf[2 * slot + 1] = v; }
     s.out_n++;
-    s.last_head = v;
+    s.last_head = v; s.last_pos = pos_v;
     if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
 }
-// the same for up to 16 edges at once: lane t < m appends (u, v) of its edge (m wave-uniform, m <= 16 <= SEL_WIN)
+// the same for up to 64 edges at once: lanes l0 .. l0 + m - 1 append (u, v) of their edge, in lane order (l0, m wave-uniform, m <= SEL_WIN).
+// The caller sets last_head / last_pos.
 #if !defined(AASM_HOST_EMUL)
-AASM_DEV void sel_push_lanes(SelCtx &s, int32_t m, int32_t u, int32_t v) {
+AASM_DEV void sel_push_lanes(SelCtx &s, int32_t l0, int32_t m, int32_t u, int32_t v) {
     SelLds *L = (SelLds *)s.lds;
     if (s.out_n + m > s.cap) { s.err = true; return; }
     const int32_t slot0 = s.out_n - s.out_flushed, room = SEL_WIN - slot0;
     const int32_t first = m < room ? m : room;
-    if (s.lane < first) { L->pb_buf[2 * (slot0 + s.lane)] = u; L->pb_buf[2 * (slot0 + s.lane) + 1] = v; }
+    const int32_t k = s.lane - l0;
+    if (k >= 0 && k < first) { L->pb_buf[2 * (slot0 + k)] = u; L->pb_buf[2 * (slot0 + k) + 1] = v; }
     s.out_n += first;
     if (s.out_n - s.out_flushed == SEL_WIN) sel_out_flush(s);
     if (m > first) {
-        if (s.lane >= first && s.lane < m) { L->pb_buf[2 * (s.lane - first)] = u; L->pb_buf[2 * (s.lane - first) + 1] = v; }
+        if (k >= first && k < m) { L->pb_buf[2 * (k - first)] = u; L->pb_buf[2 * (k - first) + 1] = v; }
         s.out_n += m - first;
     }
-    s.last_head = wave_bcast(v, m - 1);
 }
 #endif
-// edge `it` of pathA through a 64-edge LDS window.  A refill also fetches, for every edge of the
-// window at once, whether its head is a single-record vertex and its v_j (what the upgrade asks
-// about every edge), so the edge loop itself has no dependent global loads for them - and it
-// settles the common ISPR calls in advance: for the edge (u, v) followed by (v, nv), if nv sits
-// exactly two topological positions after u (so v is the only vertex between them) and the graph
-// has no edge u -> nv, then u -> v -> nv is the only path of the window from u to nv, whatever the
-// whitelist (v carries it), and internal_shortest_path_recover(u, nv) returns these two edges.
-// The edge loop uses that whenever its continuation vertex is u (99 % of the time).
-#define SETTLE_ROW_MAX 48
-AASM_DEV void sel_pa_get(SelCtx &s, int32_t it, int32_t la, int32_t &u, int32_t &v, int32_t &vj, bool &single, bool &settled) {
-    SelLds *L = (SelLds *)s.lds;
-    const WS &w = *s.w;
-    if (it < s.pa_base || it >= s.pa_base + SEL_WIN) {
-        wave_lds_sync();
-        s.pa_base = it;
-        const int32_t n = (la - it < SEL_WIN) ? (la - it) : SEL_WIN;
-        for (int32_t t = s.lane; t < 2 * n; t += AASM_WAVE) L->pa_win[t] = s.pathA[2 * it + t];
-        for (int32_t t = s.lane; t < n; t += AASM_WAVE) {
-            const int32_t tu = s.pathA[2 * (it + t)], hv = s.pathA[2 * (it + t) + 1];
-            const int32_t a = w.v_i[s.vb + hv], b = w.v_j[s.vb + hv];
-            int32_t fl = (a == b) ? 1 : 0;
-            if (it + t + 1 < la) {
-                const int32_t nvv = s.pathA[2 * (it + t + 1) + 1];
-                const int32_t pu = w.fwd_pos[s.vb + tu], dpos = w.fwd_pos[s.vb + nvv] - pu;
-                const int64_t ur0 = w.rowptr[s.vb + tu], ur1 = w.rowptr[s.vb + tu + 1];
-                if (ur1 - ur0 > SETTLE_ROW_MAX) {}                       // a long row: not worth one lane's scan, the step runs the DP
-                else if (dpos == 2) {
-                    bool has = false;
-                    for (int64_t e = ur0; e < ur1; e++) has |= w.e_col[e] == nvv;
-                    if (!has) fl |= 2;
-                } else if (dpos == 3) {
-                    // one more vertex y in the window: u -> v -> nv stays the only path if there is no edge
-                    // u -> nv, no u -> y -> nv, and no three-hop path through y (u -> y -> v or v -> y -> nv)
-                    const int32_t pv = w.fwd_pos[s.vb + hv];
-                    const bool y_first = pv == pu + 2;
-                    const int32_t y = w.fwd_order[s.vb + (y_first ? pu + 1 : pu + 2)];
-                    bool u_nv = false, u_y = false, y_nv = false, y_v = false, v_y = false;
-                    const int64_t yr0 = w.rowptr[s.vb + y], yr1 = w.rowptr[s.vb + y + 1], vr0 = w.rowptr[s.vb + hv], vr1 = w.rowptr[s.vb + hv + 1];
-                    for (int64_t e = ur0; e < ur1; e++) { const int32_t c2 = w.e_col[e]; u_nv |= c2 == nvv; u_y |= c2 == y; }
-                    const bool short_rows = yr1 - yr0 <= SETTLE_ROW_MAX && (y_first || vr1 - vr0 <= SETTLE_ROW_MAX);
-                    if (short_rows) {
-                        for (int64_t e = yr0; e < yr1; e++) { const int32_t c2 = w.e_col[e]; y_nv |= c2 == nvv; y_v |= c2 == hv; }
-                        if (!y_first) for (int64_t e = vr0; e < vr1; e++) v_y |= w.e_col[e] == y;
-                    }
-                    const bool other = u_nv || !short_rows || (u_y && y_nv) || (y_first ? (u_y && y_v) : (v_y && y_nv));
-                    if (!other) fl |= 2;
-                }
-            }
-            L->pa_vj[t] = b; L->pa_sg[t] = (uint8_t)fl;
-        }
-        wave_lds_sync();
-    }
-    u = uni(L->pa_win[2 * (it - s.pa_base)]); v = uni(L->pa_win[2 * (it - s.pa_base) + 1]);
-    vj = uni(L->pa_vj[it - s.pa_base]);
-    const int32_t fl = uni((int32_t)L->pa_sg[it - s.pa_base]);
-    single = (fl & 1) != 0; settled = (fl & 2) != 0;
-}
 
 // k_shortest_walks.hpp:254-290 -> pathA; returns #edges or -1
 AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
@@ -2866,7 +2819,7 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     while (cv != s.dest || idx >= 0) {
         if (s.err) return -1;
         if (idx >= 0 && cv == st_u) {
-            sel_push(s, cv, st_v);
+            sel_push(s, cv, st_v, -1);
             cv = st_v; idx--;
             if (idx >= 0) { st_u = uni(s.pathT[2 * idx]); st_v = uni(s.pathT[2 * idx + 1]); }
         } else {                                                     // up to sixteen tree edges per load, appended by sixteen lanes
@@ -2875,7 +2828,7 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
             for (int t = 0; t < 16; t++) {
                 const int32_t nx = rec[t];
                 if (nx < 0) { s.err = true; return -1; }
-                sel_push(s, cv, nx);
+                sel_push(s, cv, nx, -1);
                 cv = nx;
                 if (s.err || cv == s.dest || (idx >= 0 && cv == st_u)) break;   // the outer loop decides what comes next
             }
@@ -2888,7 +2841,7 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
             if (bad && ffs64(bad) <= m) { s.err = true; return -1; }
             int32_t from = wave_shfl_up(x, 1, cv);
             if (s.lane == 0) from = cv;
-            sel_push_lanes(s, m, from, x);
+            sel_push_lanes(s, 0, m, from, x);
             cv = wave_bcast(x, m - 1);
 #endif
         }
@@ -2898,6 +2851,53 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
     return s.out_n;
 }
 
+// ---- per-edge classification of a recovered path (one thread per edge) ---------------------
+// What the upgrade asks about EVERY edge t = (u, v) of the path, computed for all edges at once before the sequential
+// steps start (it was done window by window inside them: ~8 dependent round trips per 64 edges, a fifth of a conversion):
+//   * the topological position of its head, v_j of its head, whether the head is a single-record vertex (v_i == v_j);
+//   * SETTLED: for (u, v) followed by (v, nv), internal_shortest_path_recover(u, nv) is decided without running it.  If nv sits
+//     exactly two positions after u (v is the only vertex between them) and the graph has no edge u -> nv, then u -> v -> nv is
+//     the only path of the window, whatever the whitelist (v carries it).  If it sits three positions after u there is one more
+//     vertex y in the window: the same holds if there is no edge u -> nv, no u -> y -> nv, and no three-hop path through y
+//     (u -> y -> v or v -> y -> nv).  The rows of the positions pos(u) ... pos(u) + 2 - u itself and the one or two vertices
+//     in between - are ONE contiguous run of the topologically ordered CSR copy, whose heads are positions already: four row
+//     pointers and one short scan answer all of it (windows with more than SETTLE_SCAN_MAX edges are left to the DP).
+//     The step loop uses it whenever its continuation vertex is u (99 % of the time).
+// Also the tp-flag marks of the un-upgraded path (paf_data.cpp:1490-1496): mark_time[r] = smallest conversion ordinal whose
+// path touched record r.
+// cls[t] = {position of the head, v_j << 2 | settled << 1 | single}.
+#define SETTLE_SCAN_MAX 48
+AASM_DEV void sel_classify_edge(const WS &w, int64_t vb, int32_t dest, const int32_t *pathA, int32_t la, int32_t t, int32_t *mark, int32_t ord, int64_t *cls) {
+    const int32_t tu = pathA[2 * t], hv = pathA[2 * t + 1];
+    const int32_t nvv = (t + 1 < la) ? pathA[2 * t + 3] : -1;
+    const int32_t a = w.v_i[vb + hv], b = w.v_j[vb + hv];
+    const int32_t pu = w.fwd_pos[vb + tu], pv = w.fwd_pos[vb + hv];
+    const int32_t pnv = nvv >= 0 ? w.fwd_pos[vb + nvv] : -1;
+    if (hv != dest) { atomic_min_i32(&mark[a], ord); atomic_min_i32(&mark[b], ord); }
+    int32_t fl = (a == b) ? 1 : 0;
+    const int32_t dpos = pnv - pu;
+    if (nvv >= 0 && (dpos == 2 || dpos == 3)) {
+        const int64_t *tp = w.tp_ptr + vb + pu;
+        const int64_t p0 = tp[0], p1 = tp[1], p2 = tp[2], p3 = (dpos == 3) ? tp[3] : p2;
+        if (p3 - p0 <= SETTLE_SCAN_MAX) {
+            // rows: [p0, p1) = u, [p1, p2) = position pu + 1, [p2, p3) = position pu + 2 (dpos == 3 only)
+            const bool y_first = pv == pu + 2;                       // dpos == 3: the other vertex y sits at pu + 1 (else at pu + 2)
+            const int32_t py = y_first ? pu + 1 : pu + 2;
+            bool u_nv = false, u_y = false, y_nv = false, y_v = false, v_y = false;
+            for (int64_t e = p0; e < p3; e++) {
+                const int32_t tg = w.te_tgt[e];
+                const int32_t row = e < p1 ? 0 : e < p2 ? 1 : 2;    // position pu + row
+                if (row == 0) { u_nv |= tg == pnv; u_y |= tg == py; }
+                else if (pu + row == py) { y_nv |= tg == pnv; y_v |= tg == pv; }
+                else v_y |= tg == py;
+            }
+            const bool other = (dpos == 2) ? u_nv : (u_nv || (u_y && y_nv) || (y_first ? (u_y && y_v) : (v_y && y_nv)));
+            if (!other) { fl |= 2; K9STAT(dpos == 2 ? 16 : 17, 1); }
+        }
+    }
+    cls[t] = (int64_t)(((uint64_t)(((uint32_t)b << 2) | (uint32_t)fl) << 32) | (uint32_t)pv);
+}
+
 // internal_shortest_path_recover (paf_data.cpp:750-792): QRY_SCORE-mode DAG DP over the
 // forward topological window [order[a], order[b)).  The result edges are left in REVERSE
 // order in LDS (res_lds) or in pathT; returns their count, 0 when a == b, -1 on "must not
@@ -2905,14 +2905,17 @@ AASM_DEV int32_t sel_recover(SelCtx &s, int32_t kidx) {
 //
 // Targets beyond position order[b] are never expanded and never lie on the returned path,
 // so relaxing them (as the reference's hash map does) is unobservable and is skipped.
-// Two forms:
-//  * window of <= 63 vertices and <= ISPR_MAX_E edges (the common case): staged in LDS from
-//    the topologically ordered CSR copy by two coalesced load rounds, then the DP runs on
-//    LDS state, lanes sharing one source's edges;
-//  * otherwise: same DP on epoch-stamped global arrays, lanes sharing one source's edges.
+// Forms (sel_ispr picks):
+//  * window of <= ISPR_REG_W positions and <= 64 edges inside the LDS copy (99 % of the calls on sparse graphs): every
+//    edge of the window in a lane's registers, the DP position by position with the candidates folded in lane order
+//    (sel_ispr_reg, device only);
+//  * window of <= 63 vertices and <= ISPR_MAX_E edges: staged in LDS from the topologically ordered CSR copy by two
+//    coalesced load rounds, the DP runs on LDS state, lanes sharing one source's edges;
+//  * up to ISPR_WIDE positions, any number of edges: state in LDS, the rows streamed (sel_ispr_stream);
+//  * otherwise: same DP on epoch-stamped global arrays, lanes sharing one source's edges (sel_ispr_generic).
 // Inside a row targets are distinct, so the lane-parallel relaxation is conflict-free and
 // the sequential source order keeps the reference's strict-`<` first-wins behaviour.
-AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
+AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl, int32_t pa, int32_t pb) {
     // Windows too wide or too dense for LDS (most of a dense graph's): the same DP on epoch-stamped global arrays, indexed by
     // topological POSITION, over the topologically ordered copy of the CSR - a window's positions, rows and state are then
     // consecutive memory: the stamps of 64 positions are one load (a position nobody reached costs nothing; the ones reached
@@ -2920,11 +2923,11 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
     // edge's head position comes with the edge (by vertex id it was order[i] -> stamp -> row pointers -> heads -> positions
     // -> state: five dependent round trips per position, 137 us per call on the dense C5 graphs).
     const WS &w = *s.w;
-    const int32_t *order = w.fwd_order + s.vb, *pos = w.fwd_pos + s.vb;
+    const int32_t *order = w.fwd_order + s.vb;
     const int32_t ep = ++s.epoch;
-    const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
     s.res_lds = false;
     SPROF(s, 5);
+    K9STAT(10, 1);
     if (s.lane == 0) { s.dist2[pa] = dist_zero(); s.pre2[pa] = -1; s.stamp[pa] = ep; }
     wave_fence();
     for (int32_t i0 = pa; i0 < pb; i0 += AASM_WAVE) {
@@ -2955,6 +2958,7 @@ AASM_DEV int32_t sel_ispr_generic(SelCtx &s, int32_t a, int32_t bd, bool wl_flag
         }
     }
     if (uni(s.stamp[pb]) != ep) { s.err = true; return -1; }        // :783
+    s.res_ppos = uni(s.pre2[pb]);
     int32_t n = 0, last = pb;
     while (last != pa) {
         if (n >= s.cap) { s.err = true; return -1; }
@@ -2980,6 +2984,7 @@ AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32
     const int32_t *order = w.fwd_order + s.vb;
     s.res_lds = false;
     SPROF(s, 5);
+    K9STAT(9, 1);
     wave_lds_sync();
     const int64_t e_start = uni(w.tp_ptr[s.vb + pa]);
     for (int32_t t = s.lane; t <= W; t += AASM_WAVE) { X->excl[t] = (int32_t)(w.tp_ptr[s.vb + pa + t] - e_start); X->reach[t] = (t == 0) ? 1 : 0; }
@@ -3023,6 +3028,7 @@ AASM_DEV int32_t sel_ispr_stream(SelCtx &s, const SelStream *X, int32_t a, int32
         }
     }
     if (!uni((int32_t)X->reach[W])) { s.err = true; return -1; }     // :783
+    s.res_ppos = pa + uni((int32_t)X->pre[W]);
     int32_t n = 0, last = W;
     while (last != 0) {
         if (n >= s.cap) { s.err = true; return -1; }
@@ -3046,6 +3052,7 @@ AASM_DEV bool sel_cw_fill(SelCtx &s, int32_t pa, int32_t pb) {      // false: th
     SelLds *L = (SelLds *)s.lds;
     int32_t n = (int32_t)(s.V - pa);                                 // positions of the contig from pa on
     if (n > ISPR_CW) n = ISPR_CW;
+    K9STAT(14, 1);
     wave_lds_sync();                                                 // (earlier calls have read the arrays)
     // round 1: the positions (lane t: position pa + t; lane n: the end of the last row)
 #if defined(AASM_HOST_EMUL)
@@ -3081,50 +3088,169 @@ AASM_DEV bool sel_cw_fill(SelCtx &s, int32_t pa, int32_t pb) {      // false: th
     return true;
 }
 
-AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_t wl) {
-    const WS &w = *s.w;
-    if (a == bd) return 0;
-    const int32_t *pos = w.fwd_pos + s.vb;
-    const int32_t pa = uni(pos[a]), pb = uni(pos[bd]);
+// ---- the path window of the step loop ---------------------------------------------------
+// Edge `it` of pathA with its classification.  Device: 64 consecutive edges live in the lanes' registers (lane t: edge
+// pa_base + t) and an edge is read with v_readlane - no LDS round trip per question; a reload is one 16-byte round trip per
+// lane.  The 1-lane emulation reads the two arrays directly.
+struct SelEdge { int32_t u, v, pv, vj; bool single, settled; };
+#if !defined(AASM_HOST_EMUL)
+AASM_DEV void sel_win_load(SelCtx &s, int32_t it, int32_t la) {
+    s.pa_base = it;
+    s.pa_n = (la - it < AASM_WAVE) ? (la - it) : AASM_WAVE;
+    int32_t u = -1, v = -1, pv = -1, vf = 0;
+    if (s.lane < s.pa_n) {
+        u = s.pathA[2 * (it + s.lane)]; v = s.pathA[2 * (it + s.lane) + 1];
+        const int64_t c = s.cls[it + s.lane];
+        pv = (int32_t)(uint32_t)(uint64_t)c; vf = (int32_t)((uint64_t)c >> 32);
+    }
+    s.wu = u; s.wv = v; s.wpv = pv; s.wvf = vf;
+}
+#endif
+AASM_DEV SelEdge sel_edge(SelCtx &s, int32_t it) {                   // (device: `it` inside the loaded window)
+    SelEdge e;
+#if defined(AASM_HOST_EMUL)
+    e.u = s.pathA[2 * it]; e.v = s.pathA[2 * it + 1];
+    const int64_t c = s.cls[it];
+    e.pv = (int32_t)(uint32_t)(uint64_t)c;
+    const int32_t vf = (int32_t)((uint64_t)c >> 32);
+#else
+    const int32_t l = it - s.pa_base;
+    e.u = __builtin_amdgcn_readlane(s.wu, l); e.v = __builtin_amdgcn_readlane(s.wv, l); e.pv = __builtin_amdgcn_readlane(s.wpv, l);
+    const int32_t vf = __builtin_amdgcn_readlane(s.wvf, l);
+#endif
+    e.vj = vf >> 2; e.single = (vf & 1) != 0; e.settled = (vf & 2) != 0;
+    return e;
+}
+
+// append the result of the LDS / streamed / global-state DP (reverse order in L->res or pathT), optionally without its last edge
+AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last, int32_t pb) {
+    SelLds *L = (SelLds *)s.lds;
+    for (int32_t t = n - 1; t >= (drop_last ? 1 : 0); t--) {
+        int32_t u, v;
+        if (s.res_lds) { u = uni(L->res[2 * t]); v = uni(L->res[2 * t + 1]); }
+        else { u = uni(s.pathT[2 * t]); v = uni(s.pathT[2 * t + 1]); }
+        sel_push(s, u, v, -1);
+    }
+    if (n > (drop_last ? 1 : 0)) s.last_pos = drop_last ? s.res_ppos : pb;
+}
+
+#if !defined(AASM_HOST_EMUL)
+// The window DP with every edge of the window in a lane's registers (W <= ISPR_REG_W positions, <= 64 edges, inside the LDS
+// copy: o = first position relative to the copy).  Lane i holds edge e0 + i of the window's contiguous run of rows: its
+// source position (how many row starts lie at or before it), its head, its weight; cd = dist[source] + weight once the source
+// is final.  Position p = 1 .. W becomes final by folding the candidates of its in-edges IN LANE ORDER - ascending source
+// position, the order the reference relaxes them in (:761-779; the heads of one row are distinct) - with the strict `<` of
+// QRY_SCORE mode: first wins.  The state is wave-uniform and never leaves registers: two LDS round trips (row starts, the
+// lane's edge) + one for the result's vertex ids, against ~4 per SOURCE on LDS state.  The result goes straight into the
+// write buffer, in path order.  Returns the number of result edges (before drop_last), -1 on error, -2: not this form.
+#define ISPR_REG_W 16
+AASM_DEV int32_t sel_ispr_reg(SelCtx &s, int32_t o, int32_t W, int32_t pa, int32_t bd, bool wl_flag, int32_t wl, bool drop_last) {
+    SelLds *L = (SelLds *)s.lds;
+    // row starts of positions o .. o + W (lane t <= W), relative to the first
+    const int32_t xs_abs = L->excl[o + (s.lane <= W ? s.lane : W)];
+    const int32_t e0 = __builtin_amdgcn_readfirstlane(xs_abs);
+    const int32_t xs = xs_abs - e0;
+    const int32_t ne = __builtin_amdgcn_readlane(xs, W);
+    if (ne > AASM_WAVE) return -2;
+    const bool have = s.lane < ne;
+    const int32_t idx = e0 + (have ? s.lane : 0);
+    const int32_t tc = L->tgt[idx];                                  // head relative to the copy's first position (-1: beyond the copy)
+    const int64_t wq = L->wq[idx];
+    const int32_t wr = L->wr[idx];
+    const uint8_t fl = L->fl[idx];
+    int32_t src = 0;                                                 // source position of the lane's edge, relative to the window
+    for (int32_t t = 1; t < W; t++) src += (s.lane >= __builtin_amdgcn_readlane(xs, t)) ? 1 : 0;
+    const int32_t tg = tc - o;
+    bool valid = have && tc >= 0 && tg <= W;                         // (heads behind the window's end are never expanded and never on the path)
+    if (wl_flag) {                                                   // :767-773: the hop into the target only from a vertex of record wl (src / dest have vj < 0)
+        const int32_t svj = L->vj[o + src];
+        valid = valid && !(tg == W && svj != wl);
+    }
+    const Dist ew = edge_dist(wq, wr, fl);
+    Dist cd = ew;                                                    // sources at position 0: dist 0 + weight
+    bool live = src == 0;
+    int32_t prev = 0;                                                // lane p: predecessor position of position p
+    uint32_t reach = 1u;
+    for (int32_t p = 1; p <= W; p++) {
+        uint64_t m = wave_ballot(valid && live && tg == p);
+        if (!m) continue;
+        int j = ffs64(m) - 1;
+        m &= m - 1;
+        LaneArr<Dist> ca; ca.r = cd;
+        Dist best = la_get_dist(ca, j);
+        int32_t bsrc = __builtin_amdgcn_readlane(src, j);
+        while (m) {
+            j = ffs64(m) - 1;
+            m &= m - 1;
+            const Dist c2 = la_get_dist(ca, j);
+            if (dist_lt<QRY_SCORE_MODE>(c2, best)) { best = c2; bsrc = __builtin_amdgcn_readlane(src, j); }
+        }
+        reach |= 1u << p;
+        if (s.lane == p) prev = bsrc;
+        if (src == p) { cd = dist_add(best, ew); live = true; }
+    }
+    s.n_ispr_v += popc64((uint64_t)(reach & ((1u << W) - 1u)));
+    s.n_ispr_e += popc64(wave_ballot(have && ((reach >> src) & 1u)));
+    if (!((reach >> W) & 1u)) { s.err = true; return -1; }          // :783
+    // back along the predecessors: lane k = the k-th edge from the END, (from, to) as window positions
+    int32_t n = 0, last = W, cfrom = 0, cto = 0;
+    while (last != 0) {
+        const int32_t pv = __builtin_amdgcn_readlane(prev, last);
+        if (s.lane == n) { cfrom = pv; cto = last; }
+        n++;
+        last = pv;
+    }
+    const int32_t m_out = drop_last ? n - 1 : n;
+    if (m_out > 0) {
+        const int32_t r = n - 1 - (s.lane < m_out ? s.lane : 0);     // lane k < m_out appends edge k of the path = reverse index n - 1 - k
+        const int32_t pf = __shfl(cfrom, r, 64), pt = __shfl(cto, r, 64);
+        const int32_t uf = L->u[o + pf];
+        const int32_t ut = (pt == W) ? bd : L->u[o + (pt < W ? pt : 0)];
+        sel_push_lanes(s, 0, m_out, uf, ut);
+        s.last_head = __builtin_amdgcn_readlane(ut, m_out - 1);
+        s.last_pos = pa + __builtin_amdgcn_readlane(pt, m_out - 1);
+    }
+    return n;
+}
+#endif
+
+// internal_shortest_path_recover(a, bd) with the result APPENDED to the output (without its last edge if drop_last).
+// pa / pb: topological positions of a / bd.  Returns the number of result edges (0 when a == bd: the caller appends the
+// original edges), -1 on "must not happen".
+AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t pa, int32_t bd, int32_t pb, bool wl_flag, int32_t wl, bool drop_last) {
+    K9STAT(6, 1);
+    if (a == bd) { K9STAT(11, 1); return 0; }
     const int32_t W = pb - pa;
     if (W <= 0) { s.err = true; return -1; }
+    int32_t n;
     if (W > ISPR_CW) {
-        if (W > ISPR_WIDE) return sel_ispr_generic(s, a, bd, wl_flag, wl);
-        SelWide *X = (SelWide *)s.lds;                               // over the LDS copy and the narrow DP's arrays
-        s.cw_pa = -1;
-        const SelStream st{X->dist, X->excl, X->vj, X->pre, X->reach};
-        return sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+        if (W > ISPR_WIDE) n = sel_ispr_generic(s, a, bd, wl_flag, wl, pa, pb);
+        else {
+            SelWide *X = (SelWide *)(s.lds + offsetof(SelLds, wq));  // over the LDS copy and the narrow DP's arrays
+            s.cw_pa = -1;
+            const SelStream st{X->dist, X->excl, X->vj, X->pre, X->reach};
+            n = sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+        }
+        if (n > 0) sel_append_alt(s, n, drop_last, pb);
+        return n;
     }
     SPROF(s, 5);
     SelLds *L = (SelLds *)s.lds;
     if (!(s.cw_pa >= 0 && pa >= s.cw_pa && pb <= s.cw_pa + s.cw_n) && !sel_cw_fill(s, pa, pb)) {   // too many edges for the copy (which is given up: cw_pa = -1)
         const SelStream st{L->dist, L->excl, L->vj, (uint8_t *)L->pre, L->reach};
-        return sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+        n = sel_ispr_stream(s, &st, a, bd, wl_flag, wl, pa, pb);
+        if (n > 0) sel_append_alt(s, n, drop_last, pb);
+        return n;
     }
     const int32_t o = pa - s.cw_pa;                                  // window position t = cached position o + t
     SPROF(s, 2);                                                     // ISPR staging
-    if (W == 2) {
-        // 62 % of the calls: one vertex x between start and target.  If a -> x and x -> target exist, the
-        // last hop from x is allowed and there is no edge a -> target, then a -> x -> target is the only
-        // path in the window and the DP has nothing to decide: one look at the two rows instead of
-        // DP + backtrack.
-        const int32_t e0 = uni(L->excl[o]), ex = uni(L->excl[o + 1]), e2 = uni(L->excl[o + 2]);
-        const int32_t x = uni(L->u[o + 1]);
-        const bool x_ok = !wl_flag || uni(L->vj[o + 1]) == wl;
-        bool direct = false, ax = false, xb = false;
-        for (int32_t idx = e0 + s.lane; idx < e2; idx += AASM_WAVE) {
-            const int32_t rel = (int32_t)L->tgt[idx] - o;            // (a target beyond the copy is stored as -1: never 1 or 2 here)
-            if (idx < ex) { direct |= rel == 2; ax |= rel == 1; } else xb |= rel == 2;
-        }
-        if (x_ok && !wave_ballot(direct) && wave_ballot(ax) && wave_ballot(xb)) {
-            s.n_ispr_v += 2; s.n_ispr_e += e2 - e0;
-            wave_lds_sync();
-            if (s.lane == 0) { L->res[0] = x; L->res[1] = bd; L->res[2] = a; L->res[3] = x; }
-            s.res_lds = true;
-            wave_lds_sync();
-            return 2;
-        }
+#if !defined(AASM_HOST_EMUL)
+    if (W <= ISPR_REG_W) {
+        n = sel_ispr_reg(s, o, W, pa, bd, wl_flag, wl, drop_last);
+        if (n != -2) { SPROF(s, 3); return n; }
     }
+#endif
+    K9STAT(8, 1); K9STAT(15, W);
     for (int32_t t = s.lane; t <= W; t += AASM_WAVE) L->reach[t] = (t == 0) ? 1 : 0;
     if (s.lane == 0) { L->dist[0] = dist_zero(); L->pre[0] = -1; }
     wave_lds_sync();
@@ -3146,7 +3272,9 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     }
     SPROF(s, 3);                                                     // ISPR DP on LDS
     if (!uni((int32_t)L->reach[W])) { s.err = true; return -1; }     // :783
-    int32_t n = 0, last = W;
+    s.res_ppos = pa + uni((int32_t)L->pre[W]);
+    n = 0;
+    int32_t last = W;
     while (last != 0) {
         if (n >= 64) { s.err = true; return -1; }
         const int32_t pv = uni((int32_t)L->pre[last]);
@@ -3157,92 +3285,96 @@ AASM_DEV int32_t sel_ispr(SelCtx &s, int32_t a, int32_t bd, bool wl_flag, int32_
     s.res_lds = true;
     wave_lds_sync();
     SPROF(s, 4);                                                     // ISPR backtrack
+    sel_append_alt(s, n, drop_last, pb);
     return n;
 }
-// append the ISPR result (reverse order), optionally without its last edge
-AASM_DEV void sel_append_alt(SelCtx &s, int32_t n, bool drop_last) {
-    SelLds *L = (SelLds *)s.lds;
-    for (int32_t t = n - 1; t >= (drop_last ? 1 : 0); t--) {
-        int32_t u, v;
-        if (s.res_lds) { u = uni(L->res[2 * t]); v = uni(L->res[2 * t + 1]); }
-        else { u = uni(s.pathT[2 * t]); v = uni(s.pathT[2 * t + 1]); }
-        sel_push(s, u, v);
-    }
-}
 
-// upgrade_edge_path_with_alt_path (paf_data.cpp:795-921): pathA[la] -> pathB; returns lb
+// upgrade_edge_path_with_alt_path (paf_data.cpp:795-921): pathA[la] (classified: s.cls) -> pathB; returns lb
 AASM_DEV int32_t sel_upgrade(SelCtx &s, int32_t la) {
+    const WS &w = *s.w;
     sel_out_begin(s, s.pathB);
-    s.pa_base = -SEL_WIN - 1;
+    s.pa_base = 0; s.pa_n = 0;
+    s.last_head = -1; s.last_pos = -1;
+    const int32_t pos_src = uni(w.fwd_pos[s.vb + s.src]);
     for (int32_t it = 0; it < la && !s.err; ++it) {
-        int32_t u, v, vj;
-        bool v_single, settled;
-        sel_pa_get(s, it, la, u, v, vj, v_single, settled);
+#if !defined(AASM_HOST_EMUL)
+        // the window holds edge `it` and, if there is one, its successor
+        if (it < s.pa_base || it >= s.pa_base + s.pa_n || (it + 1 == s.pa_base + s.pa_n && it + 1 < la)) { SPROF(s, 5); sel_win_load(s, it, la); SPROF(s, 7); }
+#endif
+        const SelEdge e = sel_edge(s, it);
         // A run of edges whose single-record heads are all settled (the other heads are pushed as they are
-        // anyway) comes out of the steps below exactly as it went in - whether a step takes one edge
-        // (:812-833) or two (:834-843) - as long as the continuation vertex is the edge tail, which it
-        // stays inside such a run.  The part of the run inside the window is copied in one piece.
-        if (it > 0 && s.last_head == u && settled) {
-            SelLds *L = (SelLds *)s.lds;
-            const int32_t off = it - s.pa_base, n_win = (la - s.pa_base < SEL_WIN) ? (la - s.pa_base) : SEL_WIN;
-            int32_t mine = n_win;                                    // first edge at or after `it` that the steps have to look at
-            for (int32_t t = off + s.lane; t < n_win; t += AASM_WAVE) {   // (one edge per lane: the window is 64 edges)
-                const int32_t fl = L->pa_sg[t];
-                if ((((fl & 1) && !(fl & 2)) || L->pa_win[2 * t + 1] == s.dest) && t < mine) mine = t;
+        // anyway, whatever the continuation vertex: :866-873) comes out of the steps below exactly as it went in - whether a
+        // step takes one edge (:812-833) or two (:834-843) - as long as the continuation vertex is the edge tail at every
+        // settled head, which it stays inside such a run.  The part of the run inside the window is copied in one piece.
+        if (it > 0 && e.v != s.dest && (!e.single || (e.settled && s.last_head == e.u))) {
+#if defined(AASM_HOST_EMUL)
+            int32_t run = 0;
+            for (int32_t t = it; t < la && run < 64; t++, run++) {
+                const SelEdge x = sel_edge(s, t);
+                if ((x.single && !x.settled) || x.v == s.dest) break;
             }
-            const uint64_t sm = wave_ballot(mine < n_win);
-            const int32_t first = sm ? wave_bcast(mine, ffs64(sm) - 1) : n_win;      // lanes hold ascending edges: the lowest lane has the smallest
-            const int32_t run = first - off;
             if (run >= 2) {
-                if (s.out_n + run > s.cap) { s.err = true; break; }
-                sel_out_flush(s);
-                for (int32_t t = s.lane; t < 2 * run; t += AASM_WAVE) s.out_dst[2 * s.out_n + t] = L->pa_win[2 * off + t];
-                s.out_n += run; s.out_flushed = s.out_n;
-                s.last_head = uni(L->pa_win[2 * (off + run - 1) + 1]);
+                for (int32_t t = it; t < it + run; t++) { const SelEdge x = sel_edge(s, t); sel_push(s, x.u, x.v, x.pv); }
+                K9STAT(2, run);
                 it += run - 1;
                 continue;
             }
+#else
+            const int32_t l = it - s.pa_base;
+            const uint64_t stop = wave_ballot(s.lane >= l && s.lane < s.pa_n && ((((s.wvf & 1) != 0) && !(s.wvf & 2)) || s.wv == s.dest));   // edges the steps have to look at
+            const int32_t first = stop ? ffs64(stop) - 1 : s.pa_n;
+            const int32_t run = first - l;
+            if (run >= 2) {
+                sel_push_lanes(s, l, run, s.wu, s.wv);
+                s.last_head = __builtin_amdgcn_readlane(s.wv, l + run - 1);
+                s.last_pos = __builtin_amdgcn_readlane(s.wpv, l + run - 1);
+                it += run - 1;
+                continue;
+            }
+#endif
         }
-        const bool from_src = (u == s.src);
-        if (from_src || v != s.dest) {
-            int32_t start;
-            if (from_src) start = u;                                 // :804
+        const bool from_src = (e.u == s.src);
+        K9STAT(3, 1);
+        if (from_src || e.v != s.dest) {
+            int32_t start, start_pos;
+            if (from_src) { start = e.u; start_pos = pos_src; }       // :804
             else {
                 if (s.out_n == 0) { s.err = true; break; }
+                if (!e.single) { K9STAT(4, 1); sel_push(s, e.u, e.v, e.pv); continue; }      // :866-873
                 start = s.last_head;                                 // continuation_src (:863)
-                if (!v_single) { sel_push(s, u, v); continue; }      // :866-873
+                start_pos = s.last_pos;
             }
-            const int32_t y = vj;
+            if (start != e.u) K9STAT(12, 1);
+            const int32_t y = e.vj;
             if (it + 1 >= la) { s.err = true; break; }
-            int32_t nu, nv, nvj;
-            bool nvs, nsettled;
-            sel_pa_get(s, it + 1, la, nu, nv, nvj, nvs, nsettled);
-            const bool nv_single = (nv == s.dest) || nvs;
-            const bool known = settled && start == u;                // the call would return (u, v), (v, nv): see sel_pa_get
+            const SelEdge ne = sel_edge(s, it + 1);
+            const bool nv_single = (ne.v == s.dest) || ne.single;
+            const bool known = e.settled && start == e.u;            // the call would return (u, v), (v, nv): see sel_classify_edge
+            if (known) K9STAT(5, 1);
+            if (!known && start_pos < 0) start_pos = uni(w.fwd_pos[s.vb + start]);
             if (nv_single) {                                         // :812-833 / :879-899
-                if (known) sel_push(s, u, v);                        // the result without its last edge
+                if (known) sel_push(s, e.u, e.v, e.pv);              // the result without its last edge
                 else {
-                    const int32_t n = sel_ispr(s, start, nv, true, y);
+                    const int32_t n = sel_ispr(s, start, start_pos, ne.v, ne.pv, true, y, true);
                     if (n < 0) break;
-                    if (n == 0) sel_push(s, u, v);
-                    else sel_append_alt(s, n, true);
+                    if (n == 0) sel_push(s, e.u, e.v, e.pv);
                 }
             } else {                                                 // :834-843 / :900-909
-                if (known) { sel_push(s, u, v); sel_push(s, nu, nv); }
+                if (known) { sel_push(s, e.u, e.v, e.pv); sel_push(s, ne.u, ne.v, ne.pv); }
                 else {
-                    const int32_t n = sel_ispr(s, start, nv, false, -1);
+                    const int32_t n = sel_ispr(s, start, start_pos, ne.v, ne.pv, false, -1, false);
                     if (n < 0) break;
-                    if (n == 0) { sel_push(s, u, v); sel_push(s, nu, nv); }
-                    else sel_append_alt(s, n, false);
+                    if (n == 0) { sel_push(s, e.u, e.v, e.pv); sel_push(s, ne.u, ne.v, ne.pv); }
                 }
                 ++it;
             }
         } else {                                                     // v == dest (:845-858)
+            K9STAT(13, 1);
             if (s.out_n == 0) { s.err = true; break; }
-            const int32_t start = s.last_head;
-            const int32_t n = sel_ispr(s, start, v, false, -1);
+            int32_t start_pos = s.last_pos;
+            if (start_pos < 0) start_pos = uni(w.fwd_pos[s.vb + s.last_head]);
+            const int32_t n = sel_ispr(s, s.last_head, start_pos, e.v, e.pv, false, -1, false);
             if (n < 0) break;
-            if (n > 0) sel_append_alt(s, n, false);
         }
     }
     sel_out_flush(s);
@@ -3254,27 +3386,16 @@ AASM_DEV OutElem out_from_rec(const WS &w, int64_t g) {             // PafOutput
     return o;
 }
 
-// edge_path_to_paf_path (paf_data.cpp:1489-1568): path k -> cur_out; returns #elements, coverage in cov
+// edge_path_to_paf_path (paf_data.cpp:1489-1568), second half: the classified pathA[la] -> upgrade -> cur_out; returns
+// #elements, coverage in cov.
 // The tp flag (:1560-1566) depends on every path converted BEFORE this one (hazard B5):
-// mark_time[r] = smallest conversion ordinal whose un-upgraded path touched record r, and an
-// element of conversion `ord` is_alt iff mark_time[r] > ord.  sel_convert leaves the SORTED
+// mark_time[r] = smallest conversion ordinal whose un-upgraded path touched record r (sel_classify_edge), and an
+// element of conversion `ord` is_alt iff mark_time[r] > ord.  This leaves the SORTED
 // record index in is_alt; copy_resolved() turns it into the flag.
-AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int32_t ord, int64_t &cov) {
+AASM_DEV int32_t sel_upgrade_emit(SelCtx &s, int32_t la, int64_t &cov) {
     const WS &w = *s.w;
     OutElem *out = s.cur;
-    int32_t *mark = w.mark_time + s.b;
     cov = 0;
-    SPROF(s, 7);
-    const int32_t la = sel_recover(s, kidx);
-    if (la <= 0) { s.err = true; return 0; }
-    wave_fence();
-    SPROF(s, 0);                                                     // recover
-    for (int32_t t = s.lane; t < la; t += AASM_WAVE) {               // :1490-1496
-        const int32_t v = s.pathA[2 * t + 1];
-        if (v != s.dest) { atomic_min_i32(&mark[w.v_i[s.vb + v]], ord); atomic_min_i32(&mark[w.v_j[s.vb + v]], ord); }
-    }
-    wave_fence();
-    SPROF(s, 1);                                                     // marking
     const int32_t lb = sel_upgrade(s, la);                           // :1500-1501
     wave_fence();
     SPROF(s, 5);                                                     // upgrade: control + appends (ISPR parts stamped inside)
@@ -3284,6 +3405,7 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int32_t ord, int64_t &cov)
     // v == dest, which is the last edge); a pair vertex v = (x, y) clips the start of its own
     // element to edited_loc_str[x][y] and the END of the previous element to
     // edited_loc_pre_end[x][y], i.e. element t takes its end clip from edge t + 1.
+    // (From here on the bytes of s.cls belong to the elements.)
     if (lb < 2 || s.pathB[2 * (lb - 1) + 1] != s.dest) { s.err = true; return 0; }
     const int32_t n = lb - 1;
     if (n > s.N) { s.err = true; return 0; }
@@ -3306,6 +3428,22 @@ AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int32_t ord, int64_t &cov)
     if (s.lane == 0) atomic_add(&w.counters[CNT_CONVERTED], (int64_t)1);
     s.n_out_e += n;
     return n;
+}
+
+// the whole conversion of walk k by ONE wave (kb_select; the parallel form runs the three stages as three kernels)
+AASM_DEV int32_t sel_convert(SelCtx &s, int32_t kidx, int32_t ord, int64_t &cov) {
+    const WS &w = *s.w;
+    cov = 0;
+    SPROF(s, 7);
+    const int32_t la = sel_recover(s, kidx);
+    if (la <= 0) { s.err = true; return 0; }
+    K9STAT(0, 1); K9STAT(1, la);
+    wave_fence();
+    SPROF(s, 0);                                                     // recover
+    for (int32_t t = s.lane; t < la; t += AASM_WAVE) sel_classify_edge(w, s.vb, s.dest, s.pathA, la, t, w.mark_time + s.b, ord, s.cls);
+    wave_fence();
+    SPROF(s, 1);                                                     // classification + marking
+    return sel_upgrade_emit(s, la, cov);
 }
 
 AASM_DEV void copy_resolved(OutElem *dst, const OutElem *src, int32_t n, const int32_t *mark, int32_t ord, int lane) {
@@ -3407,8 +3545,9 @@ AASM_DEV void sel_ctx_init(SelCtx &s, const KCtx &k, const WS &w, int64_t c) {
     const int64_t gb = w.rec_off[c];
     s.w = &w; s.c = c; s.b = gb - w.R0; s.N = w.rec_off[c + 1] - gb; s.V = w.ctgV[c]; s.vb = w.voff[c]; s.cap = s.N + 2;
     s.src = (int32_t)(s.V - 2); s.dest = (int32_t)(s.V - 1);
-    s.epoch = 0; s.last_head = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
-    s.pa_base = -SEL_WIN - 1; s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
+    s.epoch = 0; s.last_head = -1; s.last_pos = -1; s.res_ppos = -1; s.err = false; s.res_lds = false; s.out_dst = nullptr; s.out_n = s.out_flushed = 0;
+    s.pa_base = 0; s.pa_n = 0; s.wu = s.wv = s.wpv = s.wvf = 0; s.cls = nullptr;
+    s.lane = k.lane; s.lds = k.lds; s.n_ispr_e = s.n_ispr_v = s.n_path_e = s.n_out_e = 0;
     s.cw_pa = -1; s.cw_n = 0;
 }
 AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
@@ -3418,25 +3557,53 @@ AASM_DEV void sel_flush_counters(const SelCtx &s, const WS &w) {
     }
 }
 
+// The conversion of one planned walk as three launches: (1) recovery, a chain of dependent loads, one wave per conversion
+// with nothing but the write buffer in LDS; (2) classification + marking, a thread per path edge; (3) the sequential upgrade
+// steps + the elements, one wave per conversion.
+AASM_DEV void sel_conv_setup(SelCtx &s, const KCtx &k, const WS &w, int64_t j) {
+    sel_ctx_init(s, k, w, w.cv_ctg[j]);
+    const int64_t ro = w.cv_roff[j], vo = w.cv_voff[j];
+    s.pathA = w.cv_path + 6 * ro; s.pathB = s.pathA + 2 * s.cap; s.pathT = s.pathB + 2 * s.cap;
+    s.pre2 = w.cv_pre2 + vo; s.stamp = w.cv_stamp + vo; s.dist2 = w.cv_dist2 + vo;
+    s.cur = w.cv_out + ro; s.cls = (int64_t *)s.cur;
+}
+AASM_DEV void kb_sel_recover(const KCtx &k, const WS &w) {          // one wave per conversion
+    const int64_t j = k.bid;
+    SelCtx s;
+    sel_conv_setup(s, k, w, j);
+    const int32_t la = sel_recover(s, w.cv_k[j]);
+    if (k.lane == 0) w.cv_la[j] = (la <= 0 || s.err) ? -1 : la;
+}
+AASM_DEV void kb_sel_classify(const KCtx &k, const WS &w) {         // one workgroup per conversion, a thread per path edge
+    const int64_t j = k.bid;
+    const int32_t la = w.cv_la[j];
+    if (la <= 0) return;
+    const int64_t c = w.cv_ctg[j], vb = w.voff[c], ro = w.cv_roff[j];
+    const int32_t dest = w.ctgV[c] - 1;
+    const int64_t cap = (w.rec_off[c + 1] - w.rec_off[c]) + 2;
+    (void)cap;
+    int32_t *mark = w.mark_time + (w.rec_off[c] - w.R0);
+    for (int32_t t = k.tid; t < la; t += k.nthreads) sel_classify_edge(w, vb, dest, w.cv_path + 6 * ro, la, t, mark, w.cv_ord[j], (int64_t *)(w.cv_out + ro));
+}
 AASM_DEV void kb_sel_convert(const KCtx &k, const WS &w) {          // one wave per conversion
     const int64_t j = k.bid;
     const int64_t c = w.cv_ctg[j];
     SelCtx s;
-    sel_ctx_init(s, k, w, c);
-    const int64_t ro = w.cv_roff[j], vo = w.cv_voff[j];
-    s.pathA = w.cv_path + 6 * ro; s.pathB = s.pathA + 2 * s.cap; s.pathT = s.pathB + 2 * s.cap;
-    s.pre2 = w.cv_pre2 + vo; s.stamp = w.cv_stamp + vo; s.dist2 = w.cv_dist2 + vo;
-    s.cur = w.cv_out + ro;
+    sel_conv_setup(s, k, w, j);
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     for (int i_ = 0; i_ < 8; i_++) s.kp_acc[i_] = 0;
     __builtin_amdgcn_s_waitcnt(0); s.kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0);
 #endif
     int64_t cov = 0;
-    const int32_t n = sel_convert(s, w.cv_k[j], w.cv_ord[j], cov);
+    int32_t n = 0;
+    const int32_t la = w.cv_la[j];
+    if (la <= 0) s.err = true;
+    else { K9STAT(0, 1); K9STAT(1, la); n = sel_upgrade_emit(s, la, cov); }
     if (k.lane == 0) { w.cv_n[j] = n; w.cv_cov[j] = cov; w.cv_err[j] = s.err ? 1 : 0; }
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
     if (k.lane == 0 && w.cv_ord[j] == 0) for (int i_ = 0; i_ < 8; i_++) w.prof_sel[c * 8 + i_] = s.kp_acc[i_];
 #endif
+    (void)c;
     sel_flush_counters(s, w);
 }
 
@@ -3520,7 +3687,7 @@ AASM_DEV void kb_select(const KCtx &k, const WS &w) {               // one wave 
     for (int i_ = 0; i_ < 8; i_++) s.kp_acc[i_] = 0;
     __builtin_amdgcn_s_waitcnt(0); s.kp_t0 = (int64_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0);
 #endif
-    s.cur = w.cur_out + b;
+    s.cur = w.cur_out + b; s.cls = (int64_t *)s.cur;
     const int32_t *mark = w.mark_time + b;
     int32_t ord = 0;                                                // conversion ordinal (hazard B5)
     const Dist *kd = w.kd + c * (int64_t)w.K;

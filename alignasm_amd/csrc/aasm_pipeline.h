@@ -24,7 +24,7 @@ enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
-    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_CONVERT, KN_SEL_FINAL
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -73,6 +73,8 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_TOPO_FILL: kb_topo_fill(k, w); break;
         case KN_SEL_PLAN: kb_sel_plan(k, w); break;
         case KN_SEL_PLANFILL: kb_sel_planfill(k, w); break;
+        case KN_SEL_RECOVER: kb_sel_recover(k, w); break;
+        case KN_SEL_CLASSIFY: kb_sel_classify(k, w); break;
         case KN_SEL_CONVERT: kb_sel_convert(k, w); break;
         case KN_SEL_FINAL: kb_sel_final(k, w); break;
         default: break;
@@ -340,7 +342,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         if (NCONV > 0) {
             A(cv_ctg, int32_t, NCONV, "cv_ctg"); A(cv_k, int32_t, NCONV, "cv_k"); A(cv_ord, int32_t, NCONV, "cv_ord"); A(cv_kind, int32_t, NCONV, "cv_kind");
             A(cv_szr, int32_t, NCONV, "cv_szr"); A(cv_szv, int32_t, NCONV, "cv_szv"); A(cv_roff, int64_t, NCONV + 1, "cv_roff"); A(cv_voff, int64_t, NCONV + 1, "cv_voff");
-            AZ(cv_n, int32_t, NCONV, "cv_n"); AZ(cv_err, int32_t, NCONV, "cv_err"); AZ(cv_cov, int64_t, NCONV, "cv_cov");
+            AZ(cv_n, int32_t, NCONV, "cv_n"); AZ(cv_err, int32_t, NCONV, "cv_err"); AZ(cv_cov, int64_t, NCONV, "cv_cov"); A(cv_la, int32_t, NCONV, "cv_la");
             CHECK_ALLOC();
             be.launch(KN_SEL_PLANFILL, C, AASM_WAVE, w);
             be.scan_i32(w.cv_szr, NCONV, w.cv_roff);
@@ -359,6 +361,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             A(cv_dist2, Dist, SV, "cv_dist2"); A(cv_pre2, int32_t, SV, "cv_pre2"); AZ(cv_stamp, int32_t, SV, "cv_stamp");
             CHECK_ALLOC();
             be.phase_begin(AASM_PH_SELECT);
+            be.launch(KN_SEL_RECOVER, NCONV, AASM_WAVE, w);
+            be.launch(KN_SEL_CLASSIFY, NCONV, 256, w);
             be.launch(KN_SEL_CONVERT, NCONV, AASM_WAVE, w);
             be.phase_end(AASM_PH_SELECT);
         }

@@ -54,7 +54,7 @@ struct EmuBackend {
     static int nthreads_emul(int kn, int nthreads) {
         switch (kn) {
             case KN_SORT_FIX: case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_SORT_ROWS_REV: case KN_REV_FILL_W: case KN_REV_FILL_ORD: case KN_SIDETRACK_W:
-            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_REV_SWEEP_G: case KN_FWD_SWEEP_G: case KN_HEAP: case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
+            case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_REV_SWEEP_G: case KN_FWD_SWEEP_G: case KN_HEAP: case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_RECOVER: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
                 return 1;
             default: return nthreads;
         }
@@ -76,6 +76,8 @@ WS g_ws;
 }  // namespace
 
 extern "C" {
+// K9 step statistics of the last solves (tools/k9_steps.py); reset = 1 clears them
+void emul_k9_stats(int64_t *dst, int reset) { for (int i = 0; i < 64; i++) { dst[i] = aasm::g_k9_stat[i]; if (reset) aasm::g_k9_stat[i] = 0; } }
 static int64_t g_bad_record = -1;
 int64_t emul_last_bad_record() { return g_bad_record; }   // record whose cs tag K0 rejected (AASM_E_PARSE)
 int emul_solve_batch(const aasm_batch_in *in, const aasm_opts *opts, aasm_batch_out *out) {
