@@ -2873,7 +2873,10 @@ AASM_DEV void sel_classify_edge(const WS &w, int64_t vb, int32_t dest, const int
     const int32_t a = w.v_i[vb + hv], b = w.v_j[vb + hv];
     const int32_t pu = w.fwd_pos[vb + tu], pv = w.fwd_pos[vb + hv];
     const int32_t pnv = nvv >= 0 ? w.fwd_pos[vb + nvv] : -1;
-    if (hv != dest) { atomic_min_i32(&mark[a], ord); atomic_min_i32(&mark[b], ord); }
+    if (hv != dest) {                                                // (a record the main path marked needs no atomic from the tie / alt walks)
+        atomic_min_i32(&mark[a], ord);                                // (fire and forget: a look at mark[] first would make it a dependent pair)
+        if (b != a) atomic_min_i32(&mark[b], ord);
+    }
     int32_t fl = (a == b) ? 1 : 0;
     const int32_t dpos = pnv - pu;
     if (nvv >= 0 && (dpos == 2 || dpos == 3)) {

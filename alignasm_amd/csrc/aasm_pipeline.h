@@ -233,22 +233,27 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(tp_deg, int32_t, VT, "tp_deg"); A(tp_vj, int32_t, VT, "tp_vj"); A(tp_ptr, int64_t, VT + 1, "tp_ptr");
         A(te_tgt, int32_t, ET, "te_tgt"); A(te_wq, int64_t, ET, "te_wq"); A(te_wr, int32_t, ET, "te_wr"); A(te_fl, uint8_t, ET, "te_fl");
         CHECK_ALLOC();
-        be.fork();                                                   // side stream waits for everything enqueued so far
-        be.use_side(true);
-        be.phase_begin(AASM_PH_FWD);
         // big sparse batches (mean degree <= 6, thousands of contigs: bound by instruction issue): two contigs per wave,
         // AASM_SWEEP_G lanes each; dense ones and small batches (bound by the chain per contig): a wave per contig
         const bool grouped = ET <= 6 * VT && C >= 2560;            // (few contigs: a wave each - the scalar-uniform variant has the shorter chain per pop)
         const int64_t sweep_n = AASM_WAVE / AASM_SWEEP_G;
-        if (grouped) be.launch(KN_FWD_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
-        else be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
-        be.phase_end(AASM_PH_FWD);
-        be.phase_begin(AASM_PH_TOPO);
-        be.launch(KN_TOPO_COUNT, cdiv(VT, 256), 256, w);
-        be.scan_i32(w.tp_deg, VT, w.tp_ptr);
-        be.launch(KN_TOPO_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
-        be.phase_end(AASM_PH_TOPO);
-        be.use_side(false);
+        auto side_work = [&]() {
+            be.fork();                                               // side stream waits for everything enqueued so far
+            be.use_side(true);
+            be.phase_begin(AASM_PH_FWD);
+            if (grouped) be.launch(KN_FWD_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
+            else be.launch(KN_FWD_SWEEP, C, AASM_WAVE, w);
+            be.phase_end(AASM_PH_FWD);
+            be.phase_begin(AASM_PH_TOPO);
+            be.launch(KN_TOPO_COUNT, cdiv(VT, 256), 256, w);
+            be.scan_i32(w.tp_deg, VT, w.tp_ptr);
+            be.launch(KN_TOPO_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
+            be.phase_end(AASM_PH_TOPO);
+            be.use_side(false);
+        };
+        // (Measured in round 4, same box: started after the reverse sweep instead, or beside K7 only, the reverse sweep drops to 1.98 ms
+        // but K7 beside it rises 4.10 -> 4.6 / 5.0 ms and the step 12.60 -> 12.99 / 12.91: every chain kernel is short of issue slots.)
+        side_work();
         be.phase_begin(AASM_PH_SPTREE);
         if (grouped) be.launch(KN_REV_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
         else be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
