@@ -25,6 +25,16 @@
 //  refill (F ran empty): the 64 smallest of the run heads (one block per level, merged keeping the
 //      lower half, each entry tagged with its level so the heads can be advanced).
 //
+// FAR TIER (round 4).  Every pop pushes up to three successors, 30 000 for K = 10 000, and two thirds of them are never
+// popped: sorting them into runs was 47 % of the kernel.  A pushed score sum is never below the popped one (sidetrack keys
+// are >= 0, heap children >= their parent), so the queue is split by a threshold T on the score sum: entries with sum <= T
+// live in F / I / R as above; entries with sum > T are APPENDED, unsorted, to a far buffer in global memory - one coalesced
+// store, no sort, no merge.  When the near tier runs empty the far buffer is scanned once: T moves up to the lower quartile
+// of a 64-entry sample of it, the entries at or below the new T go through I into the runs, the rest are compacted in
+// place (entries that cannot be popped any more - not below the bound - are dropped on the way).  On the bench's graphs
+// 11-13 k of the 30 k pushes ever reach the sorted tier, in ~8 scans of ~19 k entries altogether; 18 k stay where they
+// were appended.  The pop sequence is unchanged: near entries are all smaller than far ones.
+//
 // Order key.  (Distance, node, index) compares the score sum, then anom, then the ratio
 // qul_nonzero / qul_total (higher first, by cross-multiplication: paf_data.hpp:142-159), then node and
 // index.  Cross-multiplying in every compare-exchange of the networks would cost four quarter-rate
@@ -51,7 +61,8 @@ namespace aasm {
 #endif
 AASM_HD int64_t enum_k64(int64_t K) { return (K + 63) / 64 * 64; }
 AASM_HD int32_t enum_lmax(int64_t K) { int32_t l = 0; while (((int64_t)64 << l) < enum_k64(K)) l++; return l; }
-AASM_HD int64_t enum_stride(int64_t K) { return 128 * (((int64_t)1 << enum_lmax(K)) - 1) + 3 * enum_k64(K); }
+AASM_HD int64_t enum_far_off(int64_t K) { return 128 * (((int64_t)1 << enum_lmax(K)) - 1) + 3 * enum_k64(K); }   // the runs; behind them the far tier
+AASM_HD int64_t enum_stride(int64_t K) { return enum_far_off(K) + 3 * enum_k64(K) + 64; }                            // (every push may land there: <= 3 K)
 #define AASM_ENUM_MAX_N (((int64_t)1 << 20) - 2)     // longest contig (records) the key2 form is exact for
 }  // namespace aasm
 
@@ -182,6 +193,9 @@ template <int FMAX> struct EnumQT {
     int32_t in;                          // entries in I
     int32_t nruns;                       // non-empty levels
     QE bound;                            // nothing >= bound can still be popped (+inf: no bound yet)
+    uint64_t T;                          // far tier: entries with sum > T sit, unsorted, in far[0 .. far_n)
+    PqK *far;
+    int32_t far_n;
 };
 template <class Q> AASM_DEV int32_t eq_cap(const Q &q, int32_t l) { const int64_t c = (int64_t)64 << l; return l < q.lmax && c < q.k64 ? (int32_t)c : q.k64; }
 template <class Q> AASM_DEV PqK *eq_slot(const Q &q, int32_t l, int32_t s) {
@@ -266,6 +280,36 @@ template <class Q> AASM_DEV void eq_flush(Q &q, int32_t keep, int lane) {
     wave_lds_sync();
 }
 
+// The near tier is empty: move T up and bring the far entries at or below it into the runs (through I).  T = the lower
+// quartile of a 64-entry sample of the far buffer (any value of the sample makes progress: that entry itself moves).
+template <class Q> AASM_DEV void eq_redistribute(Q &q, int32_t keep, int lane) {
+    wave_fence();                                                    // the far entries were stored by lanes of this wave
+    const int32_t n = q.far_n;
+    const int32_t ns = n < 64 ? n : 64;
+    QE sm = qe_inf();
+    if (lane < ns) { const int32_t at = n < 64 ? lane : (int32_t)(((int64_t)lane * n) >> 6); sm = qe_load(q.far + at, 0, 1, 0); sm.key2 = 0; sm.nc = (uint64_t)lane; }
+    qe_sort64(sm, lane);
+    q.T = uni_u64(sm.sum, (ns + 3) / 4 - 1);
+    int32_t wr = 0;
+    for (int32_t base = 0; base < n; base += 64) {
+        const QE e = qe_load(q.far, base, n, lane);
+        const bool live = base + lane < n && qe_less(e, q.bound);    // (what is not below the bound can never be popped)
+        const bool near = live && e.sum <= q.T;
+        const uint64_t nm = wave_ballot(near), sm2 = wave_ballot(live && !near);
+        const int32_t cnt = popc64(nm);
+        if (cnt) {
+            if (q.in + cnt > EQ_ILEN) { wave_lds_sync(); eq_flush(q, keep, lane); }
+            if (near) qe_to_lds(q.L->ibuf[q.in + popc64(nm & lanemask_lt(lane))], e);
+            q.in += cnt;
+        }
+        if (live && !near) qe_store(q.far, wr + popc64(sm2 & lanemask_lt(lane)), e);   // in place: wr + rank <= base + lane, and the block is in registers
+        wr += popc64(sm2);
+    }
+    q.far_n = wr;
+    wave_lds_sync();
+    wave_fence();
+}
+
 template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
@@ -282,6 +326,7 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
     const int32_t src = (int32_t)(V - 2);
     EnumQT<FMAX> q;
     q.L = (EnumLdsT<FMAX> *)k.lds; q.g = w.pq + c * w.pq_stride; q.lmax = enum_lmax(K); q.k64 = (int32_t)enum_k64(K); q.in = 0; q.nruns = 0; q.bound = qe_inf();
+    q.T = 0; q.far = q.g + enum_far_off(K); q.far_n = 0;
     if (lane < EQ_MAXLEV) { q.L->run_slot[lane] = 0; q.L->run_head[lane] = 0; q.L->run_end[lane] = 0; }
     wave_lds_sync();
 
@@ -337,6 +382,7 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
         o0.x = uni(lo32((uint64_t)d0.qry)); o0.y = uni(hi32((uint64_t)d0.qry)); o0.z = uni(d0.anom); o0.w = uni(d0.qnz); o1.x = uni(d0.qtot); o1.y = -1; o1.z = 0; o1.w = 0;
         if (lane == 0) { I4 cd; cd.x = hs; cd.y = -1; cd.z = o0.x; cd.w = o0.y; kcand[0] = cd; I4 ce; ce.x = o0.z; ce.y = o0.w; ce.z = o1.x; ce.w = 0; kcand[1] = ce; }
         nn = 1;
+        q.T = x.sum;                                                 // the near tier starts with the first entry's score sum
         wave_lds_sync();
         f_insert(x, o0, o1);
     }
@@ -347,7 +393,12 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
     while (found < K) {                                              // :240-248
         KPROF_STAMP(0);                                              // pops + pushes
         const bool need_refill = hd == nf;
-        if (need_refill && q.in == 0 && q.nruns == 0) break;         // queue empty
+        if (need_refill && q.in == 0 && q.nruns == 0) {
+            if (q.far_n == 0) break;                                 // queue empty
+            eq_redistribute(q, K - found, lane);                     // near tier empty: the next slice of the far one
+            KPROF_STAMP(4);
+            if (q.in == 0 && q.nruns == 0 && q.far_n == 0) break;    // (everything left was beyond the bound)
+        }
         if (q.in > EQ_IFLUSH || (need_refill && q.in > 0)) { wave_lds_sync(); eq_flush(q, K - found, lane); KPROF_STAMP(1); }
         if (need_refill) {
             // ---- the 64 smallest entries of the run heads
@@ -488,7 +539,14 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
             kcand[2 * (int64_t)xcur] = cd; kcand[2 * (int64_t)xcur + 1] = ce;
         }
         nn += popc64(vm);
-        const bool live = valid && qe_less(x, q.bound);              // (the others can never be popped: dropped here)
+        const bool alive = valid && qe_less(x, q.bound);             // (the others can never be popped: dropped here)
+        const bool isfar = alive && x.sum > q.T;                     // beyond the threshold: appended, unsorted
+        const uint64_t fm = wave_ballot(isfar);
+        if (fm) {
+            if (isfar) qe_store(q.far, q.far_n + popc64(fm & lanemask_lt(lane)), x);
+            q.far_n += popc64(fm);
+        }
+        const bool live = alive && !isfar;
         const uint64_t lm = wave_ballot(live);
         if (lm == 0) continue;
         const bool behind = q.in != 0 || q.nruns != 0;               // something behind F: an entry >= max(F) goes to I (else F may grow at its end)
