@@ -320,10 +320,10 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(kcand, I4, 2 * C * (3 * K + 1), "kcand"); A(pq, PqK, C * w.pq_stride, "pq");
         CHECK_ALLOC();
         be.phase_begin(AASM_PH_ENUM);
-        // a few more contigs than the 64-entry front keeps resident (14 waves per CU = 3 584): the 40-entry front (18 per CU = 4 608) runs them
-        // in one residency round (4 000 contigs: 28.0 -> 25.7 ms); beyond that its extra refills and flushes cost more than the second round
-        // of the big front (5 000 contigs: 31.5 vs 30.2 ms)
-        be.launch(enum_heap ? KN_ENUM_HEAP : ((C > 14 * 256 && C <= 18 * 256 && K > 21) || (opts.reserved[0] & 16)) ? KN_ENUM_S : KN_ENUM, C, AASM_WAVE, w);
+        // more contigs than the 64-entry front keeps resident (14 waves per CU = 3 584): the 40-entry front (20 per CU = 5 120) runs them
+        // in one residency round (round 4, with the far tier: 5 000 contigs 23.85 -> 23.1 ms; round 3, without it, the extra refills and
+        // flushes of the small front cost more than the second round: 30.2 vs 31.5 ms); beyond 5 120 both take a second round
+        be.launch(enum_heap ? KN_ENUM_HEAP : ((C > 14 * 256 && C <= 20 * 256 && K > 21) || (opts.reserved[0] & 16)) ? KN_ENUM_S : KN_ENUM, C, AASM_WAVE, w);
         be.phase_end(AASM_PH_ENUM);
     }
 
