@@ -72,6 +72,7 @@ AASM_DEF_KERNEL_LDS(aasm_k5_fwd_sweep, KN_FWD_SWEEP, 64, AASM_FWD_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_sweep_g, KN_REV_SWEEP_G, 64, (AASM_WAVE / AASM_SWEEP_G) * AASM_REV_LDS_BYTES, 4)
 AASM_DEF_KERNEL_LDS(aasm_k5_fwd_sweep_g, KN_FWD_SWEEP_G, 64, (AASM_WAVE / AASM_SWEEP_G) * AASM_FWD_LDS_BYTES, 4)
 AASM_DEF_KERNEL(aasm_k7_children, KN_CHILDREN, 256)
+AASM_DEF_KERNEL(aasm_k7_child_side, KN_CHILD_SIDE, 256)
 AASM_DEF_KERNEL(aasm_k7_heap_cap, KN_HEAP_CAP, 256)
 AASM_DEF_KERNEL(aasm_k7_sidetrack, KN_SIDETRACK, 256)
 AASM_DEF_KERNEL_LDS(aasm_k7_sidetrack_w, KN_SIDETRACK_W, 64, AASM_SIDE_LDS_BYTES, 8)
@@ -293,6 +294,13 @@ __global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t
     }
 }
 
+// ---- scalar read-back: up to eight device words -> the host-mapped pinned words, ONE launch (it was a copyBuffer per word) ----
+struct ScalarSrc { const int64_t *p[8]; };
+__global__ void aasm_read_scalars(ScalarSrc src, int n, int64_t *dst) {
+    const int i = (int)threadIdx.x;
+    if (i < n) __hip_atomic_store(dst + i, *src.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------
 // device context + backend
 // ------------------------------------------------------------------------------------
@@ -456,7 +464,7 @@ struct GpuBackend {
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
             L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord)
             L(KN_SORT_ROWS_REV, aasm_k6_rev_place) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
-            L(KN_CHILDREN, aasm_k7_children)
+            L(KN_CHILDREN, aasm_k7_children) L(KN_CHILD_SIDE, aasm_k7_child_side)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
             L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_RECOVER, aasm_k9_sel_recover) L(KN_SEL_CLASSIFY, aasm_k9_sel_classify) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
@@ -488,25 +496,20 @@ struct GpuBackend {
     }
     void scan_i32(const int32_t *in, int64_t n, int64_t *out) { scan_t<int32_t>(in, n, out); }
     void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { scan_t<uint8_t>(in, n, out); }
-    int64_t read_i64(const int64_t *p) {
-        flush_zero();
-        if (fail) return 0;
-        hipError_t e = hipMemcpyAsync(cx.pinned, p, 8, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        g_n_stream_syncs++;
-        if (e != hipSuccess) { hip_fail("scalar read-back", e); return 0; }
-        if (scan_stalled()) return 0;
-        return cx.pinned[0];
-    }
-    // several scalars, ONE wait: the copies queue up behind the kernels that produce them
+    int64_t read_i64(const int64_t *p) { int64_t v = 0; read_i64s({p}, &v); return v; }
+    // several scalars, ONE launch and ONE wait: the kernel queues up behind the kernels that produce them and stores into the
+    // host-mapped pinned words (kernel completion at the stream sync makes system-scope stores visible to the host)
     void read_i64s(std::initializer_list<const int64_t *> ps, int64_t *out) {
         int n = 0;
         for (auto p : ps) { (void)p; out[n++] = 0; }
         flush_zero();
         if (fail) return;
-        hipError_t e = hipSuccess;
+        ScalarSrc src;
         int i = 0;
-        for (auto p : ps) { if (e == hipSuccess) e = hipMemcpyAsync(cx.pinned + i, p, 8, hipMemcpyDeviceToHost, stream); i++; }
+        for (auto p : ps) { if (i < 8) src.p[i] = p; i++; }
+        for (int j = i; j < 8; j++) src.p[j] = nullptr;
+        hipLaunchKernelGGL(aasm_read_scalars, dim3(1), dim3(64), 0, stream, src, n, cx.pinned_dev);
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         g_n_stream_syncs++;
         if (e != hipSuccess) { hip_fail("scalar read-back", e); return; }

@@ -3395,6 +3395,21 @@ AASM_DEV OutElem out_from_rec(const WS &w, int64_t g) {             // PafOutput
 // mark_time[r] = smallest conversion ordinal whose un-upgraded path touched record r (sel_classify_edge), and an
 // element of conversion `ord` is_alt iff mark_time[r] > ord.  This leaves the SORTED
 // record index in is_alt; copy_resolved() turns it into the flag.
+// element t of the upgraded path pathB[lb] (:1503-1557 as a map over path edges): edge t = (u, v) emits record cur(v) (nothing for
+// v == dest, which is the last edge); a pair vertex v = (x, y) clips the start of its own element to edited_loc_str[x][y] and the
+// END of the previous element to edited_loc_pre_end[x][y], i.e. element t takes its end clip from edge t + 1.  Returns the
+// element's coverage term (get_total_coverage, :1571-1579), -1 for a path that passes through dest (must not happen).
+AASM_DEV int64_t sel_emit_elem(const WS &w, int64_t vb, int64_t b, int32_t dest, const int32_t *pathB, int32_t t, OutElem *out) {
+    const int32_t v = pathB[2 * t + 1], nv = pathB[2 * (t + 1) + 1];
+    if (v == dest) return -1;
+    const int32_t y1 = w.v_i[vb + v], y2 = w.v_j[vb + v];
+    OutElem o = out_from_rec(w, b + y2);
+    o.is_alt = y2;                                                   // resolved by copy_resolved()
+    if (y1 != y2) { const int64_t sl = w.v_slot[vb + v]; o.qs = w.ov_stq[sl]; o.rs = w.ov_str[sl]; }
+    if (nv != dest && w.v_i[vb + nv] != w.v_j[vb + nv]) { const int64_t sl = w.v_slot[vb + nv]; o.qe = w.ov_peq[sl]; o.re = w.ov_per[sl]; }
+    out[t] = o;
+    return (o.qe - o.qs) + (o.re > o.rs ? o.re - o.rs : o.rs - o.re);
+}
 AASM_DEV int32_t sel_upgrade_emit(SelCtx &s, int32_t la, int64_t &cov) {
     const WS &w = *s.w;
     OutElem *out = s.cur;
@@ -3404,10 +3419,6 @@ AASM_DEV int32_t sel_upgrade_emit(SelCtx &s, int32_t la, int64_t &cov) {
     SPROF(s, 5);                                                     // upgrade: control + appends (ISPR parts stamped inside)
     if (s.err) return 0;
     s.n_path_e += la + lb;
-    // :1503-1557 as a map over path edges: edge t = (u, v) emits record cur(v) (nothing for
-    // v == dest, which is the last edge); a pair vertex v = (x, y) clips the start of its own
-    // element to edited_loc_str[x][y] and the END of the previous element to
-    // edited_loc_pre_end[x][y], i.e. element t takes its end clip from edge t + 1.
     // (From here on the bytes of s.cls belong to the elements.)
     if (lb < 2 || s.pathB[2 * (lb - 1) + 1] != s.dest) { s.err = true; return 0; }
     const int32_t n = lb - 1;
@@ -3415,15 +3426,8 @@ AASM_DEV int32_t sel_upgrade_emit(SelCtx &s, int32_t la, int64_t &cov) {
     int64_t part = 0;
     bool bad = false;
     for (int32_t t = s.lane; t < n; t += AASM_WAVE) {
-        const int32_t v = s.pathB[2 * t + 1], nv = s.pathB[2 * (t + 1) + 1];
-        if (v == s.dest) { bad = true; continue; }
-        const int32_t y1 = w.v_i[s.vb + v], y2 = w.v_j[s.vb + v];
-        OutElem o = out_from_rec(w, s.b + y2);
-        o.is_alt = y2;                                               // resolved by copy_resolved()
-        if (y1 != y2) { const int64_t sl = w.v_slot[s.vb + v]; o.qs = w.ov_stq[sl]; o.rs = w.ov_str[sl]; }
-        if (nv != s.dest && w.v_i[s.vb + nv] != w.v_j[s.vb + nv]) { const int64_t sl = w.v_slot[s.vb + nv]; o.qe = w.ov_peq[sl]; o.re = w.ov_per[sl]; }
-        out[t] = o;
-        part += (o.qe - o.qs) + (o.re > o.rs ? o.re - o.rs : o.rs - o.re);   // get_total_coverage, :1571-1579
+        const int64_t cv = sel_emit_elem(w, s.vb, s.b, s.dest, s.pathB, t, out);
+        if (cv < 0) bad = true; else part += cv;
     }
     if (wave_ballot(bad)) { s.err = true; return 0; }
     cov = wave_sum(part);

@@ -23,7 +23,7 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_CHILDREN, KN_CHILD_SIDE, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL
 };
 
@@ -53,6 +53,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_REV_SWEEP_G: kb_rev_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_FWD_SWEEP_G: kb_fwd_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_CHILDREN: kb_children(k, w); break;
+        case KN_CHILD_SIDE: kb_children(k, w); kb_sidetrack(k, w); break;   // both a thread per vertex, nothing of one feeds the other: one launch
         case KN_HEAP_CAP: kb_heap_cap(k, w); break;
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_SIDETRACK_W: kb_sidetrack_w(k, w); break;
@@ -268,9 +269,10 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
         CHECK_ALLOC();
-        be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
-        if (ET > 6 * VT) be.launch(KN_SIDETRACK_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
-        else be.launch(KN_SIDETRACK, cdiv(VT, 256), 256, w);
+        if (ET > 6 * VT) {
+            be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
+            be.launch(KN_SIDETRACK_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
+        } else be.launch(KN_CHILD_SIDE, cdiv(VT, 256), 256, w);
         be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32(w.hcap_cnt, C, w.hoff);
