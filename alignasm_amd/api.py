@@ -48,7 +48,7 @@ LIB = _load()
 EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
-    "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_solve_batch_range", "aasm_writer_open", "aasm_writer_append", "aasm_writer_close", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_debug_sort_replay", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
+    "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_solve_batch_range", "aasm_writer_open", "aasm_writer_append", "aasm_writer_close", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_sssp_dial", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_debug_sort_replay", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
     "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
@@ -78,6 +78,18 @@ def sssp_dijkstra(g_voff, rowptr, col, w5, src, device=0):
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     _check(LIB.aasm_sssp_dijkstra(C.c_int64(len(g_voff) - 1), P(g_voff), P(rowptr), P(col), P(w5), P(src), P(d), P(prev), int(device)))
     return d, prev
+
+
+def sssp_dial(g_voff, rowptr, col, cost, src, lim=2, device=0):
+    """k_weighted_bfs() of the reference (Dial's bucketed BFS, k_weighted_bfs.hpp:16-37) on the GPU over a batch of digraphs.
+    Returns (dist: [V] int64, -1 = unreachable; pre: [V] int64 local ids, -1 = none)."""
+    g_voff = np.ascontiguousarray(g_voff, np.int64); rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int32); cost = np.ascontiguousarray(cost, np.int32); src = np.ascontiguousarray(src, np.int32)
+    VT = int(g_voff[-1])
+    dist, pre = np.zeros(VT, np.int64), np.zeros(VT, np.int64)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(LIB.aasm_sssp_dial(C.c_int64(len(g_voff) - 1), P(g_voff), P(rowptr), P(col), P(cost), P(src), int(lim), P(dist), P(pre), int(device)))
+    return dist, pre
 
 
 def debug_counter(name):

@@ -202,6 +202,122 @@ __global__ void __launch_bounds__(64) aasm_sssp_dijkstra_kernel(int64_t n_graphs
     if (over && lane == 0) pg[s] = -2;                               // reported by the host entry
 }
 
+// ---- Dial's bucketed BFS (k_weighted_bfs.hpp:16-37), one wave per graph -------------------------------------------------
+// The reference keeps lim + 1 circular buckets, each a LIFO stack, and walks d = 0, 1, ...: pop the top of bucket d mod (lim + 1),
+// skip it when its distance is stale, relax its out-edges in list order; a successful relaxation (dist[nxt] == -1 or > d + cost)
+// sets dist / pre and pushes nxt onto bucket (d + cost) mod (lim + 1).  dist is order-independent, pre is not: it names the FIRST
+// vertex, in the reference's pop order, that reached the final distance - so the pops stay sequential and the relaxations of ONE
+// popped row run on the lanes:
+//  * buckets staged in LDS: every stack's top DIAL_WIN entries live in an LDS ring (ring slot = stack position mod DIAL_WIN);
+//    a full ring spills its lower half to the stack's slice of global memory in one coalesced store, an empty one refills from it;
+//  * a row is relaxed 64 edges at a time; the lanes that succeed are compacted PER BUCKET by ballot + prefix count, so a chunk's
+//    pushes land on every stack in list order (what the LIFO pops then reverse, as in the reference);
+//  * a chunk that names a head twice (parallel edges) is relaxed edge by edge - the second edge must see the first one's result.
+// The solver drives it with lim = 2 on the anomaly weights and keeps one scalar (paf_data.cpp:704-715), which the pipeline folds
+// into its forward sweep; this entry is the algorithm itself, for any digraph (cycles allowed) and weights 0 .. lim <= 7.
+#define DIAL_WIN 256
+#define DIAL_MAXB 8
+struct DialLds { int32_t ring[DIAL_MAXB][DIAL_WIN]; };
+__global__ void __launch_bounds__(64) aasm_sssp_dial_kernel(int64_t n_graphs, const int64_t *voff, const int64_t *rowptr, const int32_t *col, const int32_t *cost,
+                                                            const int32_t *src, int32_t nb, int64_t *dist, int64_t *pre, int32_t *spill, const int64_t *soff) {
+    __shared__ DialLds L;
+    const int64_t g = blockIdx.x;
+    if (g >= n_graphs) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t vb = voff[g], V = voff[g + 1] - vb;
+    int64_t *dg = dist + vb, *pg = pre + vb;
+    const int64_t cap = (soff[g + 1] - soff[g]) / nb;                // per bucket
+    int32_t *sp = spill + soff[g];
+    for (int64_t v = lane; v < V; v += 64) { dg[v] = -1; pg[v] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    int32_t base[DIAL_MAXB], cnt[DIAL_MAXB];                        // stack b = global [0, base) + ring [base, base + cnt)
+#pragma unroll
+    for (int b = 0; b < DIAL_MAXB; b++) { base[b] = 0; cnt[b] = 0; }
+    bool over = false;
+    // room for m more entries on stack b (m <= 64): spill the lower half of a ring that would overflow
+    auto make_room = [&](int b, int32_t m) {
+#pragma unroll
+        for (int bb = 0; bb < DIAL_MAXB; bb++) if (bb == b && cnt[bb] + m > DIAL_WIN) {
+            const int32_t n = DIAL_WIN / 2;
+            if ((int64_t)base[bb] + n > cap) { over = true; return; }
+            for (int32_t t = lane; t < n; t += 64) sp[(int64_t)bb * cap + base[bb] + t] = L.ring[bb][(base[bb] + t) & (DIAL_WIN - 1)];
+            base[bb] += n; cnt[bb] -= n;
+        }
+    };
+    auto push_lanes = [&](int b, bool mine, int32_t v) {             // the lanes with `mine` push v onto stack b, in lane order
+        const uint64_t m = __ballot(mine);
+        if (!m) return;
+        make_room(b, __popcll(m));
+        if (over) return;
+#pragma unroll
+        for (int bb = 0; bb < DIAL_MAXB; bb++) if (bb == b) {
+            if (mine) L.ring[bb][(base[bb] + cnt[bb] + __popcll(m & ((1ull << lane) - 1ull))) & (DIAL_WIN - 1)] = v;
+            cnt[bb] += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    };
+    const int32_t s0 = src[g];
+    if (lane == 0) dg[s0] = 0;
+    push_lanes(0, lane == 0, s0);
+    int64_t maxd = 0;
+    for (int64_t d = 0; d <= maxd && !over; d++) {
+        const int b = (int)(d % nb);
+        while (!over) {
+            int32_t c_b = 0, b_b = 0;
+#pragma unroll
+            for (int bb = 0; bb < DIAL_MAXB; bb++) if (bb == b) { c_b = cnt[bb]; b_b = base[bb]; }
+            if (c_b == 0) {
+                if (b_b == 0) break;                                 // the bucket is empty
+                const int32_t n = b_b < DIAL_WIN / 2 ? b_b : DIAL_WIN / 2;   // refill the ring from the stack's global part
+                for (int32_t t = lane; t < n; t += 64) L.ring[b][(b_b - n + t) & (DIAL_WIN - 1)] = sp[(int64_t)b * cap + b_b - n + t];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                for (int bb = 0; bb < DIAL_MAXB; bb++) if (bb == b) { base[bb] -= n; cnt[bb] += n; }
+                continue;
+            }
+            const int32_t cur = __builtin_amdgcn_readfirstlane(L.ring[b][(b_b + c_b - 1) & (DIAL_WIN - 1)]);   // q.back(); q.pop_back()
+#pragma unroll
+            for (int bb = 0; bb < DIAL_MAXB; bb++) if (bb == b) cnt[bb]--;
+            const int64_t dc = dg[cur];
+            if (__builtin_amdgcn_readfirstlane((int32_t)(dc != d))) continue;   // stale (:24)
+            const int64_t r0 = rowptr[vb + cur], r1 = rowptr[vb + cur + 1];
+            for (int64_t e0 = r0; e0 < r1 && !over; e0 += 64) {
+                const int64_t e = e0 + lane;
+                const bool act = e < r1;
+                const int32_t nxt = act ? col[e] : -1 - lane;
+                const int32_t cs = act ? cost[e] : 0;
+                // a head named twice in this chunk?  (lane i looks at the lanes below it)
+                bool dup = false;
+                const int32_t nlan = (int32_t)((r1 - e0 < 64) ? (r1 - e0) : 64);
+                for (int32_t j = 0; j + 1 < nlan; j++) dup |= (lane > j) && (__builtin_amdgcn_readlane(nxt, j) == nxt);
+                if (__ballot(dup)) {                                 // edge by edge, as the reference (:25-32)
+                    for (int32_t j = 0; j < nlan && !over; j++) {
+                        const int32_t nj = __builtin_amdgcn_readlane(nxt, j), cj = __builtin_amdgcn_readlane(cs, j);
+                        const int64_t nd = d + cj, dn = dg[nj];
+                        const bool ok = __builtin_amdgcn_readfirstlane((int32_t)(dn == -1 || dn > nd)) != 0;
+                        if (!ok) continue;
+                        if (lane == 0) { dg[nj] = nd; pg[nj] = cur; }
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        push_lanes((int)(nd % nb), lane == 0, nj);
+                        if (nd > maxd) maxd = nd;
+                    }
+                    continue;
+                }
+                const int64_t nd = d + cs;
+                bool ok = false;
+                if (act) { const int64_t dn = dg[nxt]; ok = dn == -1 || dn > nd; if (ok) { dg[nxt] = nd; pg[nxt] = cur; } }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const int bk = (int)(nd % nb);
+                for (int bb = 0; bb < nb && !over; bb++) push_lanes(bb, ok && bk == bb, nxt);
+                int64_t mx = ok ? nd : 0;
+                for (int o = 32; o >= 1; o >>= 1) { const int64_t y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+                if (mx > maxd) maxd = mx;
+            }
+        }
+    }
+    if (over && lane == 0) pg[s0] = -2;                              // reported by the host entry
+}
+
 // ---- exclusive scan: T in -> int64 out[n+1] -----------------------------------------
 // ONE launch per scan (the pipeline runs ~14 per batch, most over 7-15 M entries): tiles take their number from a
 // ticket (so every tile's predecessors are running or done), publish their sum, and find their prefix by looking back
@@ -863,6 +979,62 @@ int aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *r
     if (!ok) { set_last_error(hip_err("aasm_sssp_dijkstra", e)); return e == hipErrorOutOfMemory ? AASM_E_NOMEM : AASM_E_HIP; }
     if (overflowed >= 0) { set_last_error("graph " + std::to_string(overflowed) + ": dijkstra heap capacity exceeded at 64 x (E + 2) entries"); return AASM_E_OVERFLOW; }
     for (int64_t v = 0; v < VT; v++) { d5[5 * v] = hd[(size_t)v].qry; d5[5 * v + 1] = hd[(size_t)v].ref; d5[5 * v + 2] = hd[(size_t)v].anom; d5[5 * v + 3] = hd[(size_t)v].qnz; d5[5 * v + 4] = hd[(size_t)v].qtot; }
+    return AASM_OK;
+}
+
+// Dial's bucketed BFS (k_weighted_bfs.hpp:16-37) over a batch of graphs; host pointers in and out
+int aasm_sssp_dial(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int32_t *cost,
+                   const int32_t *src, int lim, int64_t *dist, int64_t *pre, int device) {
+    if (n_graphs <= 0 || !g_voff || !rowptr || !col || !cost || !src || !dist || !pre) return AASM_E_INVAL;
+    if (lim < 0 || lim + 1 > DIAL_MAXB) { set_last_error("aasm_sssp_dial: lim outside 0 .. 7"); return AASM_E_INVAL; }
+    int rc = ctx_init(device);
+    if (rc != AASM_OK) return rc;
+    hipSetDevice(device);
+    const int nb = lim + 1;
+    const int64_t VT = g_voff[n_graphs], ET = rowptr[VT];
+    if (VT <= 0 || g_voff[0] != 0 || rowptr[0] != 0) { set_last_error("inconsistent graph offsets"); return AASM_E_INVAL; }
+    std::vector<int64_t> soff((size_t)n_graphs + 1, 0);
+    for (int64_t g = 0; g < n_graphs; g++) {
+        const int64_t v0 = g_voff[g], v1 = g_voff[g + 1];
+        if (v1 <= v0 || src[g] < 0 || src[g] >= v1 - v0) { set_last_error("graph " + std::to_string(g) + ": empty, or source outside it"); return AASM_E_INVAL; }
+        for (int64_t e = rowptr[v0]; e < rowptr[v1]; e++) {
+            if (col[e] < 0 || col[e] >= v1 - v0) { set_last_error("graph " + std::to_string(g) + ": edge head outside the graph"); return AASM_E_INVAL; }
+            if (cost[e] < 0 || cost[e] > lim) { set_last_error("edge " + std::to_string(e) + ": cost outside 0 .. lim (the reference asserts it, k_weighted_bfs.hpp:27)"); return AASM_E_INVAL; }
+        }
+        // a vertex is pushed once per successful relaxation: its distance falls by at least one each time and by at most lim in all
+        // after the first (a later pop has d' >= d), so <= lim + 1 pushes per vertex - and never more than one per edge, plus the source
+        const int64_t E = rowptr[v1] - rowptr[v0], by_v = (v1 - v0) * (int64_t)nb;
+        const int64_t per = ((E + 1 < by_v ? E + 1 : by_v) + DIAL_WIN + 63) / 64 * 64;
+        soff[(size_t)g + 1] = soff[(size_t)g] + per * nb;
+    }
+    std::vector<void *> dev;
+    bool ok = true;
+    hipError_t e = hipSuccess;
+    auto up = [&](const void *p, size_t bytes) -> void * {
+        void *q = nullptr;
+        if (!ok) return nullptr;
+        if ((e = hipMalloc(&q, bytes ? bytes : 8)) != hipSuccess) { ok = false; return nullptr; }
+        dev.push_back(q);
+        if (p && bytes && (e = hipMemcpy(q, p, bytes, hipMemcpyHostToDevice)) != hipSuccess) ok = false;
+        return q;
+    };
+    const int64_t *d_voff = (const int64_t *)up(g_voff, (size_t)(n_graphs + 1) * 8), *d_rowptr = (const int64_t *)up(rowptr, (size_t)(VT + 1) * 8);
+    const int32_t *d_col = (const int32_t *)up(col, (size_t)ET * 4), *d_cost = (const int32_t *)up(cost, (size_t)ET * 4), *d_src = (const int32_t *)up(src, (size_t)n_graphs * 4);
+    const int64_t *d_soff = (const int64_t *)up(soff.data(), (size_t)(n_graphs + 1) * 8);
+    int64_t *d_dist = (int64_t *)up(nullptr, (size_t)VT * 8), *d_pre = (int64_t *)up(nullptr, (size_t)VT * 8);
+    int32_t *d_spill = (int32_t *)up(nullptr, (size_t)soff[(size_t)n_graphs] * 4);
+    if (ok) {
+        hipLaunchKernelGGL(aasm_sssp_dial_kernel, dim3((unsigned)n_graphs), dim3(64), 0, g_ctx[device].stream, n_graphs, d_voff, d_rowptr, d_col, d_cost, d_src, (int32_t)nb, d_dist, d_pre, d_spill, d_soff);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_ctx[device].stream);
+        if (e == hipSuccess) e = hipMemcpy(dist, d_dist, (size_t)VT * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(pre, d_pre, (size_t)VT * 8, hipMemcpyDeviceToHost);
+        ok = e == hipSuccess;
+    }
+    for (void *q : dev) hipFree(q);
+    if (!ok) { set_last_error(hip_err("aasm_sssp_dial", e)); return e == hipErrorOutOfMemory ? AASM_E_NOMEM : AASM_E_HIP; }
+    for (int64_t g = 0; g < n_graphs; g++)
+        if (pre[g_voff[g] + src[g]] == -2) { set_last_error("graph " + std::to_string(g) + ": bucket capacity exceeded (must not happen)"); return AASM_E_INTERNAL; }
     return AASM_OK;
 }
 

@@ -209,6 +209,14 @@ int  aasm_partition_costs(const double *cost, int64_t n_contigs, int n_shards, i
 int  aasm_sssp_dijkstra(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int64_t *w5,
                         const int32_t *src, int64_t *d5, int32_t *prev, int device);
 
+/* Dial's bucketed BFS, k_weighted_bfs() (src/k_weighted_bfs.hpp:16-37; the solver runs it with lim = 2 on the anomaly weights,
+ * src/paf_data.cpp:704-713), over a batch of digraphs that may contain cycles and parallel edges: same graph layout as
+ * aasm_sssp_dijkstra, cost one int32 per edge in 0 .. lim (lim <= 7), src the local source per graph.  dist (-1 = unreachable)
+ * and pre (-1 = none; LOCAL vertex ids) are exactly the vectors the reference fills - pre depends on the LIFO order inside a
+ * bucket, which the kernel keeps (buckets staged in LDS, pushes compacted per bucket by ballot + prefix count). */
+int  aasm_sssp_dial(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowptr, const int32_t *col, const int32_t *cost,
+                    const int32_t *src, int lim, int64_t *dist, int64_t *pre, int device);
+
 /* Same, with the batch already resident in device memory (in->pointers are device
  * pointers; in->ctg_rec_off / rec_rng_off too).  `stream` is a hipStream_t (or NULL).
  * The device result stays resident in an opaque handle until fetched/freed.          */

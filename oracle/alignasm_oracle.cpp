@@ -1114,6 +1114,18 @@ int64_t oracle_generic_dijkstra(int64_t n, const int64_t *rowptr, const int64_t 
     return n;
 }
 
+// Dial's bucketed BFS restated (k_weighted_bfs above) on a caller-supplied digraph: the checker of the product's aasm_sssp_dial;
+// pinned to the real header by tests/test_dial.py (ref_dial_bfs in oracle/ref_harness.cpp).
+int64_t oracle_dial_bfs(int64_t n, const int64_t *rowptr, const int64_t *col, const int64_t *cost, int64_t src, int64_t lim, int64_t *dist_out, int64_t *pre_out) {
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> gr((size_t)n);
+    for (int64_t u = 0; u < n; u++)
+        for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) gr[(size_t)u].push_back({col[e], cost[e]});
+    std::vector<int64_t> dist, pre;
+    k_weighted_bfs(gr, src, lim, dist, pre);
+    for (int64_t v = 0; v < n; v++) { dist_out[v] = dist[(size_t)v]; pre_out[v] = pre[(size_t)v]; }
+    return n;
+}
+
 // K1 / K2 predicates and the PafOutputData constructor exposed for truth tables against the
 // real header (oracle/ref_harness.cpp: ref_read_lt, ref_qry_contains, ref_qry_partial_overlap,
 // ref_output_from_read).

@@ -139,6 +139,18 @@ int64_t ref_generic_kwalks(int64_t n, const int64_t *rowptr, const int64_t *col,
     return (int64_t)dist.size();
 }
 
+// k_weighted_bfs() itself (k_weighted_bfs.hpp:16-37) on a caller-supplied digraph (cycles and parallel edges allowed):
+// dist and pre exactly as the reference fills them.  cost one int64 per edge, 0 .. lim.
+int64_t ref_dial_bfs(int64_t n, const int64_t *rowptr, const int64_t *col, const int64_t *cost, int64_t src, int64_t lim, int64_t *dist_out, int64_t *pre_out) {
+    Graph<int64_t> gr(n);
+    for (int64_t u = 0; u < n; u++)
+        for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) add_edge<int64_t>(gr, u, col[e], cost[e]);
+    std::vector<int64_t> dist, pre;
+    k_weighted_bfs(gr, src, lim, dist, pre);
+    for (int64_t v = 0; v < n; v++) { dist_out[v] = dist[v]; pre_out[v] = pre[v]; }
+    return n;
+}
+
 int64_t ref_generic_path(int64_t source, int64_t sink, int64_t k, int64_t *uv, int64_t cap) {
     if (!g_solver) return -1;
     auto p = g_solver->kth_shortest_walk_recover(source, sink, k, false);
