@@ -384,12 +384,38 @@ def cpu_baseline(paf, nc, K, sample):
     threads, rate, dt = max(full, key=lambda x: x[1])
     best = max([rate] + [r for _, r in ladder])
     stops = next((t for t, r in ladder if r >= 0.9 * best), cores)
-    return {"value": round(rate, 2), "unit": "contigs/s", "cores": threads, "kind": "port",
+    ref = reference_prefix(paf, nc, usable)
+    return {"reference_k1_k8": ref, "value": round(rate, 2), "unit": "contigs/s", "cores": threads, "kind": "port",
             "sample": f"first {n} contigs of the same workload, K={K}, one contig per task over {threads} threads, {dt:.2f} s wall "
                       f"(the best of {[t for t, _, _ in full]} threads on this sample; the host shows {cores} hardware threads, the process may use {usable} CPUs)",
             "full_sample": [{"threads": t, "contigs_per_sec": round(r, 1)} for t, r, _ in full],
             "value_1t": round(r1, 2), "sample_1t": f"first {min(40, nc)} contigs on 1 thread, {dt1:.2f} s",
             "scaling": [{"threads": t, "contigs_per_sec": round(r, 1)} for t, r in ladder], "stops_scaling_at": stops}
+
+
+def reference_prefix(paf, nc, usable):
+    """The REAL reference's own K1 ... K8 (oracle/_ref/libaasm_ref_prefix.so = paf_data.cpp:223-738 compiled in the build container; it
+    travels with the snapshot) beside the port stopped at the same line, same contigs, same threads, on THIS box's cores: how the
+    `port` figure above reads in reference time.  The reference's MAX_PATH_COUNT is fixed at 10 000, so the port runs that K here too.
+    None when the library is not there."""
+    import ctypes as C
+    import aasm_testlib as T
+    from alignasm_amd._abi import HostBatch
+    R = T.ref_prefix(mono=False)
+    if R is None:
+        return None
+    O = T.oracle()
+    O.oracle_time_prefix.restype = C.c_double
+    n = min(96, nc)
+    hb = HostBatch.from_view_range(paf.view(), 0, n)
+    out = {"sample": f"first {n} contigs of the workload, K1-K8 only, K = 10000 (the reference's constant), one contig per task", "rows": []}
+    for th in sorted({1, min(8, usable), usable}):
+        m = n if th > 1 else min(n, 24)
+        tr = R.refp_time_batch(C.byref(hb.view), C.c_int64(0), C.c_int64(m), th, 0)
+        tp = O.oracle_time_prefix(C.byref(hb.view), C.c_int64(0), C.c_int64(m), th, 0, C.c_int64(10000))
+        out["rows"].append({"threads": th, "contigs": m, "reference_ms_per_contig": round(1e3 * tr / m, 3), "port_ms_per_contig": round(1e3 * tp / m, 3),
+                            "reference_over_port": round(tr / tp, 2)})
+    return out
 
 
 def usable_cpus():
