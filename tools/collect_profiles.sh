@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards).
-#   gpurun -- 'bash tools/collect_profiles.sh r03'
+#   gpurun -- 'bash tools/collect_profiles.sh r04'
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -34,5 +34,9 @@ AASM_LIB_OVERRIDE=$R/alignasm_amd/libalignasm_amd_kprof.so python3 $R/tools/sort
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --heavy 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_heavy_tail.json
 python3 $R/tools/giant_probe.py > $O/${TAG}_giant_contigs.jsonl 2>&1
 python3 $R/tools/e2e_cli.py --contigs 5000 --k 4 > $O/${TAG}_e2e_cli.log 2>&1
+AASM_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $O/${TAG}_c4_selflaunch_2ranks_1gpu_gloo.json 2> $O/c4.err
+python3 $R/tools/kprof.py 5000 1000 4 0 21 > $O/${TAG}_k7_k9_sections_c3.txt 2>&1
+python3 $R/tools/kprof.py 5000 1000 4 0 21 3 > $O/${TAG}_k7_k9_sections_c3_dup3.txt 2>&1
+python3 $R/tools/kprof_enum.py 5000 1000 10000 0 21 > $O/${TAG}_k8_sections.txt 2>&1
 rm -rf $O/kt $O/kt5 $O/ktk $O/ktd $O/pmc5_fetch $O/pmc5_write $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
