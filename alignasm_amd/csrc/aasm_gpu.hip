@@ -410,6 +410,29 @@ __global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t
     }
 }
 
+// ---- fills: the memsets a solve needs between two launches (fresh arrays, counters, 0xFF / 0x7F patterns) as ONE launch ----
+#define FILL_MAX 8
+#define FILL_BLOCK_BYTES 65536
+struct FillSegs { void *p[FILL_MAX]; uint64_t n[FILL_MAX]; uint32_t v[FILL_MAX]; uint32_t blk0[FILL_MAX + 1]; int cnt; };
+__global__ void __launch_bounds__(256) aasm_multi_fill(FillSegs s) {
+    const uint32_t b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < s.cnt && b >= s.blk0[i + 1]) i++;
+    const uint64_t off = (uint64_t)(b - s.blk0[i]) * FILL_BLOCK_BYTES;
+    const uint64_t end = s.n[i] < off + FILL_BLOCK_BYTES ? s.n[i] : off + FILL_BLOCK_BYTES;
+    char *p = (char *)s.p[i];
+    const uint32_t v = s.v[i];
+    if ((((uintptr_t)p) & 15) == 0) {
+        uint4 q; q.x = q.y = q.z = q.w = v;
+        uint64_t o = off + (uint64_t)threadIdx.x * 16;
+        for (; o + 16 <= end; o += 256 * 16) *(uint4 *)(p + o) = q;
+        const uint64_t tail = end & ~(uint64_t)15;                  // (off is a multiple of 16: the last partial quad of the segment)
+        if (tail >= off && tail + threadIdx.x < end) p[tail + threadIdx.x] = (char)v;
+    } else {
+        for (uint64_t o = off + threadIdx.x; o < end; o += 256) p[o] = (char)v;
+    }
+}
+
 // ---- scalar read-back: up to eight device words -> the host-mapped pinned words, ONE launch (it was a copyBuffer per word) ----
 struct ScalarSrc { const int64_t *p[8]; };
 __global__ void aasm_read_scalars(ScalarSrc src, int n, int64_t *dst) {
@@ -548,27 +571,45 @@ struct GpuBackend {
         return true;
     }
     bool oom() const { return out_of_memory; }
-    // zero fills of arrays that sit back to back in the arena (the AZ(...) runs of the pipeline) are merged into one
-    // memset: a request only extends the pending span; whatever touches the stream next issues it first
-    char *z_lo = nullptr, *z_hi = nullptr;
+    // Fills are DEFERRED: a request joins a pending list (a zero fill of an array that sits right behind the last one in the arena
+    // only extends it), and whatever touches the stream next issues the list first - as ONE launch (aasm_multi_fill), or a plain
+    // memset when it is a single span.  A step of the pipeline had 19 fillBufferAligned dispatches.
+    FillSegs fs_;
+    int n_fs = 0;
     void flush_zero() {
-        if (!z_lo) return;
-        char *lo = z_lo; size_t n = (size_t)(z_hi - z_lo);
-        z_lo = z_hi = nullptr;
+        if (n_fs == 0) return;
+        const int n = n_fs;
+        n_fs = 0;
         if (fail) return;
-        hipError_t e = hipMemsetAsync(lo, 0, n, stream);
-        if (e != hipSuccess) hip_fail("hipMemsetAsync", e);
+        if (n == 1) {
+            hipError_t e = hipMemsetAsync(fs_.p[0], (int)(fs_.v[0] & 0xff), (size_t)fs_.n[0], stream);
+            if (e != hipSuccess) hip_fail("hipMemsetAsync", e);
+            return;
+        }
+        uint32_t blocks = 0;
+        for (int i = 0; i < n; i++) { fs_.blk0[i] = blocks; blocks += (uint32_t)((fs_.n[i] + FILL_BLOCK_BYTES - 1) / FILL_BLOCK_BYTES); }
+        fs_.blk0[n] = blocks; fs_.cnt = n;
+        hipLaunchKernelGGL(aasm_multi_fill, dim3(blocks), dim3(256), 0, stream, fs_);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) hip_fail("fill launch", e);
     }
-    void zero_alloc(void *p, size_t n) {                             // a WHOLE fresh allocation
-        if (!p || fail) return;
+    void add_fill(void *p, int v, size_t n, bool fresh) {
+        if (!p || n == 0 || fail) return;
         char *c = (char *)p;
-        if (z_lo && c >= z_hi && (size_t)(c - z_hi) <= 256) { z_hi = c + n; return; }   // (the gap is the allocator's alignment padding: nobody's data)
-        flush_zero();
-        z_lo = c; z_hi = c + n;
+        const uint32_t vv = (uint32_t)(v & 0xff) * 0x01010101u;
+        if (fresh && n_fs > 0 && fs_.v[n_fs - 1] == vv) {           // a WHOLE fresh allocation right behind the last span (the gap is the
+            char *hi = (char *)fs_.p[n_fs - 1] + fs_.n[n_fs - 1];   // allocator's alignment padding: nobody's data): one longer span
+            if (c >= hi && (size_t)(c - hi) <= 256) { fs_.n[n_fs - 1] = (uint64_t)(c + n - (char *)fs_.p[n_fs - 1]); return; }
+        }
+        bool overlap = false;                                        // spans of one launch are written concurrently: an overlapping request waits for the list
+        for (int i = 0; i < n_fs; i++) overlap |= c < (char *)fs_.p[i] + fs_.n[i] && (char *)fs_.p[i] < c + n;
+        if (overlap || n_fs == FILL_MAX || n >= ((size_t)4000 << 20) * 64) flush_zero();   // (a span's block count must fit 32 bits)
+        fs_.p[n_fs] = p; fs_.n[n_fs] = n; fs_.v[n_fs] = vv; n_fs++;
     }
-    void zero(void *p, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
-    void fill_byte(void *p, int v, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, v, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
-    void fill_ff(void *p, size_t n) { flush_zero(); if (p && !fail) { hipError_t e = hipMemsetAsync(p, 0xFF, n, stream); if (e != hipSuccess) hip_fail("hipMemsetAsync", e); } }
+    void zero_alloc(void *p, size_t n) { add_fill(p, 0, n, true); }  // a WHOLE fresh allocation
+    void zero(void *p, size_t n) { add_fill(p, 0, n, false); }
+    void fill_byte(void *p, int v, size_t n) { add_fill(p, v, n, false); }
+    void fill_ff(void *p, size_t n) { add_fill(p, 0xFF, n, false); }
     void launch(int kn, int64_t nblocks, int nthreads, const WS &w) {
         flush_zero();
         if (fail || nblocks <= 0) return;
