@@ -2050,26 +2050,42 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
     if (depth < 0) {                                                                // past the cached prefix: chase and extend the cache
         depth = sp.len;
         int32_t a = sp.tail;
+        const int32_t d0 = depth;
+        int32_t my_a = -1;                                                          // lane j in [d0, depth): the ring node it will cache
         if (a >= 0) wave_lds_sync();                                                // ring writes of earlier inserts before the ring reads
         while (a >= 0) {
-            // the chased node goes straight into the registers of the lane that will cache it (lane `depth`):
-            // one lane loads, compares and keeps it; only the outcome and the right pointer become scalars
+            // The walk itself is wave-uniform: every lane reads the node at `a` (one address: an LDS broadcast), the outcome and the
+            // right pointer are the same in all of them.  The lane that will cache the node only notes its index; the nodes come
+            // into the spine registers after the walk, all lanes at once - the loop carries scalars, not the sixteen spine registers.
             if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
-            bool lt = false;
-            FOR_LANE_EQ(j, depth, lane) {
-                const NodeQ n = heap_read(hs, a);
+            const bool in_ring = a >= hs.alloc - HEAP_RING && a >= hs.ring_lo;
+            const NodeQ n = heap_read(hs, a);
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-                kp.acc[(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
+            if (lane == 0) kp.acc[in_ring ? 7 : 6] += 1;                            // diagnostic: chase steps served by the ring / by global memory
 #endif
-                const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
-                sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum;
-                lt = (nsum < ksum) | ((nsum == ksum) & key_tie_lt(n, key));
-            }
-            if (!wave_ballot(lt)) { a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; break; }   // the stop node (its copy in lane `depth` is overwritten by the new leaf)
-            a = LA_GET(sp.n, depth, .q2.y);                                         // ->right
+            const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
+#if defined(AASM_HOST_EMUL)
+            FOR_LANE_EQ(j, depth, lane) { sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum; }
+            (void)in_ring;
+#else
+            if (in_ring) { if (lane == depth) my_a = a; }
+            else if (lane == depth) { sp.n.r = n; sp.idx.r = a; sp.sum.r = nsum; }                      // (an old node, from global memory through the bounce slot - a few per cent: kept at once)
+#endif
+            const bool lt = uni((nsum < ksum) | ((nsum == ksum) & key_tie_lt(n, key)));
+            if (!lt) { a_rank = uni(n.q1.w) & 0xff; break; }                        // the stop node (the new leaf takes its place in lane `depth`)
+            a = uni(n.q2.y);                                                        // ->right
             depth++;
         }
         a_stop = a;
+#if defined(AASM_HOST_EMUL)
+        (void)d0; (void)my_a;
+#else
+        if (depth > d0 && my_a >= 0) {                                              // the chased nodes that sit in the ring: all lanes at once
+            const NodeQ n = nodeq_load(&hs.ring[my_a & (HEAP_RING - 1)]);
+            sp.n.r = n; sp.idx.r = my_a; sp.sum.r = nodeq_key(n).qry + nodeq_key(n).ref;
+        }
+        // (measured: with the old nodes deferred too - no spine write inside the walk at all - K7 4.03 -> 4.08 ms)
+#endif
     }
     if (hs.alloc + depth + 1 > hs.cap) { hs.ovf = true; return -1; }
     if (hs.alloc + depth + 1 - hs.flushed > HEAP_RING) heap_flush(hs, lane);        // the new nodes must not overwrite unflushed ring slots
