@@ -479,8 +479,8 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
                         if (j > 0) { dq -= cq; ds -= cs; da -= ch.q1.x; dn -= ch.q1.y; dt -= ch.q1.z; }   // same heap: add the difference (:246-247)
                         const uint64_t ssum = f.sum + ds, sq = oq + dq;
                         const int32_t sa = o0.z + da, sn = o0.w + dn, st = o1.x + dt;
-                        const uint64_t k2 = qe_key2(sa, sn, st);
-                        a.x = lo32(ssum); a.y = hi32(ssum); a.z = lo32(k2); a.w = hi32(k2);
+                        a.x = lo32(ssum); a.y = hi32(ssum); a.z = 0; a.w = 0;   // (key2 - a double division - is made at the pop, by the lane that pushes the successor: one division for
+                                                                                 //  the whole step instead of three in a row per fetched entry, which is what a one-pop-per-step contig pays)
                         b.x = lo32(sq); b.y = hi32(sq); b.z = sid[j]; b.w = sa; pn[j] = sn; pt[j] = st;
                     }
                     q.L->slot[sl][2 + 2 * j] = a; q.L->slot[sl][3 + 2 * j] = b;
@@ -507,9 +507,10 @@ template <int FMAX> AASM_DEV void kb_enum_lsm(const KCtx &k, const WS &w) {   //
         if (pi < P) {
             const I4 a = q.L->slot[pslot][2 + 2 * pj], b = q.L->slot[pslot][3 + 2 * pj], t1 = q.L->slot[pslot][1], t8 = q.L->slot[pslot][8];
             valid = b.z >= 0;
-            x.sum = mk64(a.x, a.y); x.key2 = mk64(a.z, a.w); x.nc = (uint64_t)(uint32_t)b.z << 32;
+            x.sum = mk64(a.x, a.y); x.nc = (uint64_t)(uint32_t)b.z << 32;
             x0.x = b.x; x0.y = b.y; x0.z = b.w; x0.w = pj == 0 ? t1.z : pj == 1 ? t8.x : t8.z;
             x1.x = pj == 0 ? t1.w : pj == 1 ? t8.y : t8.w; x1.y = pj == 0 ? pcur : t1.y;
+            x.key2 = qe_key2(x0.z, x0.w, x1.x);
         }
         // a successor smaller than a front entry behind its parent has to be popped before that entry: the step ends with its parent
         if (P > 1) {
