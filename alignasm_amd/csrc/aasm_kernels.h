@@ -2034,7 +2034,7 @@ AASM_DEV void heap_flush(HeapState &hs, int lane) {
 }
 
 // One persistent insert (leftist_heap.hpp:29-40) into heap `hu`; returns the new root.
-template <class KP>
+template <bool UNI_CHASE, class KP>
 AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist key, int32_t eu, int32_t ev, int lane, KP &kp) {
     const int64_t ksum = key.qry + key.ref;
     if (hu != sp.root) { sp.root = hu; sp.len = 0; sp.tail = hu; }                   // root switch: nothing cached yet
@@ -2047,7 +2047,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         const uint64_t stop = ~lt & lanemask_lt(sp.len);
         if (stop) { depth = ffs64(stop) - 1; a_stop = LA_GET(sp.idx, depth, ); a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; }
     }
-    if (depth < 0) {                                                                // past the cached prefix: chase and extend the cache
+    if (depth < 0 && UNI_CHASE) {                                                                // past the cached prefix: chase and extend the cache
         depth = sp.len;
         int32_t a = sp.tail;
         const int32_t d0 = depth;
@@ -2086,6 +2086,30 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         }
         // (measured: with the old nodes deferred too - no spine write inside the walk at all - K7 4.03 -> 4.08 ms)
 #endif
+    }
+    if (depth < 0 && !UNI_CHASE) {                                                  // the walk lane by lane (the several-waves kernel: dense heaps, where the uniform form measured 4 % slower)
+        depth = sp.len;
+        int32_t a = sp.tail;
+        if (a >= 0) wave_lds_sync();                                                // ring writes of earlier inserts before the ring reads
+        while (a >= 0) {
+            // the chased node goes straight into the registers of the lane that will cache it (lane `depth`):
+            // one lane loads, compares and keeps it; only the outcome and the right pointer become scalars
+            if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
+            bool lt = false;
+            FOR_LANE_EQ(j, depth, lane) {
+                const NodeQ n = heap_read(hs, a);
+#if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
+                kp.acc[(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
+#endif
+                const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
+                sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum;
+                lt = (nsum < ksum) | ((nsum == ksum) & key_tie_lt(n, key));
+            }
+            if (!wave_ballot(lt)) { a_rank = LA_GET(sp.n, depth, .q1.w) & 0xff; break; }   // the stop node (its copy in lane `depth` is overwritten by the new leaf)
+            a = LA_GET(sp.n, depth, .q2.y);                                         // ->right
+            depth++;
+        }
+        a_stop = a;
     }
     if (hs.alloc + depth + 1 > hs.cap) { hs.ovf = true; return -1; }
     if (hs.alloc + depth + 1 - hs.flushed > HEAP_RING) heap_flush(hs, lane);        // the new nodes must not overwrite unflushed ring slots
@@ -2229,7 +2253,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
                 wave_lds_sync();                                     // i.e. for the next vertex's prefetch issued a moment earlier
             }
             const Dist cc = S->key[t & (HEAP_KMAX - 1)];
-            hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
+            hu = heap_insert<true>(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
         }
         KPROF_STAMP(3);                                              // inserts
         pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
@@ -2423,7 +2447,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
             FOR_LANE(t, m, k.lane) key.at(t) = sk[(int64_t)so + base + t];
             for (int32_t t = 0; t < m && !hs.ovf; t++) {
                 const Dist cc = la_get_dist(key, t);
-                hu = heap_insert(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
+                hu = heap_insert<false>(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
             }
         }
         if (hs.ovf) { if (k.lane == 0) L->stop = 1; break; }
