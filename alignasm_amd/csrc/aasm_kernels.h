@@ -247,6 +247,28 @@ AASM_DEV void kb_sort(const KCtx &k, const WS &w) {
     if (N <= 0) return;
     SortLds *L = (SortLds *)k.lds;
     const int64_t *qs = w.in_qs + gb, *qe = w.in_qe + gb;
+    {   // A contig whose records already come in (qry_str, qry_end) order - a file written in query order - needs no network: the stable
+        // order is the input order.  One pass over neighbouring pairs decides (and finds equal keys for kb_sort_fix on the way).
+        int32_t *flag = (int32_t *)k.lds;                            // [0] out of order somewhere, [1] equal neighbours
+        if (k.tid < 2) flag[k.tid] = 0;
+        block_barrier();
+        int unsorted = 0, dup = 0;
+        for (int64_t r = k.tid; r + 1 < N; r += k.nthreads) {
+            const int64_t a0 = qs[r], a1 = qe[r], b0 = qs[r + 1], b1 = qe[r + 1];
+            unsorted |= (b0 < a0 || (b0 == a0 && b1 < a1)) ? 1 : 0;
+            dup |= (b0 == a0 && b1 == a1) ? 1 : 0;
+        }
+        if (unsorted) flag[0] = 1;
+        if (dup) flag[1] = 1;
+        block_barrier();
+        const bool in_order = flag[0] == 0, has_dup = flag[1] != 0;
+        block_barrier();                                             // (the LDS words are the network's from here on)
+        if (in_order) {
+            for (int64_t r = k.tid; r < N; r += k.nthreads) w.perm[b + r] = (int32_t)r;
+            if (k.tid == 0) w.dupflag[c] = 2 | ((has_dup && N > 16) ? 1 : 0);   // bit 1: the order is final (kb_sort_rank leaves the contig alone)
+            return;
+        }
+    }
     const int64_t nch = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     // scratch for the sorted chunks of a long contig: the sorted-record arrays K1's gather fills later
     int64_t *t_qs = w.s_qs + b, *t_qe = w.s_qe + b;
@@ -303,7 +325,7 @@ AASM_DEV void kb_sort_rank(const KCtx &k, const WS &w) {
     int64_t lo_c = 0, hi_c = w.C;                                    // contig of the record: last c with rec_off[c] - R0 <= g
     while (hi_c - lo_c > 1) { const int64_t m = (lo_c + hi_c) >> 1; if (w.rec_off[m] - w.R0 <= g) lo_c = m; else hi_c = m; }
     const int64_t c = lo_c, gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
-    if (N <= SORT_CHUNK) return;
+    if (N <= SORT_CHUNK || (w.dupflag[c] & 2)) return;
     const int64_t *t_qs = w.s_qs + b, *t_qe = w.s_qe + b;
     const int32_t *t_ix = w.s_orig + b;
     const int64_t i = g - b, nch = (N + SORT_CHUNK - 1) / SORT_CHUNK;
@@ -717,7 +739,7 @@ AASM_DEV bool sf_sort_lds(SfLds *L, int32_t n, int32_t depth0, int32_t *out, int
 // the range's own slice of perm) until a range fits LDS, which then finishes it.
 AASM_DEV void kb_sort_fix(const KCtx &k, const WS &w) {
     const int64_t c = k.bid;
-    if (c >= w.C || !w.dupflag[c]) return;
+    if (c >= w.C || !(w.dupflag[c] & 1)) return;
     const int64_t gb = w.rec_off[c], N = w.rec_off[c + 1] - gb, b = gb - w.R0;
     int32_t *perm = w.perm + b;
     SfLds *L = (SfLds *)k.lds;
