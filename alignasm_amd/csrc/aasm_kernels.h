@@ -38,7 +38,8 @@ struct WS {
     // ---- K0 (optional): match ranges derived on the device from the cs tags
     const char *cs_text;
     const int64_t *cs_off;
-    int64_t *rql_w, *rqr_w, *rrl_w;
+    int64_t *rng_rec;                    // K0's output: one 32-byte record {qry_l, qry_r, ref_l, -} per match range (a lane writes whole 32-byte sectors)
+    int64_t rng_stride;                  // words between consecutive ranges behind rql / rqr / rrl: 1 (the caller's three arrays) or 4 (K0's records)
     int32_t *cs_bad;                     // 0, or (smallest record, relative to R0, whose tag is malformed) - INT32_MAX
     // ---- K1: sorted records, indexed by (sorted position + rec_off[c] - R0)
     int32_t *perm, *dupflag, *np, *pstart;
@@ -160,11 +161,17 @@ AASM_DEV void cs_close_op(CsScan &s, const WS &w) {                  // the open
         if (s.plen < 1 || s.val <= 0 || s.n >= s.cnt) { s.bad = true; return; }   // (a length beyond int64 has set val = -1: from_chars' out_of_range)
         if (s.fwd) {
             const int64_t o = s.o0 + s.n;
-            w.rql_w[o] = s.q; w.rqr_w[o] = s.q + s.val - 1; w.rrl_w[o] = s.rr;
+            I4 lo, hi; const int64_t qr = s.q + s.val - 1;
+            lo.x = lo32((uint64_t)s.q); lo.y = hi32((uint64_t)s.q); lo.z = lo32((uint64_t)qr); lo.w = hi32((uint64_t)qr);
+            hi.x = lo32((uint64_t)s.rr); hi.y = hi32((uint64_t)s.rr); hi.z = 0; hi.w = 0;
+            I4 *rec = (I4 *)(w.rng_rec + 4 * o); rec[0] = lo; rec[1] = hi;
             s.q += s.val;
         } else {
             const int64_t o = s.o0 + s.cnt - 1 - s.n;
-            w.rql_w[o] = s.q - s.val; w.rqr_w[o] = s.q - 1; w.rrl_w[o] = s.rr + s.val - 1;
+            I4 lo, hi; const int64_t ql = s.q - s.val, qr = s.q - 1, rl = s.rr + s.val - 1;
+            lo.x = lo32((uint64_t)ql); lo.y = hi32((uint64_t)ql); lo.z = lo32((uint64_t)qr); lo.w = hi32((uint64_t)qr);
+            hi.x = lo32((uint64_t)rl); hi.y = hi32((uint64_t)rl); hi.z = 0; hi.w = 0;
+            I4 *rec = (I4 *)(w.rng_rec + 4 * o); rec[0] = lo; rec[1] = hi;
             s.q -= s.val;
         }
         s.rr += s.val;
@@ -207,8 +214,11 @@ AASM_DEV void kb_cs_ranges(const KCtx &k, const WS &w) {
                 const unsigned dg = (unsigned)(c - '0');
                 if (dg > 9u) s.bad = true;
                 else {                                               // std::from_chars<int64_t>: any number of digits, leading zeros included, value <= INT64_MAX
-                    const uint64_t nv = (uint64_t)s.val * 10u + dg;
-                    s.val = (s.val < 0 || s.val > INT64_MAX / 10 || nv > (uint64_t)INT64_MAX) ? -1 : (int64_t)nv;
+                    if ((uint64_t)s.val < 100000000ull) s.val = (int64_t)((uint32_t)s.val * 10u + dg);   // (up to nine digits: 32-bit arithmetic, no overflow to look for)
+                    else {
+                        const uint64_t nv = (uint64_t)s.val * 10u + dg;
+                        s.val = (s.val < 0 || s.val > INT64_MAX / 10 || nv > (uint64_t)INT64_MAX) ? -1 : (int64_t)nv;
+                    }
                     s.plen = 1;
                 }
             } else if (s.t && (unsigned)((c | 32) - 'a') < 26u) s.plen++;
@@ -889,8 +899,9 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
         uint8_t ok = 0;
         // qry_partial_overlap (paf_data.hpp:78-86) on sorted records: qs_i <= qs_j, qs_j <= qe_i
         if (w.s_qs[g] < w.s_qs[gj] && w.s_qe[g] < w.s_qe[gj]) {
-            const int64_t *il = w.rql + w.s_rb[g], *ir = w.rqr + w.s_rb[g], *irl = w.rrl + w.s_rb[g];
-            const int64_t *jl = w.rql + w.s_rb[gj], *jr = w.rqr + w.s_rb[gj], *jrl = w.rrl + w.s_rb[gj];
+            const int64_t st = w.rng_stride;                                 // ranges as three arrays (st = 1) or as K0's 32-byte records (st = 4)
+            const int64_t *il = w.rql + w.s_rb[g] * st, *ir = w.rqr + w.s_rb[g] * st, *irl = w.rrl + w.s_rb[g] * st;
+            const int64_t *jl = w.rql + w.s_rb[gj] * st, *jr = w.rqr + w.s_rb[gj] * st, *jrl = w.rrl + w.s_rb[gj] * st;
             const int64_t ni = w.s_rn[g], nj = w.s_rn[gj];
             const int64_t step_i = (w.s_fl[g] & 1) ? 1 : -1, step_j = (w.s_fl[gj] & 1) ? 1 : -1;
             bool determined = false;
@@ -898,23 +909,23 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
             if (ni > 0 && nj > 0) {
                 // fast-forward: while r_i + 1 < l_j0 the loop of :308-359 only records the
                 // (strictly shrinking) gap and advances p_i; jump to the first other range.
-                const int64_t lj0 = jl[0];
+                const int64_t lj0 = jl[(0) * st];
                 int64_t a = 0, z = ni;
-                while (a < z) { const int64_t m = (a + z) >> 1; if (ir[m] + 1 < lj0) a = m + 1; else z = m; steps++; }
-                if (a > 0) { min_gap = lj0 - (ir[a - 1] + 1); mg_i = a - 1; mg_j = 0; }
+                while (a < z) { const int64_t m = (a + z) >> 1; if (ir[(m) * st] + 1 < lj0) a = m + 1; else z = m; steps++; }
+                if (a > 0) { min_gap = lj0 - (ir[(a - 1) * st] + 1); mg_i = a - 1; mg_j = 0; }
                 p_i = a;
             }
             while (p_i < ni && p_j < nj) {
                 steps++;
-                const int64_t l_i = il[p_i], r_i = ir[p_i], l_j = jl[p_j], r_j = jr[p_j];
+                const int64_t l_i = il[(p_i) * st], r_i = ir[(p_i) * st], l_j = jl[(p_j) * st], r_j = jr[(p_j) * st];
                 if (l_i == l_j) {                                                 // :315-327
                     if (l_j == r_j) { p_j++; continue; }
-                    peq = l_i; per = irl[p_i]; stq = l_j + 1; str_ = jrl[p_j] + step_j;
+                    peq = l_i; per = irl[(p_i) * st]; stq = l_j + 1; str_ = jrl[(p_j) * st] + step_j;
                     determined = true; break;
                 }
                 if (l_i < l_j) {                                                  // :328-346
                     if (l_j <= r_i + 1) {
-                        peq = l_j - 1; per = irl[p_i] + ((l_j - 1) - l_i) * step_i; stq = l_j; str_ = jrl[p_j];
+                        peq = l_j - 1; per = irl[(p_i) * st] + ((l_j - 1) - l_i) * step_i; stq = l_j; str_ = jrl[(p_j) * st];
                         determined = true; break;
                     } else {
                         const int64_t gap = l_j - (r_i + 1);
@@ -923,7 +934,7 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
                     p_i++;
                 } else {                                                          // :347-358
                     if (l_i <= r_j - 1) {
-                        peq = l_i; per = irl[p_i]; stq = l_i + 1; str_ = jrl[p_j] + (l_i + 1 - l_j) * step_j;
+                        peq = l_i; per = irl[(p_i) * st]; stq = l_i + 1; str_ = jrl[(p_j) * st] + (l_i + 1 - l_j) * step_j;
                         determined = true; break;
                     }
                     p_j++;
@@ -931,8 +942,8 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
             }
             if (determined || min_gap != -1) {                                    // :360-372
                 if (!determined) {
-                    const int64_t l_i = il[mg_i], r_i = ir[mg_i];
-                    peq = r_i; per = irl[mg_i] + (r_i - l_i) * step_i; stq = jl[mg_j]; str_ = jrl[mg_j];
+                    const int64_t l_i = il[(mg_i) * st], r_i = ir[(mg_i) * st];
+                    peq = r_i; per = irl[(mg_i) * st] + (r_i - l_i) * step_i; stq = jl[(mg_j) * st]; str_ = jrl[(mg_j) * st];
                 }
                 ok = 1;
             } else {

@@ -104,7 +104,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     w.sort_depth_test = (opts.reserved[2] >> 8) & 0xff;               // test hook: depth limit of kb_sort_fix's introsort
     w.rec_off = in.ctg_rec_off; w.in_qs = in.qry_str; w.in_qe = in.qry_end; w.in_rs = in.ref_str; w.in_re = in.ref_end;
     w.in_qt = in.qry_total; w.in_chr = in.ref_chr; w.in_fwd = in.aln_fwd; w.in_mq = in.map_qul;
-    w.in_rng_off = in.rec_rng_off; w.rql = in.rng_qry_l; w.rqr = in.rng_qry_r; w.rrl = in.rng_ref_l;
+    w.in_rng_off = in.rec_rng_off; w.rql = in.rng_qry_l; w.rqr = in.rng_qry_r; w.rrl = in.rng_ref_l; w.rng_stride = 1;
     sz.C = C; sz.R = R;
     if (C <= 0 || R <= 0) return AASM_E_INVAL;
 
@@ -126,15 +126,15 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         const int64_t G0 = gg[0], G1 = gg[1];
         be.phase_begin(AASM_PH_CS);
         w.cs_text = in.cs_text; w.cs_off = in.rec_cs_off;
-        A(rql_w, int64_t, G1 - G0, "rql_w"); A(rqr_w, int64_t, G1 - G0, "rqr_w"); A(rrl_w, int64_t, G1 - G0, "rrl_w"); A(cs_bad, int32_t, 2, "cs_bad");
+        A(rng_rec, int64_t, 4 * (G1 - G0), "rng_rec"); A(cs_bad, int32_t, 2, "cs_bad");
         CHECK_ALLOC();
-        w.rql_w -= G0; w.rqr_w -= G0; w.rrl_w -= G0;                // indexed with the batch's own range offsets
+        w.rng_rec -= 4 * G0;                                         // indexed with the batch's own range offsets
         be.zero(w.cs_bad, 8);
         be.launch(KN_CS_RANGES, cdiv(R, 256), 256, w);
         be.phase_end(AASM_PH_CS);
         const int32_t badv = (int32_t)(uint32_t)(uint64_t)be.read_i64((const int64_t *)w.cs_bad);   // 0 = none, else record - INT32_MAX
         if (badv != 0) { sz.bad_record = R0 + ((int64_t)badv + INT32_MAX); return AASM_E_PARSE; }
-        w.rql = w.rql_w; w.rqr = w.rqr_w; w.rrl = w.rrl_w;
+        w.rql = w.rng_rec; w.rqr = w.rng_rec + 1; w.rrl = w.rng_rec + 2; w.rng_stride = 4;
     } else if (!in.rng_qry_l) return AASM_E_INVAL;
 
     // ---- K1 sort + parts

@@ -312,6 +312,14 @@ def emul_solve(hb: HostBatch, K=10000, nsl=False, sequential_select=False, heap_
         emul().emul_free_out(C.byref(out))
 
 
+def k0_ranges(fetch):
+    """K0's output (one 32-byte record {qry_l, qry_r, ref_l, -} per match range) as the three columns the caller's arrays hold:
+    a dict with the old per-array names, for `fetch` = emul_debug or DeviceResult.debug."""
+    rec = fetch("rng_rec", np.int64)
+    rec = rec[:len(rec) // 4 * 4].reshape(-1, 4)
+    return {"rql_w": rec[:, 0].copy(), "rqr_w": rec[:, 1].copy(), "rrl_w": rec[:, 2].copy()}
+
+
 def emul_debug(name, dtype):
     n = emul().emul_debug_fetch(name.encode(), None, C.c_int64(0))
     assert n >= 0, name

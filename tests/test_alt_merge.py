@@ -138,4 +138,4 @@ def test_alt_merge_with_device_side_ranges(T):
         T.emul().emul_free_out(C.byref(out))
     assert T.diff_outputs(want, got) == []
     n = int(hv.n_ranges)
-    assert np.array_equal(T.emul_debug("rql_w", np.int64)[:n], host.batch().arrays["rng_qry_l"])
+    assert np.array_equal(T.k0_ranges(T.emul_debug)["rql_w"][:n], host.batch().arrays["rng_qry_l"])

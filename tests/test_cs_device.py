@@ -80,7 +80,7 @@ def test_device_cs_ranges_equal_oracle_codec(T):
     n = int(host["rec_rng_off"][-1])
     assert np.array_equal(dev.batch().arrays["rec_rng_off"], host["rec_rng_off"])
     for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
-        assert np.array_equal(T.emul_debug(name, np.int64)[:n], host[key]), name
+        assert np.array_equal(T.k0_ranges(T.emul_debug)[name][:n], host[key]), name
 
 
 def test_device_cs_solve_equals_host_range_solve(T):
@@ -96,7 +96,7 @@ def test_device_cs_solve_equals_host_range_solve(T):
         T.emul().emul_free_out(C.byref(out))
     assert T.diff_outputs(want, got) == []
     n = int(hb.arrays["rec_rng_off"][-1])
-    assert np.array_equal(T.emul_debug("rql_w", np.int64)[:n], hb.arrays["rng_qry_l"])
+    assert np.array_equal(T.k0_ranges(T.emul_debug)["rql_w"][:n], hb.arrays["rng_qry_l"])
 
 
 BAD = [
@@ -159,7 +159,7 @@ def test_device_cs_fuzz_valid_and_mutated_tags(T):
     T.emul().emul_free_out(C.byref(out))
     n = int(host["rec_rng_off"][-1])
     for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
-        assert np.array_equal(T.emul_debug(name, np.int64)[:n], host[key]), name
+        assert np.array_equal(T.k0_ranges(T.emul_debug)[name][:n], host[key]), name
     n_bad = 0
     for trial in range(60):
         victim = int(rng.integers(0, len(tags)))

@@ -145,7 +145,7 @@ def test_k0_emulation_equals_the_recorded_reference_vectors(T, golden):
     assert T.emul().emul_solve_batch(C.byref(view), C.byref(Opts(1, 0, 0, 0, 1)), C.byref(out)) == 0
     T.emul().emul_free_out(C.byref(out))
     off = dev.batch().arrays["rec_rng_off"]
-    _check_ranges(rows, off, *(T.emul_debug(k, np.int64) for k in ("rql_w", "rqr_w", "rrl_w")))
+    _check_ranges(rows, off, *(T.k0_ranges(T.emul_debug)[k] for k in ("rql_w", "rqr_w", "rrl_w")))
     for text, at, msg in _rejected_files(golden, 10):
         with pytest.raises(api.AlignasmError) as e:
             api.Paf.parse(text)                                     # the host reader: same text as the reference
@@ -165,7 +165,7 @@ def test_k0_device_equals_the_recorded_reference_vectors(T, golden):
     db = api.DeviceBatch(dev)
     res = db.solve(max_paths=1, keep_debug=True)
     off = dev.batch().arrays["rec_rng_off"]
-    _check_ranges(rows, off, *(res.debug(k, np.int64) for k in ("rql_w", "rqr_w", "rrl_w")))
+    _check_ranges(rows, off, *(T.k0_ranges(res.debug)[k] for k in ("rql_w", "rqr_w", "rrl_w")))
     res.close(); db.close()
 
 

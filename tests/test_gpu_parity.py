@@ -152,7 +152,7 @@ def test_device_cs_ranges(T):
     res = db.solve(max_paths=4, keep_debug=True)
     n = int(host["rec_rng_off"][-1])
     for name, key in (("rql_w", "rng_qry_l"), ("rqr_w", "rng_qry_r"), ("rrl_w", "rng_ref_l")):
-        assert np.array_equal(res.debug(name, np.int64)[:n], host[key]), name
+        assert np.array_equal(T.k0_ranges(res.debug)[name][:n], host[key]), name
     res.close(); db.close()
 
 
