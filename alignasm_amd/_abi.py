@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 AASM_N_PHASES = 16
-PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "heap_prep", "topo", "misc", "cs", "final"]
+PHASE_NAMES = ["sort", "pairs", "edges", "revcsr", "sptree", "fwd", "heap", "enum", "select", "gather", "heap_prep", "topo", "misc", "cs", "final", "chain"]
 
 AASM_OK = 0
 AASM_E_INVAL, AASM_E_NODEVICE, AASM_E_HIP, AASM_E_NOMEM = -1, -2, -3, -4

@@ -49,7 +49,7 @@ EXPORTED = [
     "aasm_abi_version", "aasm_device_count", "aasm_init", "aasm_last_error", "aasm_solve_batch", "aasm_solve_batch_multi", "aasm_solve_device",
     "aasm_result_stats", "aasm_result_fetch", "aasm_result_free", "aasm_free_out", "aasm_upload_batch", "aasm_upload_free",
     "aasm_contig_costs", "aasm_partition_contigs", "aasm_partition_costs", "aasm_solve_batch_range", "aasm_writer_open", "aasm_writer_append", "aasm_writer_close", "aasm_reserve_workspace", "aasm_sssp_dijkstra", "aasm_sssp_dial", "aasm_debug_fetch", "aasm_debug_counter", "aasm_debug_predicates", "aasm_debug_sort_replay", "aasm_paf_read", "aasm_paf_read_opts", "aasm_paf_parse_mem", "aasm_paf_parse_mem_opts", "aasm_paf_merge_alt", "aasm_paf_merge_alt_mem", "aasm_paf_free", "aasm_paf_batch", "aasm_paf_n_contigs",
-    "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_paf_to_text", "aasm_paf_save",
+    "aasm_paf_write_outputs", "aasm_set_host_threads", "aasm_cs_match_ranges", "aasm_cs_edit", "aasm_synth_paf", "aasm_synth_paf_range", "aasm_paf_to_text", "aasm_paf_save",
 ]
 
 
@@ -105,11 +105,12 @@ def reserve_workspace(device=0, nbytes=0):
 
 
 def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False,
-              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False, test_dirty_scan=False):
+              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False, test_dirty_scan=False, chain="auto"):
     o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
     # bit 0: force the one-wave-per-contig selection kernel; bits 1 / 2: K7 with several waves per contig for every contig / for none
     # bit 3: K8 with the d-ary heap queue instead of the sorted-front / sorted-runs queue (cross-check of the two)
-    o.reserved[0] = (1 if sequential_select else 0) | {"auto": 0, "all": 2, "none": 4}[heap_waves] | (8 if enum_heap else 0) | (16 if enum_small else 0) | (32 if grid_order else 0) | ((1 << 8) if heap_input_order else (int(heap_block_waves) << 8))   # bits 8-15: 1 = K7's several-waves class in input order instead of largest first; 4 / 8 / 16 = that many waves per contig of it
+    # bits 6 / 7: the chain class (aasm_k67_chain: a contig's sweep, pre-pass and heaps beside each other) for every sparse contig / for none
+    o.reserved[0] = (1 if sequential_select else 0) | {"auto": 0, "all": 2, "none": 4}[heap_waves] | (8 if enum_heap else 0) | (16 if enum_small else 0) | (32 if grid_order else 0) | {"auto": 0, "all": 64, "none": 128, "half": 192}[chain] | ((1 << 8) if heap_input_order else (int(heap_block_waves) << 8))   # bits 8-15: 1 = K7's several-waves class in input order instead of largest first; 4 / 8 / 16 = that many waves per contig of it
     o.reserved[1] = int(test_max_contigs)              # test hook: longer contig ranges "do not fit" (range split)
     o.reserved[2] = (1 if test_inject_launch_failure else 0) | (2 if wrap_devices else 0) | (4 if test_dirty_scan else 0) | ((int(sort_depth_test) & 0xff) << 8)   # bit 1: shards wrap around the devices that exist
     return o
@@ -135,11 +136,17 @@ class Paf:
         return Paf(h)
 
     @staticmethod
-    def synth(n_contigs, recs_per_contig, seed, dense=False, heavy_tail=False, dup_every=0, shuffle=False, no_cs=False):
+    def synth(n_contigs, recs_per_contig, seed, dense=False, heavy_tail=False, dup_every=0, shuffle=False, no_cs=False,
+              first=0, count=None, records_only=False):
+        """The synthetic file (n_contigs, ...), or its contigs [first, first + count); records_only: no match ranges / cs
+        tags (enough for the contig cost model that cuts the file into shards)."""
         cfg = SynthCfg(n_contigs, recs_per_contig, seed, 1 if dense else 0, 1 if heavy_tail else 0, dup_every,
-                       (1 if shuffle else 0) | (2 if no_cs else 0))
+                       (1 if shuffle else 0) | (2 if no_cs else 0) | (4 if records_only else 0))
         h = C.c_void_p()
-        _check(LIB.aasm_synth_paf(C.byref(cfg), C.byref(h)))
+        if first == 0 and count is None:
+            _check(LIB.aasm_synth_paf(C.byref(cfg), C.byref(h)))
+        else:
+            _check(LIB.aasm_synth_paf_range(C.byref(cfg), C.c_int64(int(first)), C.c_int64(int(n_contigs - first if count is None else count)), C.byref(h)))
         return Paf(h)
 
     def merge_alt(self, text: bytes, alt_baseline=0.5):
@@ -197,10 +204,10 @@ def free_out(out: BatchOut):
 
 
 def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False,
-                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, heap_input_order=False, test_dirty_scan=False):
+                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, heap_input_order=False, test_dirty_scan=False, chain="auto"):
     """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
     view = batch.view if isinstance(batch, HostBatch) else batch.view()
-    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap, wrap_devices, heap_input_order=heap_input_order, test_dirty_scan=test_dirty_scan)
+    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap, wrap_devices, heap_input_order=heap_input_order, test_dirty_scan=test_dirty_scan, chain=chain)
     if n_devices > 1:
         out = BatchOut()
         _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(opts), int(n_devices), C.byref(out)))
@@ -225,9 +232,9 @@ class DeviceBatch:
         self.n_contigs = int(view.n_contigs)
         self.n_records = int(view.n_records)
 
-    def solve(self, max_paths=10000, non_skip_linkable=False, timing=False, keep_debug=False, stream=None, heap_waves="auto", enum_heap=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False):
+    def solve(self, max_paths=10000, non_skip_linkable=False, timing=False, keep_debug=False, stream=None, heap_waves="auto", enum_heap=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False, chain="auto"):
         res = C.c_void_p()
-        opts = make_opts(max_paths, non_skip_linkable, self.device, timing, keep_debug, heap_waves=heap_waves, enum_heap=enum_heap, enum_small=enum_small, sort_depth_test=sort_depth_test, heap_input_order=heap_input_order, heap_block_waves=heap_block_waves, grid_order=grid_order)
+        opts = make_opts(max_paths, non_skip_linkable, self.device, timing, keep_debug, heap_waves=heap_waves, enum_heap=enum_heap, enum_small=enum_small, sort_depth_test=sort_depth_test, heap_input_order=heap_input_order, heap_block_waves=heap_block_waves, grid_order=grid_order, chain=chain)
         _check(LIB.aasm_solve_device(C.byref(self.dev_view), C.byref(opts), C.c_void_p(stream or 0), C.byref(res)))
         return DeviceResult(res)
 

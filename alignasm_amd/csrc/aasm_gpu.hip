@@ -78,6 +78,7 @@ AASM_DEF_KERNEL(aasm_k7_sidetrack, KN_SIDETRACK, 256)
 AASM_DEF_KERNEL_LDS(aasm_k7_sidetrack_w, KN_SIDETRACK_W, 64, AASM_SIDE_LDS_BYTES, 8)
 AASM_DEF_KERNEL(aasm_k7_heap_hdr, KN_HEAP_HDR, 256)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
+AASM_DEF_KERNEL_LDS(aasm_k67_chain, KN_CHAIN, 64 * CHAIN_WAVES, AASM_CHAIN_LDS_BYTES, 4)   // sweep + pre-pass + heaps of one contig, a wave each
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw, KN_HEAP_MW, 256, AASM_MW_LDS_BYTES(4), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw8, KN_HEAP_MW8, 512, AASM_MW_LDS_BYTES(8), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw16, KN_HEAP_MW16, 1024, AASM_MW_LDS_BYTES(16), 4)
@@ -448,8 +449,8 @@ struct ArenaBlock { char *p; size_t cap, used; };
 struct DevCtx {
     int device = -1;
     bool ready = false;
-    hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;
+    hipEvent_t ev_fork, ev_join, ev_fork2, ev_join2;
     int64_t *d_scratch2 = nullptr;      // scan tile sums of the side stream
     size_t d_scratch2_cap = 0;
     std::vector<ArenaBlock> blocks;
@@ -462,7 +463,8 @@ struct DevCtx {
     std::atomic<int> input_arrived{0};  // an upload for this context has begun: a warm-up that has not allocated yet stands back
     std::mutex mu;
     hipEvent_t ev_b[AASM_N_PHASES], ev_e[AASM_N_PHASES], ev_t0, ev_t1;
-    int n_events_made = 0;              // ev_fork, ev_join, then timing_event(0 ..)
+    int n_events_made = 0;              // ev_fork, ev_join, then timing_event(0 ..); ev_fork2 / ev_join2 are counted by n_events2
+    int n_events2 = 0;
     hipEvent_t *timing_event(int i) { return i < AASM_N_PHASES ? &ev_b[i] : i < 2 * AASM_N_PHASES ? &ev_e[i - AASM_N_PHASES] : i == 2 * AASM_N_PHASES ? &ev_t0 : &ev_t1; }
     bool events = false;
     size_t peak_bytes = 0;
@@ -493,12 +495,21 @@ static int ctx_init(int device) {
         if (cx.n_events_made > 1) { hipEventDestroy(cx.ev_join); }
         for (int i = 2; i < cx.n_events_made; i++) hipEventDestroy(*cx.timing_event(i - 2));
         cx.n_events_made = 0;
+        if (cx.n_events2 > 0) { hipEventDestroy(cx.ev_fork2); }
+        if (cx.n_events2 > 1) { hipEventDestroy(cx.ev_join2); }
+        cx.n_events2 = 0;
+        if (cx.side2) { hipStreamDestroy(cx.side2); cx.side2 = nullptr; }
         if (cx.side) { hipStreamDestroy(cx.side); cx.side = nullptr; }
         if (cx.stream) { hipStreamDestroy(cx.stream); cx.stream = nullptr; }
         return AASM_E_NODEVICE;
     };
     if ((e = hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&cx.side, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&cx.side2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&cx.ev_fork2, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    cx.n_events2 = 1;
+    if ((e = hipEventCreateWithFlags(&cx.ev_join2, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    cx.n_events2 = 2;
     if ((e = hipEventCreateWithFlags(&cx.ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     cx.n_events_made = 1;
     if ((e = hipEventCreateWithFlags(&cx.ev_join, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
@@ -520,7 +531,7 @@ struct GpuBackend {
     static constexpr bool host_emulation = false;
     DevCtx &cx;
     hipStream_t stream, main_stream;
-    bool on_side = false, forked = false;
+    bool on_side = false, forked = false, forked2 = false;
     bool timing;
     bool fail = false, out_of_memory = false;
     bool phase_used[AASM_N_PHASES] = {false};
@@ -624,6 +635,7 @@ struct GpuBackend {
             L(KN_CHILDREN, aasm_k7_children) L(KN_CHILD_SIDE, aasm_k7_child_side)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
+            L(KN_CHAIN, aasm_k67_chain)
             L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_RECOVER, aasm_k9_sel_recover) L(KN_SEL_CLASSIFY, aasm_k9_sel_classify) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L
             default: break;
@@ -691,6 +703,10 @@ struct GpuBackend {
     void fork() { flush_zero(); if (fail) return; hipEventRecord(cx.ev_fork, main_stream); hipStreamWaitEvent(cx.side, cx.ev_fork, 0); forked = true; }
     void use_side(bool on) { flush_zero(); on_side = on; stream = on ? cx.side : main_stream; }
     void join() { flush_zero(); if (fail || !forked) return; hipEventRecord(cx.ev_join, cx.side); hipStreamWaitEvent(main_stream, cx.ev_join, 0); forked = false; }
+    // third stream (the chain class's workgroups): same protocol; it runs no scans, so it needs no scratch of its own
+    void fork2() { flush_zero(); if (fail) return; hipEventRecord(cx.ev_fork2, main_stream); hipStreamWaitEvent(cx.side2, cx.ev_fork2, 0); forked2 = true; }
+    void use_side2(bool on) { flush_zero(); stream = on ? cx.side2 : main_stream; }
+    void join2() { flush_zero(); if (fail || !forked2) return; hipEventRecord(cx.ev_join2, cx.side2); hipStreamWaitEvent(main_stream, cx.ev_join2, 0); forked2 = false; }
     void phase_begin(int ph) { flush_zero(); if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_b[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); phase_used[ph] = true; } }
     void phase_end(int ph) { flush_zero(); if (timing && !fail) { hipError_t e = hipEventRecord(cx.ev_e[ph], stream); if (e != hipSuccess) hip_fail("hipEventRecord", e); } }
 };
@@ -726,8 +742,10 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
     be->flush_zero();
     if (timing) hipEventRecord(cx.ev_t1, stream);
     be->join();
+    be->join2();
     hipError_t e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipStreamSynchronize(cx.side);
+    if (e == hipSuccess) e = hipStreamSynchronize(cx.side2);
     be->scan_stalled();
     if (rc == AASM_OK && be->failed()) rc = be->oom() ? AASM_E_NOMEM : AASM_E_HIP;
     if (rc == AASM_OK && e != hipSuccess) { set_last_error(hip_err("pipeline", e)); rc = AASM_E_HIP; }

@@ -122,11 +122,19 @@ struct WS {
     I4 *rvh;                             // K6: per-vertex in-list header, 3 words (see kb_rev_hdr)
     I4 *r_pk;                            // K6: one packed record per in-edge, in in-list order
     I4 *fvh;                             // K5: per-vertex out-list header, 2 words (see kb_rev_hdr)
+    // ---- the chain class (kb_chain): contigs whose K6 sweep, K7 pre-pass and K7 heaps run BESIDE each other in one workgroup
+    int32_t chain_mode;                  // 0: by batch shape, 1: every sparse one-wave contig, 2: none (tests, probes)
+    int32_t chain_all, chain_minN;       // mode 0: every contig of the batch (small batches) / contigs of at least this many records (the long tail)
+    int32_t *chain_flag, *chain_list;    // per contig: in the class; the contigs of the class, in any order
+    int32_t *pend;                       // per vertex: in-neighbours whose keys are not written yet (the prep wave counts them down)
+    int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
+// the chain class (kb_chain): contigs whose sweep, K7 pre-pass and heaps run in one workgroup; the one-stage kernels skip them
+AASM_DEV bool in_chain_class(const WS &w, int64_t c) { return w.chain_flag != nullptr && w.chain_flag[c] != 0; }
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
 // int32, e_wr is int32): coordinates in [0, 2^40), so that a path sum over < 2^20 edges of
 // 2 * coordinate stays far inside int64 and every per-edge reference weight fits int32 after the
@@ -1531,6 +1539,7 @@ AASM_UNROLL
     w.sp_d[gv] = (gv == vend - 1) ? dist_zero() : dist_max();
     w.sp_best[gv] = -1;
     w.an[gv] = (gv == vend - 2) ? 0 : -1;
+    if (w.pend) w.pend[gv] = (int32_t)(r1 - r0);                    // (kb_chain's prep wave: in-neighbours still without keys)
 }
 
 // Contigs per wave: the graphs are long chains (~1.4 vertices per Kahn level, in-degree ~2), so a wave that
@@ -1553,11 +1562,21 @@ template <int G> struct SweepGrp {
     AASM_MEM int32_t count(uint64_t m) const { return G >= 64 ? popc64(m) : __builtin_popcount(bits(m)); }
 };
 
-template <int G>
-AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
+// Progress words of one chain-class workgroup (kb_chain), in LDS.  sweep wave -> prep wave: `tail_pub` vertices of rev_order are
+// final (d, best and the order entry are in memory); prep wave -> heap wave: a vertex's header words in global memory turn from
+// -1 to their values; `sweep_done` / `prep_done` end the waits (1: finished, 2: gave up).
+struct ChainSync { int32_t tail_pub, sweep_done, prep_done, pad; };
+#if defined(AASM_HOST_EMUL)
+AASM_DEV void st_shared_i32(int32_t *p, int32_t v) { *p = v; }
+#else
+AASM_DEV void st_shared_i32(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+
+template <int G, bool PUB = false>
+AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w, ChainSync *S = nullptr) {
     const SweepGrp<G> sg(k.lane);
     const int64_t c = k.bid * SweepGrp<G>::N + sg.g;
-    const bool valid = c < w.C;
+    const bool valid = c < w.C && (PUB || !in_chain_class(w, c));   // (the chain class sweeps inside kb_chain)
     const int64_t V = valid ? (int64_t)w.ctgV[c] : 0;
     const int64_t vb = valid ? w.voff[c] : 0;
     RevQ *Q = (RevQ *)k.lds + sg.g;                                  // queue positions [head, lds_hi)
@@ -1578,6 +1597,10 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
     }
     lds_hi = tail < REVQ_N ? tail : REVQ_N;
     wave_lds_sync();
+    int32_t pub = 0;                                                 // (PUB: G == 64, tail is wave-uniform)
+    // (every lane stores the same word: with `if (lane == 0)` around the store inside the pop loop the compiler unswitched the whole
+    // loop on the lane id - lanes != 0 first, lane 0 after them - and the sweep, whose lanes work together, stopped after two pops)
+    if (PUB) { pub = uni(tail); store_drain(); st_shared_i32(&S->tail_pub, pub); }
     int32_t head = 0;
     while (wave_any(head < tail)) {
         const bool live = head < tail;
@@ -1632,8 +1655,15 @@ AASM_DEV void kb_rev_sweep(const KCtx &k, const WS &w) {
             tail += nnew;
         }
         wave_lds_sync();
+        // a vertex is final the moment it is appended (every out-edge relaxed): its d / best / order entry leave this wave before
+        // the count that tells the prep wave about them
+        if (PUB) {
+            const int32_t tu = uni(tail);                            // (scalar: the publish is a uniform branch, no exec masking around the fence)
+            if (tu != pub) { store_drain(); st_shared_i32(&S->tail_pub, tu); pub = tu; }
+        }
     }
     if (valid && tail != (int32_t)V && sg.gl == 0) set_status(w, c, -6);   // cycle: cannot happen (:144-148)
+    if (PUB) { store_drain(); st_shared_i32(&S->sweep_done, 1); }
 }
 
 // forward Kahn order (paf_data.cpp:742-746) + anomaly distance to dest.  The reference
@@ -1767,9 +1797,7 @@ AASM_DEV void kb_topo_fill(const KCtx &k, const WS &w) {            // wave per 
 // v -> u, so it is a source in u's in-list - which is in ascending (source, position) order already; parallel edges of
 // one source are neighbours there.  The list is written over the front of u's OWN in-list slots (cval is indexed
 // like r_pk): no counting pass, no scan, no atomics, nothing to sort.
-AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread per vertex
-    const int64_t gv = k.bid * k.nthreads + k.tid;
-    if (gv >= w.VT) return;
+AASM_DEV void children_vertex(const WS &w, int64_t gv) {
     const int64_t vb = w.voff[w.v_ctg[gv]];
     const int32_t u = (int32_t)(gv - vb);
     const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
@@ -1790,6 +1818,11 @@ AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread p
     }
     w.ccnt[gv] = n;
 }
+AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;       // (the chain class: its prep wave does this, kb_chain)
+    children_vertex(w, gv);
+}
 // K7 pre-pass 1, thread per vertex u (k_shortest_walks.hpp:204-210 without the insert): the sidetrack cost
 // c = w + d[v] - d[u] of every out-edge that goes into u's heap - not when d[v] is max() (:204-205), and not
 // the FIRST edge of the list that is u's tree edge (:207-210) - written COMPACTED to the front of u's row of
@@ -1797,9 +1830,7 @@ AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread p
 // one coalesced load (lane t = key t) instead of flag, cost and head through three dependent loads.
 // A sidetrack cost has score sum >= 0 (d[u] is minimal in the CALC_SUM order, whose first key is the sum), so
 // no heap key is ever max() (sum -2): K7's key test needs no sentinel handling.  Checked here.
-AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
-    const int64_t gv = k.bid * k.nthreads + k.tid;
-    if (gv >= w.VT) return;
+AASM_DEV void sidetrack_vertex(const WS &w, int64_t gv) {
     const int64_t c = w.v_ctg[gv], vb = w.voff[c];
     const Dist *d = w.sp_d + vb;
     const Dist du = w.sp_d[gv];
@@ -1833,6 +1864,11 @@ AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     t.z = t.y >= 0 ? w.sp_best[vb + t.y] : -1;
     t.w = t.z >= 0 ? w.sp_best[vb + t.z] : -1;
     w.tnx[gv] = t;
+}
+AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;
+    sidetrack_vertex(w, gv);
 }
 // The same for dense graphs (rows of tens to hundreds of edges): a wave takes AASM_WAVE consecutive rows - one contiguous run of
 // edges - in chunks of 64 edges, lanes = edges.  What is sequential per row becomes ballots: the tree edge is the lowest
@@ -1912,17 +1948,14 @@ AASM_DEV void kb_sidetrack_w(const KCtx &k, const WS &w) {          // wave per 
 // and per child-list slot cinfo = {child, so(child), #keys(child), -}.  A parent hands every child the place
 // of its keys, so the wave fetches a vertex's header AND keys while it still works on the vertex before it
 // (the queue front; in a path-like tree the first child of the vertex at hand).
-AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
-    const int64_t gv = k.bid * k.nthreads + k.tid;
-    if (gv >= w.VT) return;
+// (returns the two header quads: kb_chain's prep wave publishes them only after everything else the vertex's step reads is in memory)
+AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b) {
     const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
     const int64_t c0 = w.rptr[gv], c1 = c0 + w.ccnt[gv];          // (kb_children: the list sits at the front of the in-list slots)
     const int32_t fc = (c1 > c0) ? w.cval[c0] : -1;
-    I4 a, b;
     a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;
     b.x = (int32_t)(uint32_t)(uint64_t)c0; b.y = (int32_t)((uint64_t)c0 >> 32);
     b.z = fc >= 0 ? (int32_t)(w.rowptr[vb + fc] - e_base) : 0; b.w = fc >= 0 ? w.st_n[vb + fc] : 0;
-    w.vhdr[gv] = a; w.vhdr2[gv] = b;
     {   // sixteen tree hops = four 4-hop records chained (kb_sidetrack wrote those; -1 past dest)
         I4 neg; neg.x = neg.y = neg.z = neg.w = -1;
         I4 *o = (I4 *)(w.tnx16 + 16 * gv);
@@ -1946,6 +1979,13 @@ AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
         }
     }
 }
+AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;
+    I4 a, b;
+    heap_hdr_vertex(w, gv, a, b);
+    w.vhdr[gv] = a; w.vhdr2[gv] = b;
+}
 
 // arena capacity per contig: an insert into a heap of s nodes allocates at most
 // floor(log2(s+1)) + 2 nodes (right-spine length + the new leaf), s < #sidetracks.
@@ -1954,10 +1994,11 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     if (c >= w.C) return;
     const int64_t V = w.ctgV[c];
     w.mw_flag[c] = 0; w.mw_cap[c] = 0; w.mw_lg[c] = 2;
+    if (w.chain_flag) w.chain_flag[c] = 0;
     if (V == 0) { w.hcap_cnt[c] = 0; return; }
     const int64_t vb = w.voff[c];
     const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
-    if (E > (int64_t)INT32_MAX - 64) { w.status[c] = -5; w.hcap_cnt[c] = 0; return; }   // contig-local edge ids are int32 (AASM_E_OVERFLOW)
+    if (E > (int64_t)INT32_MAX - 64) { w.status[c] = -5; w.hcap_cnt[c] = 0; return; }   // contig-local edge ids are int32 (AASM_E_OVERFLOW)  (not in the chain class either)
     int64_t I = E - (V - 1);
     if (I < 0) I = 0;
     int lg = 0;
@@ -1970,6 +2011,16 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     w.mw_cap[c] = w.mw_flag[c] ? (int32_t)cap : 0;
     w.hcap_cnt[c] = (w.mw_flag[c] && !w.mw_compact) ? 0 : (int32_t)cap;   // (a several-waves contig whose nodes stay in the provisional arena needs no final one)
     if (w.mw_flag[c]) { const int64_t slot = atomic_add(&w.counters[CNT_MW], (int64_t)1); w.mw_list[slot] = (int32_t)c; w.mw_key[slot] = (int32_t)cap; }
+    if (w.chain_flag) {
+        // the chain class: sparse one-wave contigs whose sweep, pre-pass and heaps run beside each other (kb_chain) - every contig of
+        // a small batch (the step is the chain of its slowest contig, not throughput) or the long tail of a big one
+        const int64_t N = w.rec_off[c + 1] - w.rec_off[c];
+        const bool sparse_batch = w.rowptr[w.VT] <= 6 * w.VT;
+        const bool in = !w.mw_flag[c] && sparse_batch && w.status[c] == 0 &&
+                        (w.chain_mode == 1 || (w.chain_mode == 0 && (w.chain_all || (w.chain_minN > 0 && N >= w.chain_minN))));
+        w.chain_flag[c] = in ? 1 : 0;
+        if (in) { const int64_t slot = atomic_add(&w.counters[CNT_CHAIN], (int64_t)1); w.chain_list[slot] = (int32_t)c; }
+    }
 }
 
 // Cooperative K7.  One wave per contig walks the SP tree in BFS order (arena index == allocation order,
@@ -2203,10 +2254,26 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
 }
 
 struct KProfNone { int64_t acc[8]; };   // (acc: only touched by the -DAASM_KPROF diagnostic build)
-AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave per contig
+// kb_chain's heap wave: the header of vertex u is in memory (the prep wave writes the two marker words last, after everything a
+// step reads through them); false: the prep wave is gone and the header never came, or 30 s passed (AASM_E_INTERNAL, not a hang)
+AASM_DEV bool chain_wait_hdr(ChainSync *S, const I4 *vh, const I4 *vh2, int32_t u) {
+    const int64_t t0 = wave_realtime();
+    int64_t guard = 0;
+    for (;;) {
+        const int32_t pd = uni(ld_shared_i32(&S->prep_done));       // (read before the words: a header written before the flag is seen)
+        const int32_t x = uni(ld_shared_i32(&vh[u].x)), y = uni(ld_shared_i32(&vh2[u].y));
+        if (x != -1 && y != -1) { wave_fence(); return true; }
+        if (pd) return false;
+        if ((++guard & 1023) == 0 && wave_realtime() - t0 > (int64_t)30 * 100000000) return false;
+        wave_sleep();
+    }
+}
+template <bool CHAIN = false>
+AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
+    if (!CHAIN && in_chain_class(w, c)) return;                      // (built inside kb_chain)
     HeapLds *L = (HeapLds *)k.lds;
     const int64_t vb = w.voff[c];
     int32_t *h = w.h_root + vb, *q = w.bq + vb;
@@ -2229,7 +2296,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 #endif
     if (k.lane == 0) w.h_cnt[c] = 0;
     if (w.status[c] != 0) return;
-    if (dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)
+    if (!CHAIN && dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)  (CHAIN: the sweep is still running - checked at the end)
+    bool chain_lost = false;                                         // CHAIN: a header never came
     int32_t head = 0, tail = 0, lds_hi = 0;                          // BFS queue positions; [head, lds_hi) live in the LDS window
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
@@ -2239,8 +2307,9 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
 #else
     KProfNone kp;
 #endif
-    int32_t u = dest, hu = -1, so, n;                                // the vertex at hand: id, inherited heap, key offset, #keys
-    {
+    int32_t u = dest, hu = -1, so = 0, n = 0;                        // the vertex at hand: id, inherited heap, key offset, #keys
+    if (CHAIN && !chain_wait_hdr(S, vh, vh2, dest)) chain_lost = true;
+    else {
         const I4 a0 = vh[dest];
         so = uni(a0.x); n = uni(a0.y);
     }
@@ -2248,11 +2317,13 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     int32_t pend_u = -1, pend_root = -1;                             // finished root of the previous vertex (lane 0), stored at the start of the next step
     int32_t staged = -1;                                             // the vertex whose keys are parked in L->stage and whose header words are in c_* (-1: none)
     int32_t c_nch = 0, c_fc = -1, c_sofc = 0, c_nfc = 0, c_c0lo = 0, c_c0hi = 0;   // {#children, first child, its key offset / #keys, child-list start}
-    while (!hs.ovf) {
-        HeapStage *S = &L->stage;
-        if (staged != u) {                                           // not staged (the root, a spilled queue entry): fetch now
+    while (!hs.ovf && !chain_lost) {
+        HeapStage *St = &L->stage;
+        if (staged != u) {                                           // not staged (the root, a spilled queue entry; CHAIN: a header that was not there yet when it was prefetched): fetch now
+            if (CHAIN && !chain_wait_hdr(S, vh, vh2, u)) { chain_lost = true; break; }
             const I4 ha = vh[u], hb = vh2[u];
-            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; S->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
+            if (CHAIN) { so = uni(ha.x); n = uni(ha.y); }            // (a spilled entry's pop could not read them yet)
+            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; St->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
             c_nch = uni(ha.z); c_fc = uni(ha.w); c_sofc = uni(hb.z); c_nfc = uni(hb.w); c_c0lo = uni(hb.x); c_c0hi = uni(hb.y);
             wave_lds_sync();
         }
@@ -2282,20 +2353,22 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
         for (int32_t t = 0; t < n && !hs.ovf; t++) {
             if (t >= HEAP_KMAX && (t & (HEAP_KMAX - 1)) == 0) {      // a row with more sidetracks than the slot holds (dense graphs): the next HEAP_KMAX keys replace the used ones.
                 wave_lds_sync();                                     // The insert below must only ever see a key that came out of LDS: with a global load as the other source of
-                FOR_LANE(j, (n - t < HEAP_KMAX ? n - t : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t + j]; S->key[j] = kk; }   // `cc` the compiler makes EVERY insert wait for vmcnt(0),
+                FOR_LANE(j, (n - t < HEAP_KMAX ? n - t : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t + j]; St->key[j] = kk; }   // `cc` the compiler makes EVERY insert wait for vmcnt(0),
                 wave_lds_sync();                                     // i.e. for the next vertex's prefetch issued a moment earlier
             }
-            const Dist cc = S->key[t & (HEAP_KMAX - 1)];
+            const Dist cc = St->key[t & (HEAP_KMAX - 1)];
             hu = heap_insert<true>(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
         }
         KPROF_STAMP(3);                                              // inserts
         pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
         // ---- park the prefetched context (its loads had the whole step; this vertex's keys are used up)
-        if (v2 >= 0) {                                               // (header words: straight into scalars - the loads are back by now)
+        bool v2_ok = v2 >= 0;
+        if (CHAIN && v2_ok && (uni(pa.x) == -1 || uni(pb.y) == -1)) v2_ok = false;   // its header was not written yet: the step that takes it waits (staged != u)
+        if (v2_ok) {                                                 // (header words: straight into scalars - the loads are back by now)
             c_nch = uni(pa.z); c_fc = uni(pa.w); c_sofc = uni(pb.z); c_nfc = uni(pb.w); c_c0lo = uni(pb.x); c_c0hi = uni(pb.y);
-            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) S->key[t] = pk.at(t);
+            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) St->key[t] = pk.at(t);
         }
-        staged = v2;
+        staged = v2_ok ? v2 : -1;
         // ---- children adopt the heap (:213)
         if (nch == 1 && head == tail) {                              // path-like tree: the only child is next, no queue traffic
             u = fc; so = so_fc; n = n_fc;
@@ -2332,8 +2405,168 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w) {                 // one wave 
     if (pend_u >= 0) h[pend_u] = pend_root;
     heap_flush(hs, k.lane);
     KPROF_FLUSH(w.prof_heap, c, k.lane);
+    if (CHAIN) {
+        // :188-189 (no src -> dest path: must not happen) can only be asked once the sweep has finished
+        const int64_t t0 = wave_realtime();
+        int64_t guard = 0;
+        while (!chain_lost && !uni(ld_shared_i32(&S->sweep_done))) {
+            if ((++guard & 1023) == 0 && wave_realtime() - t0 > (int64_t)30 * 100000000) chain_lost = true;
+            wave_sleep();
+        }
+        wave_fence();
+        if (chain_lost || uni(ld_shared_i32(&w.sp_d[vb + src].anom)) < 0) { if (k.lane == 0) { set_status(w, c, -6); w.h_cnt[c] = 0; } return; }   // (max() is the only distance with a negative anom)
+    }
     if (hs.ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
     if (k.lane == 0) { w.h_cnt[c] = hs.alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)hs.alloc); }
+}
+
+// ====================================================================================
+// The chain class: K6's sweep, K7's pre-pass and K7's heaps of ONE contig beside each other (kb_chain)
+// ====================================================================================
+// K6 -> K7 pre-pass -> K7 were three launches, each one wave's dependent chain per contig, each ending on the launch's longest
+// contig: their times ADD (one 1 000-record contig: 0.98 + 2.18 ms; the 8 057-record contig of a heavy-tailed file: 11.3 + 21.6 ms
+// while the rest of the chip idles).  Nothing in the data says they have to: a vertex's distance and tree edge are final the
+// moment the sweep APPENDS it to its queue (every out-edge relaxed: k_shortest_walks.hpp:160-175), its sidetrack keys need only
+// that and the distances of its heads (final earlier), and the heap of a vertex needs its parent's heap and its own keys
+// (:196-215).  So a workgroup of three waves takes a contig:
+//   wave 0  the reverse sweep as before (kb_rev_sweep), which now also publishes how many vertices of rev_order are final;
+//   wave 1  the pre-pass, lanes over vertices, behind it: for the vertices that became final - their sidetrack keys (what
+//           kb_sidetrack does), then one count-down per out-edge on the head's `pend`; a vertex whose in-neighbours ALL have their
+//           keys gets its child list and header (kb_children + kb_heap_hdr: the children of u are in-neighbours of u) - these
+//           go through a work list (cq) and are published by the header's two marker words turning from -1;
+//   wave 2  the heaps in the reference's BFS order, exactly kb_heap (same arena, same indices), which waits for a header only
+//           where the one-launch form could assume it.
+// The graphs are local (edges join neighbouring parts, paf_data.cpp:599-694), so a vertex's in-neighbours are final soon after
+// it: the heap wave - the slowest of the three - finds what it needs and the contig costs max(K6, K7) instead of the sum.
+// Every wait ends: the sweep waits for nobody; the pre-pass only for the sweep (`sweep_done`); the heap wave only for the
+// pre-pass (`prep_done`), and gives up with AASM_E_INTERNAL after 30 s rather than sit.
+#define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES + 16)
+#define CHAIN_WAVES 3
+#define CHAIN_LONG_ROW 8
+struct ChainLds { RevQ rq; HeapLds hl; ChainSync s; };
+static_assert(sizeof(ChainLds) <= AASM_CHAIN_LDS_BYTES, "LDS budget");
+
+AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
+    const int64_t vb = w.voff[c];
+    const int32_t *q = w.rev_order + vb;
+    int32_t *pend = w.pend + vb, *cq = w.cq + vb;
+    int32_t done1 = 0, r2_head = 0, r2_tail = 0;                     // final vertices keyed so far; work list [r2_head, r2_tail)
+    const int64_t t_start = wave_realtime();
+    int64_t guard = 0;
+    int32_t result = 1;
+    for (;;) {
+        const int32_t sd = uni(ld_shared_i32(&S->sweep_done));      // (before the count: once it is set the count is the last one)
+        const int32_t t = uni(ld_shared_i32(&S->tail_pub));
+        wave_fence();
+        bool did = false;
+        if (done1 < t) {
+            // ---- keys of up to 64 newly final vertices, a lane each; then the count-downs along their out-edges
+            const int32_t n1 = (t - done1 < AASM_WAVE) ? (t - done1) : AASM_WAVE;
+            int32_t v = -1, deg = 0;
+            int64_t r0 = 0;
+            bool self = false;
+            if (k.lane < n1) {
+                v = q[done1 + k.lane];
+                sidetrack_vertex(w, vb + v);
+                r0 = w.rowptr[vb + v]; deg = (int32_t)(w.rowptr[vb + v + 1] - r0);
+                self = w.rptr[vb + v + 1] == w.rptr[vb + v];        // no in-neighbour (src): nothing to wait for
+            }
+            wave_fence();                                            // the keys are in memory before anybody is told
+            {
+                const uint64_t m = wave_ballot(self);
+                if (self) cq[r2_tail + popc64(m & lanemask_lt(k.lane))] = v;
+                r2_tail += popc64(m);
+            }
+            const bool longrow = deg > CHAIN_LONG_ROW;
+            for (int32_t e = 0; wave_any(!longrow && e < deg); e++) {   // short rows: the lane walks its own row
+                bool hit = false;
+                int32_t x = -1;
+                if (!longrow && e < deg) { x = w.e_col[r0 + e]; hit = atomic_add(&pend[x], (int32_t)-1) == 1; }
+                const uint64_t m = wave_ballot(hit);
+                if (hit) cq[r2_tail + popc64(m & lanemask_lt(k.lane))] = x;
+                r2_tail += popc64(m);
+            }
+            uint64_t lm = wave_ballot(longrow);                      // long rows (src's, a wide part's): all lanes over the row
+            while (lm) {
+                const int sl = ffs64(lm) - 1;
+                lm &= lm - 1;
+                const int64_t r02 = wave_bcast(r0, sl);
+                const int32_t deg2 = wave_bcast(deg, sl);
+                for (int32_t e0 = 0; e0 < deg2; e0 += AASM_WAVE) {
+                    const int32_t e = e0 + k.lane;
+                    bool hit = false;
+                    int32_t x = -1;
+                    if (e < deg2) { x = w.e_col[r02 + e]; hit = atomic_add(&pend[x], (int32_t)-1) == 1; }
+                    const uint64_t m = wave_ballot(hit);
+                    if (hit) cq[r2_tail + popc64(m & lanemask_lt(k.lane))] = x;
+                    r2_tail += popc64(m);
+                }
+            }
+            done1 += n1;
+            did = true;
+            wave_fence();
+        }
+        if (r2_head < r2_tail) {
+            // ---- child lists + headers of up to 64 vertices whose in-neighbours all have their keys
+            const int32_t n2 = (r2_tail - r2_head < AASM_WAVE) ? (r2_tail - r2_head) : AASM_WAVE;
+            int32_t u = -1;
+            if (k.lane < n2) { u = cq[r2_head + k.lane]; children_vertex(w, vb + u); }
+            wave_fence();                                            // (the header pass reads the child list back)
+            I4 a, b;
+            a.x = a.y = a.z = a.w = 0; b = a;
+            if (k.lane < n2) heap_hdr_vertex(w, vb + u, a, b);
+            wave_fence();                                            // child slots, jump records: in memory before the marker words
+            if (k.lane < n2) { w.vhdr2[vb + u] = b; w.vhdr[vb + u] = a; }
+            r2_head += n2;
+            did = true;
+            wave_fence();
+        }
+        if (!did) {
+            if (sd && done1 >= t && r2_head == r2_tail) break;
+            if ((++guard & 1023) == 0 && wave_realtime() - t_start > (int64_t)60 * 100000000) { result = 2; break; }   // (never: the sweep always ends)
+            wave_sleep();
+        }
+    }
+    store_drain();
+    st_shared_i32(&S->prep_done, result);
+}
+
+// The three roles share one kernel, hence one register allocation: with every role reading its pointers from the kernel's
+// argument block the compiler loads them all into scalar registers up front, and the heap role - the critical path, 89 SGPRs on
+// its own - ran with 36 of its scalars spilled to vector lanes (2.36 ms for a 1 000-record contig against 2.16 in the kernel of
+// its own).  The sweep and the pre-pass have time to spare, so THEY read the argument block through a pointer the compiler
+// cannot see through: their loads stay inside their branch and land in vector registers.
+#if defined(AASM_HOST_EMUL)
+AASM_DEV const WS &chain_role_ws(const WS &w) { return w; }
+#else
+// (WS is the kernel's only argument: offset 0 of the argument segment.  Taking &w instead would make the compiler copy the
+// whole structure to scratch memory first.)
+AASM_DEV const WS &chain_role_ws(const WS &) {
+    const WS *p = (const WS *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+#endif
+AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAVES waves per contig of the class
+    ChainLds *L = (ChainLds *)k.lds;
+    const int64_t c = w.chain_list[k.bid];
+    const int wv = k.tid / AASM_WAVE;
+    if (k.tid == 0) { L->s.tail_pub = 0; L->s.sweep_done = 0; L->s.prep_done = 0; L->s.pad = 0; }
+    block_barrier();
+    KCtx k2 = k;
+    k2.bid = c; k2.tid = k.lane; k2.nthreads = AASM_WAVE;
+    if (wv == 0) {
+        k2.lds = (char *)&L->rq;
+        kb_rev_sweep<AASM_WAVE, true>(k2, chain_role_ws(w), &L->s);
+    } else if (wv == 1) {
+        chain_prep(k2, chain_role_ws(w), c, &L->s);
+    } else {
+#if !defined(AASM_HOST_EMUL)
+        __builtin_amdgcn_s_setprio(1);                               // the heap wave is the contig's critical path
+#endif
+        k2.lds = (char *)&L->hl;
+        kb_heap<true>(k2, w, &L->s);
+    }
 }
 
 // ====================================================================================

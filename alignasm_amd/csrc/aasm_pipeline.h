@@ -24,7 +24,7 @@ enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_CHILD_SIDE, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
-    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -58,7 +58,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_SIDETRACK_W: kb_sidetrack_w(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
-        case KN_HEAP: kb_heap(k, w); break;
+        case KN_HEAP: kb_heap<false>(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
         case KN_MW_RANK: kb_mw_rank(k, w); break;
 #if defined(AASM_HOST_EMUL)
@@ -78,11 +78,13 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SEL_CLASSIFY: kb_sel_classify(k, w); break;
         case KN_SEL_CONVERT: kb_sel_convert(k, w); break;
         case KN_SEL_FINAL: kb_sel_final(k, w); break;
+        case KN_CHAIN: kb_chain(k, w); break;
         default: break;
     }
 }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+#define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups at 4 waves / SIMD)
 
 struct PipelineSizes { int64_t C = 0, R = 0, S = 0, VT = 0, ET = 0, HT = 0, bad_record = -1; };
 
@@ -102,6 +104,15 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     w.nsl = opts.non_skip_linkable ? 1 : 0;
     w.xcd_map = (opts.reserved[0] & 32) ? 0 : 1;                      // (bit 5, probes: blocks take work items in grid order)
     w.sort_depth_test = (opts.reserved[2] >> 8) & 0xff;               // test hook: depth limit of kb_sort_fix's introsort
+    // the chain class (kb_chain: sweep, pre-pass and heaps of a contig beside each other).  reserved[0] bit 6: every sparse contig,
+    // bit 7: none; else by shape: every contig of a batch too small to fill the chip (its step is its slowest contig's chain), and
+    // the long tail of a big one (contigs of >= 4x the mean and >= 2048 records: each a chain many times the batch's own step)
+    // (both bits, tests: the contigs of at least the batch's mean size - a class that is part of the batch whatever its shape, so that
+    // the class's workgroups and the three launches of the others run beside each other)
+    w.chain_mode = (opts.reserved[0] & 192) == 192 ? 0 : (opts.reserved[0] & 64) ? 1 : (opts.reserved[0] & 128) ? 2 : 0;
+    w.chain_all = ((opts.reserved[0] & 192) != 192 && C <= AASM_CHAIN_SMALL_BATCH) ? 1 : 0;
+    w.chain_minN = (int32_t)std::min<int64_t>(std::max<int64_t>(2048, 4 * (R / std::max<int64_t>(C, 1))), INT32_MAX);
+    if ((opts.reserved[0] & 192) == 192) w.chain_minN = (int32_t)std::min<int64_t>(std::max<int64_t>(1, cdiv(R, std::max<int64_t>(C, 1))), INT32_MAX);
     w.rec_off = in.ctg_rec_off; w.in_qs = in.qry_str; w.in_qe = in.qry_end; w.in_rs = in.ref_str; w.in_re = in.ref_end;
     w.in_qt = in.qry_total; w.in_chr = in.ref_chr; w.in_fwd = in.aln_fwd; w.in_mq = in.map_qul;
     w.in_rng_off = in.rec_rng_off; w.rql = in.rng_qry_l; w.rqr = in.rng_qry_r; w.rrl = in.rng_ref_l; w.rng_stride = 1;
@@ -197,12 +208,23 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.launch(KN_NSL, cdiv(R, 256), 256, w);
         }
         A(deg, int32_t, VT, "deg"); A(rowptr, int64_t, VT + 1, "csr_rowptr");
+        // (heap arena sizing + classes need only V and E per contig: sized here, so that their read-back shares the edges' one)
+        A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
+        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted"); A(mw_key, int32_t, C, "mw_key");
+        A(chain_flag, int32_t, C, "chain_flag"); A(chain_list, int32_t, C, "chain_list");
+        w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
+        w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         CHECK_ALLOC();
         be.launch(KN_ROW_COUNT, cdiv(VT, 256), 256, w);
         be.scan_i32(w.deg, VT, w.rowptr);
-        int64_t et_mv[2];
-        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV}, et_mv);
+        be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
+        be.scan_i32(w.hcap_cnt, C, w.hoff);
+        be.scan_i32(w.mw_cap, C, w.mw_off);
+        int64_t et_mv[7];
+        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN}, et_mv);
         const int64_t ET = et_mv[0], MAXV_OVER = et_mv[1];            // (MAXV_OVER: 0, or the largest contig of more than REV_ORD_MAXV vertices)
+        const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
+        const int64_t NCHAIN = et_mv[6];
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
         AZ(indeg, int32_t, VT, "indeg");
@@ -224,6 +246,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         }
         A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
         A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
+        if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); }
         CHECK_ALLOC();
         be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
@@ -255,30 +278,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // (Measured in round 4, same box: started after the reverse sweep instead, or beside K7 only, the reverse sweep drops to 1.98 ms
         // but K7 beside it rises 4.10 -> 4.6 / 5.0 ms and the step 12.60 -> 12.99 / 12.91: every chain kernel is short of issue slots.)
         side_work();
-        be.phase_begin(AASM_PH_SPTREE);
-        if (grouped) be.launch(KN_REV_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
-        else be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
-        be.phase_end(AASM_PH_SPTREE);
-
-        // ---- K7 heaps
-        be.phase_begin(AASM_PH_HEAP_PREP);
+        // ---- K7's arrays (the chain class fills them while its sweep still runs, so they exist before any sweep starts)
         A(ccnt, int32_t, VT, "ccnt"); A(cval, int32_t, ET, "cval");
-        A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
-        A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted"); A(mw_key, int32_t, C, "mw_key");
-        w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
-        w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         A(st_cost, Dist, ET, "st_cost"); A(st_n, int32_t, VT, "st_n"); A(vhdr, I4, VT, "vhdr"); A(vhdr2, I4, VT, "vhdr2"); A(cinfo, I4, ET, "cinfo"); A(tnx, I4, VT, "tnx"); A(tnx16, int32_t, 16 * VT, "tnx16");
-        CHECK_ALLOC();
-        if (ET > 6 * VT) {
-            be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
-            be.launch(KN_SIDETRACK_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
-        } else be.launch(KN_CHILD_SIDE, cdiv(VT, 256), 256, w);
-        be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
-        be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
-        be.scan_i32(w.hcap_cnt, C, w.hoff);
-        be.scan_i32(w.mw_cap, C, w.mw_off);
-        int64_t hh[4];
-        be.read_i64s({w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN}, hh);
         const int64_t HT = hh[0], HTM = hh[1], NMW = HTM > 0 ? hh[2] : 0;
         sz.HT = HT;
         w.avg_sidetracks = (int32_t)std::min<int64_t>((ET - VT + C) / (C > 0 ? C : 1), INT32_MAX);
@@ -288,6 +290,31 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         CHECK_ALLOC();
         be.fill_ff(w.h_root, sizeof(int32_t) * (size_t)VT);
         be.fill_ff(w.bq, sizeof(int32_t) * (size_t)VT);
+        if (NCHAIN > 0) {
+            // the class's workgroups (three waves a contig) on a stream of their own, beside the forward sweep and - when the class is
+            // only the batch's long tail - beside the three launches of everybody else
+            be.fill_ff(w.vhdr, sizeof(I4) * (size_t)VT);             // the marker words the heap wave waits on
+            be.fill_ff(w.vhdr2, sizeof(I4) * (size_t)VT);
+            be.fork2();
+            be.use_side2(true);
+            be.phase_begin(AASM_PH_CHAIN);
+            be.launch(KN_CHAIN, NCHAIN, AASM_WAVE * CHAIN_WAVES, w);
+            be.phase_end(AASM_PH_CHAIN);
+            be.use_side2(false);
+        }
+        if (NCHAIN < C) {
+        be.phase_begin(AASM_PH_SPTREE);
+        if (grouped) be.launch(KN_REV_SWEEP_G, cdiv(C, sweep_n), AASM_WAVE, w);
+        else be.launch(KN_REV_SWEEP, C, AASM_WAVE, w);
+        be.phase_end(AASM_PH_SPTREE);
+
+        // ---- K7 heaps
+        be.phase_begin(AASM_PH_HEAP_PREP);
+        if (ET > 6 * VT) {
+            be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
+            be.launch(KN_SIDETRACK_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
+        } else be.launch(KN_CHILD_SIDE, cdiv(VT, 256), 256, w);
+        be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_HEAP_PREP);
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
@@ -311,6 +338,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             } else be.launch(kn, C, AASM_WAVE * mw, w);
         }
         be.phase_end(AASM_PH_HEAP);
+        }                                                            // (NCHAIN < C)
+        be.join2();                                                  // the chain class's heaps, before anybody enumerates
 
         // ---- K8 enumeration
         const int64_t K = w.K;

@@ -175,9 +175,14 @@ void gen_contig(const aasm_synth_cfg &cfg, int64_t c, int64_t nrec, bool want_cs
 
 }  // namespace
 
-extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
+// Contigs [first, first + count) of the file `cfg` describes (a contig has its own PRNG stream, so a range of the file equals
+// the same contigs of the whole; names keep the file's numbering).  cfg->reserved bit 2: records only - no match ranges, no cs
+// tags (what the contig cost model reads: a rank of a sharded run cuts the WHOLE file from this form, then generates its block).
+extern "C" int aasm_synth_paf_range(const aasm_synth_cfg *cfg, int64_t first, int64_t count, aasm_paf **out) {
     if (!cfg || !out || cfg->n_contigs <= 0 || cfg->recs_per_contig <= 0) return AASM_E_INVAL;
-    const bool want_cs = !(cfg->reserved & 2);
+    if (first < 0 || count <= 0 || first > cfg->n_contigs - count) return AASM_E_INVAL;
+    const bool recs_only = (cfg->reserved & 4) != 0;
+    const bool want_cs = !(cfg->reserved & 2) && !recs_only;
     const int64_t C = cfg->n_contigs;
     // contig sizes
     std::vector<int64_t> sizes(C, cfg->recs_per_contig);
@@ -195,13 +200,22 @@ extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
         const double scale = (double)(cfg->recs_per_contig * C) / tot;
         for (int64_t c = 0; c < C; c++) sizes[c] = std::max<int64_t>(1, (int64_t)std::llround(raw[c] * scale));
     }
-    std::vector<CtgOut> parts(C);
+    std::vector<CtgOut> parts(count);
     unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (C < 8) nt = 1;
+    if (count < 8) nt = 1;
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] { for (int64_t c = t; c < C; c += nt) gen_contig(*cfg, c, sizes[c], want_cs, parts[c]); });
+            th.emplace_back([&, t] {
+                for (int64_t c = t; c < count; c += nt) {
+                    CtgOut &p = parts[c];
+                    gen_contig(*cfg, first + c, sizes[first + c], want_cs, p);
+                    if (recs_only) {                                 // keep the records, drop the ranges
+                        std::vector<int64_t>().swap(p.ql); std::vector<int64_t>().swap(p.qr); std::vector<int64_t>().swap(p.rl);
+                        std::fill(p.rng_off.begin(), p.rng_off.end(), 0);
+                    }
+                }
+            });
         for (auto &x : th) x.join();
     }
     aasm_paf *paf = new aasm_paf();
@@ -218,9 +232,9 @@ extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
     paf->ctg_rec_off.push_back(0); paf->rec_rng_off.push_back(0); paf->cs_off.push_back(0);
     char name[32];
     int32_t row = 0;
-    for (int64_t c = 0; c < C; c++) {
+    for (int64_t c = 0; c < count; c++) {
         CtgOut &p = parts[c];
-        std::snprintf(name, sizeof name, "ptg%06lldl", (long long)c);
+        std::snprintf(name, sizeof name, "ptg%06lldl", (long long)(first + c));
         paf->ctg_name.push_back(name);
         const int64_t n = (int64_t)p.qs.size();
         const int64_t rng_base = (int64_t)paf->rng_qry_l.size();
@@ -245,4 +259,9 @@ extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
     }
     *out = paf;
     return AASM_OK;
+}
+
+extern "C" int aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **out) {
+    if (!cfg) return AASM_E_INVAL;
+    return aasm_synth_paf_range(cfg, 0, cfg->n_contigs, out);
 }

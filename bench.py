@@ -19,8 +19,10 @@ solves only its own block.  Contigs are independent, so no collective runs on th
 (only the barrier + MAX-reduce of the wall time).  Total work is fixed as N grows, hence
 "scaling": "strong"; value = 5 000 contigs x steps / max-over-ranks time.  The weak-scaling
 number (every rank solves its own C3-sized file, seed 21 + 1000*rank) is reported beside it
-under "weak".  `--workload c5` (dense, K=16) is defined on 8 GPUs at 1 250 contigs per GPU -- the
-10 000-contig file does not fit one GPU -- and keeps that per-GPU share for any N (weak).
+under "weak".  `--workload c5` (BASELINE configs[4]: 10 000 dense contigs, K=16) is ONE file too:
+aasm_partition_contigs cuts it into 8 cost-balanced pieces (a piece is what fits one GPU's HBM with
+its ~59 GB workspace), rank r of N generates and solves pieces [r*8/N, (r+1)*8/N) one after the
+other, a step = every piece once; strong scaling, value = 10 000 contigs x steps / time.
 
 Extra keys of the N = 1 line: `step_with_fetch_ms` (the step plus the D2H + ragged pack of the
 three result lists); `k10000` (the same hot path at the reference's shipped MAX_PATH_COUNT = 10000,
@@ -53,8 +55,9 @@ WORKLOADS = {
     # name: (contigs, recs, dense, K, seed, description)
     "c2": (50, 1000, False, 1, 11, "C2 single-chromosome synthetic PAF: 50 contigs x 1000 records, sparse, K=1, seed 11"),
     "c3": (5000, 1000, False, 4, 21, "C3 human WGS-scale synthetic PAF: 5000 contigs x 1000 records (5M records), sparse, K=4, seed 21"),
-    # C5 is defined on 8 GPUs (10000 contigs, contig-sharded): the per-GPU share, kept fixed for any --gpus (weak scaling)
-    "c5": (1250, 1000, True, 16, 31, "C5 cancer-karyotype synthetic PAF: 10000 contigs x 1000 records on 8 GPUs = 1250 contigs per GPU, dense, K=16, seed 31"),
+    # C5 (BASELINE configs[4]): ONE 10000-contig dense file.  aasm_partition_contigs cuts it into 8 pieces (what one GPU holds:
+    # ~59 GB of workspace per piece); rank r of N solves pieces [r*8/N, (r+1)*8/N) one after the other - the same file at every N
+    "c5": (10000, 1000, True, 16, 31, "C5 cancer-karyotype synthetic PAF: 10000 contigs x 1000 records (10M records), dense, K=16, seed 31"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -78,20 +81,51 @@ def total_bytes(st, n_records):
             + 24 * st["n_heap_nodes"] + 192 * st["n_paths_found"])
 
 
-def timed_steps(db, K, steps, barrier):
-    """K x steps of the resident batch; returns (elapsed seconds, summed phase times, last stats)."""
+def merge_stats(acc, st):
+    """Sum of the per-piece statistics of one step (a rank may hold its block of the file as several resident pieces)."""
+    if acc is None:
+        acc = {k: (dict(v) if isinstance(v, dict) else v) for k, v in st.items()}
+        return acc
+    for k, v in st.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                acc[k][kk] = acc[k].get(kk, 0.0) + vv
+        elif k == "device_bytes":
+            acc[k] = max(acc[k], v)
+        elif isinstance(v, (int, float)):
+            acc[k] = acc.get(k, 0) + v
+    return acc
+
+
+def timed_steps(dbs, K, steps, barrier):
+    """steps x (every resident piece of this rank once); returns (elapsed seconds, summed phase times, stats of the last step)."""
+    if not isinstance(dbs, (list, tuple)):
+        dbs = [dbs]
     phase_acc, stats = {}, None
     barrier()
     t_begin = time.perf_counter()
     for _ in range(steps):
-        res = db.solve(max_paths=K, timing=True)          # enqueues the pipeline and syncs its stream
-        stats = res.stats()
-        res.close()
-        for k, v in stats["phase_ms"].items():
-            phase_acc[k] = phase_acc.get(k, 0.0) + v
+        stats = None
+        for db in dbs:
+            res = db.solve(max_paths=K, timing=True)      # enqueues the pipeline and syncs its stream
+            st = res.stats()
+            res.close()
+            for k, v in st["phase_ms"].items():
+                phase_acc[k] = phase_acc.get(k, 0.0) + v
+            stats = merge_stats(stats, st)
     elapsed = time.perf_counter() - t_begin
     barrier()
     return elapsed, phase_acc, stats
+
+
+def library_identity(A):
+    """Which shared object this process measured: path + sha256 (the line did not say)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(A.api.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return {"path": os.path.relpath(A.api.LIB_PATH, ROOT), "sha256": h.hexdigest(), "override": bool(os.environ.get("AASM_LIB_OVERRIDE"))}
 
 
 def main():
@@ -107,7 +141,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip step_with_fetch / k10000 / weak (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="contigs of the workload timed on the CPU oracle")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end command-line run")
+    ap.add_argument("--allow-override", action="store_true", help="accept AASM_LIB_OVERRIDE (a diagnostic build of the library; the line names what it loaded)")
     args = ap.parse_args()
+
+    if os.environ.get("AASM_LIB_OVERRIDE") and not args.allow_override:
+        raise SystemExit("bench.py: AASM_LIB_OVERRIDE is set (%s); the bench measures the in-tree library - unset it, or pass "
+                         "--allow-override to measure that build on purpose" % os.environ["AASM_LIB_OVERRIDE"])
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (nothing has touched the GPU yet) and
@@ -152,8 +191,9 @@ def main():
     K = args.k or K
     if custom:
         desc = f"CUSTOM {nc} contigs x {nr} records, {'dense' if dense else 'sparse'}, K={K}, seed {seed} (not the BASELINE workload)"
-    strong = world > 1 and args.workload != "c5"           # C4: one file, sharded
-    if strong and not custom:
+    pieces_file = args.workload == "c5"                    # C5: one file in 8 (or a multiple of N) pieces, a rank solves its pieces in turn
+    strong = world > 1 or pieces_file                      # C4 / C5: one file, sharded
+    if world > 1 and not pieces_file and not custom:
         desc = ("C4 = the C3 file (5000 contigs x 1000 records, sparse, K=4, seed 21) contig-sharded over %d GPUs, "
                 "static cost-balanced contiguous partition" % world)
 
@@ -170,28 +210,49 @@ def main():
 
     # ---- synthetic batch of this rank, uploaded before the timed region
     t0 = time.time()
-    if strong:
+    pafs = []                                              # library handles to release at the end
+    if pieces_file:
+        n_pieces = 8 if 8 % world == 0 else world * -(-8 // world)
+        n_pieces = min(n_pieces, nc)
+        whole = A.Paf.synth(nc, nr, seed, dense=dense, records_only=True)    # every rank cuts the SAME file (records only: what the cost model reads)
+        cuts = shard.partition_contigs(whole, n_pieces)
+        whole.close()
+        per = n_pieces // world
+        mine = []
+        for pc in range(rank * per, (rank + 1) * per):
+            pp = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True, first=cuts[pc], count=cuts[pc + 1] - cuts[pc])   # = those contigs of the whole file
+            pafs.append(pp)
+            mine.append(pp)
+        paf = mine[0]
+        my_contigs = sum(cuts[pc + 1] - cuts[pc] for pc in range(rank * per, (rank + 1) * per))
+        n_records = sum(int(m.view().n_records) for m in mine)
+        contigs_total = nc
+        desc += "; cut into %d pieces by aasm_partition_contigs, %d piece(s) per rank solved one after the other" % (n_pieces, per)
+    elif world > 1:
         paf = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True)            # the SAME file on every rank
         cuts = shard.partition_contigs(paf, world)
-        mine = HostBatch.from_view_range(paf.view(), cuts[rank], cuts[rank + 1])
+        mine = [HostBatch.from_view_range(paf.view(), cuts[rank], cuts[rank + 1])]
         paf.close()
         paf = None
-        my_contigs, n_records = mine.n_contigs, int(mine.view.n_records)
+        my_contigs, n_records = mine[0].n_contigs, int(mine[0].view.n_records)
         contigs_total = nc
     else:
-        paf = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
-        mine = paf
+        paf = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True)
+        pafs.append(paf)
+        mine = [paf]
         my_contigs, n_records = nc, int(paf.view().n_records)
-        contigs_total = nc * world
+        contigs_total = nc
         cuts = None
     gen_s = time.time() - t0
     t0 = time.time()
-    db = A.DeviceBatch(mine, device=local_rank)
+    dbs = [A.DeviceBatch(m, device=local_rank) for m in mine]
+    db = dbs[0]
     upload_s = time.time() - t0
 
     for _ in range(args.warmup):
-        db.solve(max_paths=K, timing=True).close()
-    elapsed, phase_acc, stats = timed_steps(db, K, args.steps, barrier)
+        for d_ in dbs:
+            d_.solve(max_paths=K, timing=True).close()
+    elapsed, phase_acc, stats = timed_steps(dbs, K, args.steps, barrier)
     elapsed = allreduce(elapsed, dist.ReduceOp.MAX if dist else None)
     total_edges = allreduce(stats["n_edges"], dist.ReduceOp.SUM if dist else None)
     max_contigs = allreduce(my_contigs, dist.ReduceOp.MAX if dist else None)
@@ -202,11 +263,12 @@ def main():
         barrier()
         t = time.perf_counter()
         for _ in range(args.steps):
-            res = db.solve(max_paths=K)
-            A.api.free_out(res.fetch_raw())                          # aasm_result_fetch: D2H + ragged pack, as a C caller receives it
-            res.close()
+            for d_ in dbs:
+                res = d_.solve(max_paths=K)
+                A.api.free_out(res.fetch_raw())                      # aasm_result_fetch: D2H + ragged pack, as a C caller receives it
+                res.close()
         extras["step_with_fetch_ms"] = round(allreduce((time.perf_counter() - t) * 1e3 / max(args.steps, 1), dist.ReduceOp.MAX if dist else None), 3)
-        if world == 1:
+        if world == 1 and len(dbs) == 1:
             # the reference's shipped MAX_PATH_COUNT (paf_data.cpp:729): the whole batch, and a 1000-contig slice of it
             def at_k10000(batch_dev, n):
                 batch_dev.solve(max_paths=10000).close()
@@ -220,7 +282,7 @@ def main():
                         "pq_pushes": stk["pq_pushes"], "enum_ms": round(stk["phase_ms"].get("enum", 0.0), 3), "select_ms": round(stk["phase_ms"].get("select", 0.0), 3)}
             full = at_k10000(db, my_contigs)
             nk = min(1000, my_contigs)
-            hbk = HostBatch.from_view_range(mine.view() if not isinstance(mine, HostBatch) else mine.view, 0, nk)
+            hbk = HostBatch.from_view_range(mine[0].view() if not isinstance(mine[0], HostBatch) else mine[0].view, 0, nk)
             dbk = A.DeviceBatch(hbk, device=local_rank)
             part = at_k10000(dbk, nk)
             dbk.close()
@@ -230,7 +292,9 @@ def main():
                 # the shapes real PAFs have (alignasm.cpp:346-361 takes contigs of any size): same record count, same K
                 uniform_ms = elapsed * 1e3 / max(args.steps, 1)
                 for key, kw, what in (("c3_heavy_tail", {"heavy_tail": True}, "contig sizes log-normal(ln 600, 1) clipped to [1, 8000], rescaled to 5M records"),
-                                      ("c3_dup3", {"dup_every": 3}, "every third record duplicated on another chromosome (equal sort keys, tied scores)")):
+                                      ("c3_dup3", {"dup_every": 3}, "every third record duplicated on another chromosome (equal sort keys, tied scores)"),
+                                      ("c3_shuffled", {"shuffle": True}, "the SAME C3 file with the records of every contig in random order (the generator writes contigs in query order, "
+                                       "which K1's sorted-input shortcut detects: aligner output has no such order - `phase_ms.sort` here is the sort phase that does not depend on it)")):
                     pv = A.Paf.synth(nc, nr, seed, dense=dense, no_cs=True, **kw)
                     sizes = pv.batch().arrays["ctg_rec_off"]
                     longest = int((sizes[1:] - sizes[:-1]).max())
@@ -246,7 +310,7 @@ def main():
                     pv.close()
             if not args.no_e2e and not custom:
                 extras["e2e"] = e2e_cli(nc, nr, seed, dense, K)
-        if strong:
+        if world > 1 and not pieces_file:
             # weak scaling beside it: every rank solves its own C3-sized file
             db.close()
             pw = A.Paf.synth(nc, nr, seed + 1000 * rank, dense=dense, no_cs=True)
@@ -258,7 +322,7 @@ def main():
                               "contigs_per_gpu": nc, "note": "every rank solves its own C3-sized file (seed 21 + 1000*rank)"}
             dbw.close()
             pw.close()
-            db = None
+            dbs = []
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -293,18 +357,19 @@ def main():
                       "paths_found": stats["n_paths_found"], "paths_converted": stats["n_paths_converted"],
                       "device_MB": stats["device_bytes"] >> 20},
             "setup": {"gen_s": round(gen_s, 2), "upload_s": round(upload_s, 2)},
+            "library": library_identity(A),
         }
         out.update(extras)
         pmc = pmc_traffic(args.workload, custom or world > 1, dom_name)
         if pmc:
             out["roofline"].update(pmc)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(paf, nc, K, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(paf, min(nc, paf.n_contigs), K, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    if db is not None:
-        db.close()
-    if paf is not None:
-        paf.close()
+    for d_ in dbs:
+        d_.close()
+    for p_ in pafs:
+        p_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -312,13 +377,11 @@ def main():
 
 def self_launch(n):
     """One rank per GPU through torch.distributed.run, as the driver launches N > 1 itself; returns the child's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks a free rendezvous port itself (binding port 0, closing it and handing the number on left a window
+    # for another process to take it); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     print("bench.py: --gpus %d without a launcher, starting: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
@@ -408,11 +471,17 @@ def reference_prefix(paf, nc, usable):
     O.oracle_time_prefix.restype = C.c_double
     n = min(96, nc)
     hb = HostBatch.from_view_range(paf.view(), 0, n)
-    out = {"sample": f"first {n} contigs of the workload, K1-K8 only, K = 10000 (the reference's constant), one contig per task", "rows": []}
+    out = {"sample": f"first {n} contigs of the workload, K1-K8 only, one contig per task",
+           "note": "timed at K = 10000 on BOTH sides: MAX_PATH_COUNT is a constant of the reference (paf_data.cpp:729), so its K1-K8 cannot run at the "
+                   "headline's K; the `port` figures of this block (`value`, `value_1t`, `scaling`) are at the headline's K",
+           "max_paths": 10000, "rows": []}
     for th in sorted({1, min(8, usable), usable}):
         m = n if th > 1 else min(n, 24)
         tr = R.refp_time_batch(C.byref(hb.view), C.c_int64(0), C.c_int64(m), th, 0)
         tp = O.oracle_time_prefix(C.byref(hb.view), C.c_int64(0), C.c_int64(m), th, 0, C.c_int64(10000))
+        if not (tr > 0 and tp > 0):                                  # (an error return of either timer: no row, the rest of cpu_baseline stands)
+            out["rows"].append({"threads": th, "contigs": m, "error": "timer returned reference %r, port %r" % (tr, tp)})
+            continue
         out["rows"].append({"threads": th, "contigs": m, "reference_ms_per_contig": round(1e3 * tr / m, 3), "port_ms_per_contig": round(1e3 * tp / m, 3),
                             "reference_over_port": round(tr / tp, 2)})
     return out

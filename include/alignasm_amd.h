@@ -92,6 +92,9 @@ typedef struct aasm_opts {
                                 *            bit 3: K8 on the d-ary heap queue (cross-check of the default sorted-front / sorted-runs queue);
                                 *            bit 4: K8 with the 40-entry front it takes for batches of more than 3 584 contigs
                                 *            bit 5: workgroups take their work items in grid order (default: XCD by XCD, aasm_gpu.hip)
+                                *            bit 6: every sparse contig in the chain class (aasm_k67_chain: sweep, pre-pass and heaps of a contig
+                                *            beside each other in one workgroup); bit 7: none; both: the contigs of at least the batch's mean size (default: small
+                                *            batches and the long tail of big ones)
                                 *            bits 8-15: 1 = the several-waves heap kernel launched in input order, a block per contig of
                                 *            the batch (default: a block per contig of its class, largest node bound first); 4 / 8 / 16 =
                                 *            that many waves per contig of the class (default: by how many contigs share the chip)
@@ -151,7 +154,8 @@ enum {
     AASM_PH_TOPO,         /* topologically ordered CSR copy for K9        */
     AASM_PH_MISC,
     AASM_PH_CS,           /* K0 aasm_k0_cs_ranges alone (only with cs_text input) */
-    AASM_PH_FINAL         /* K9 per-contig final pick (aasm_k9_sel_final)          */
+    AASM_PH_FINAL,        /* K9 per-contig final pick (aasm_k9_sel_final)          */
+    AASM_PH_CHAIN         /* aasm_k67_chain: K6 sweep + K7 pre-pass + K7 heaps of the chain class, beside each other */
 };
 
 /* Ragged result of a batch: three lists per contig, exactly the three output
@@ -312,9 +316,13 @@ typedef struct aasm_synth_cfg {
     int32_t dense;             /* 0 sparse, 1 dense/high-multiplicity                  */
     int32_t heavy_tail;        /* log-normal contig sizes                              */
     int32_t dup_every;         /* >0: duplicate every n-th record on another chr (ties)*/
-    int32_t reserved;
+    int32_t reserved;          /* bit 0: shuffle records inside a contig; bit 1: no cs tags; bit 2: records only (no match
+                                  ranges, no cs: the form the contig cost model reads)                            */
 } aasm_synth_cfg;
 int  aasm_synth_paf(const aasm_synth_cfg *cfg, aasm_paf **paf);     /* full PAF w/ cs  */
+/* contigs [first, first + count) of that file: a contig has its own PRNG stream, so the range equals the same contigs of the
+   whole (BASELINE configs[3] / [4]: a rank of a contig-sharded run generates only its own block of the one file)            */
+int  aasm_synth_paf_range(const aasm_synth_cfg *cfg, int64_t first, int64_t count, aasm_paf **paf);
 int  aasm_paf_to_text(const aasm_paf *paf, char **text, int64_t *len); /* free()       */
 int  aasm_paf_save(const aasm_paf *paf, const char *path);          /* the same text written to a file (no 2 GiB limit on the caller's side) */
 

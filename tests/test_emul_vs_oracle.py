@@ -61,3 +61,26 @@ def test_multiwave_heap_kernel_is_bit_identical(T, case):
     got = T.emul_solve(hb, K, nsl, heap_waves="all")
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+
+
+@pytest.mark.parametrize("chain", ["none", "half", "all"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[7], CASES[9]], ids=lambda c: "chain_c%dx%d_s%d" % (c[0], c[1], c[2]))
+def test_chain_class_forms(T, case, chain):
+    """The chain class (kb_chain: a contig's sweep, pre-pass and heaps in one workgroup; the default for the sparse contigs of
+    batches this small) against the three-launch form (`none`) and a split of the batch between the two (`half`): outputs and every
+    intermediate.  One lane and the three roles one after the other here - the host logic, the work lists and the count-downs;
+    the GPU tier runs the three waves beside each other."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = T.emul_solve(hb, K, nsl, chain=chain)
+    assert T.diff_outputs(want, got) == []
+    assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+    n_class = int(T.emul_debug("counters", np.int64)[17])
+    sizes = np.diff(hb.arrays["ctg_rec_off"])
+    if chain == "none" or dense:
+        assert n_class == 0
+    elif chain == "all":
+        assert n_class == int((sizes > 1).sum())
+    else:
+        assert n_class == int(((sizes >= -(-int(sizes.sum()) // len(sizes))) & (sizes > 1)).sum())

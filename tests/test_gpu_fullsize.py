@@ -2,10 +2,17 @@
 the per-GPU share of C5 (10 000 dense contigs on 8 GPUs = 1 250 x 1 000, K = 16): size-independent
 properties of the result + exact comparison with the oracle on a sample of contigs (the oracle needs
 seconds per hundred sparse contigs and ~0.1 s per dense one, not per thousands)."""
+import os
+import time
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# the contigs compared with the oracle change from run to run (VERDICT r4: seeds 3 / 5 sampled the same 48 / 20 contigs every time);
+# AASM_TEST_SEED reproduces a run - the seed is printed (pytest shows it with -s or on failure)
+SAMPLE_SEED = int(os.environ.get("AASM_TEST_SEED", "0")) or (int(time.time()) ^ os.getpid()) & 0x7fffffff
 
 
 @pytest.fixture(scope="module")
@@ -80,7 +87,8 @@ def test_c3_idempotent_and_deterministic(T, c3):
 def test_c3_sample_matches_oracle(T, c3):
     paf, db, out, st = c3
     from alignasm_amd._abi import HostBatch
-    rng = np.random.default_rng(3)
+    print("sample seed (AASM_TEST_SEED reproduces it):", SAMPLE_SEED)
+    rng = np.random.default_rng(SAMPLE_SEED)
     starts = sorted(int(x) for x in rng.choice(4990, size=6, replace=False))
     for c0 in starts:                                  # 6 windows of 8 contigs
         hb = HostBatch.from_view_range(paf.view(), c0, c0 + 8)
@@ -88,9 +96,9 @@ def test_c3_sample_matches_oracle(T, c3):
         mo, ao = out["main_off"], out["alt_off"]
         got_main = out["main"][mo[c0]:mo[c0 + 8]]
         got_alt = out["alt"][ao[c0]:ao[c0 + 8]]
-        assert np.array_equal(want["main"], got_main), c0
-        assert np.array_equal(want["alt"], got_alt), c0
-        assert np.array_equal(want["main_off"], mo[c0:c0 + 9] - mo[c0]), c0
+        assert np.array_equal(want["main"], got_main), (SAMPLE_SEED, c0)
+        assert np.array_equal(want["alt"], got_alt), (SAMPLE_SEED, c0)
+        assert np.array_equal(want["main_off"], mo[c0:c0 + 9] - mo[c0]), (SAMPLE_SEED, c0)
 
 
 # ---- C5: the per-GPU share of BASELINE configs[4] (10 000 dense contigs x 1 000 records, K = 16, 8 GPUs)
@@ -122,15 +130,69 @@ def test_c5_share_idempotent(T, c5):
 def test_c5_share_sample_matches_oracle(T, c5):
     paf, db, out, st = c5
     from alignasm_amd._abi import HostBatch
-    rng = np.random.default_rng(5)
+    print("sample seed (AASM_TEST_SEED reproduces it):", SAMPLE_SEED)
+    rng = np.random.default_rng(SAMPLE_SEED + 1)
     for c0 in sorted(int(x) for x in rng.choice(1246, size=5, replace=False)):      # 5 windows of 4 dense contigs
         hb = HostBatch.from_view_range(paf.view(), c0, c0 + 4)
         want = T.oracle_solve(hb, 16)
         mo, ao, po = out["main_off"], out["alt_off"], out["all_path_off"]
-        assert np.array_equal(want["main"], out["main"][mo[c0]:mo[c0 + 4]]), c0
-        assert np.array_equal(want["alt"], out["alt"][ao[c0]:ao[c0 + 4]]), c0
-        assert np.array_equal(want["main_off"], mo[c0:c0 + 5] - mo[c0]), c0
-        assert np.array_equal(want["all_path_off"], po[c0:c0 + 5] - po[c0]), c0
+        assert np.array_equal(want["main"], out["main"][mo[c0]:mo[c0 + 4]]), (SAMPLE_SEED, c0)
+        assert np.array_equal(want["alt"], out["alt"][ao[c0]:ao[c0 + 4]]), (SAMPLE_SEED, c0)
+        assert np.array_equal(want["main_off"], mo[c0:c0 + 5] - mo[c0]), (SAMPLE_SEED, c0)
+        assert np.array_equal(want["all_path_off"], po[c0:c0 + 5] - po[c0]), (SAMPLE_SEED, c0)
+
+
+def test_c5_file_itself_through_the_sharded_path(T, c5):
+    """BASELINE configs[4] as it is defined: the ONE 10 000-contig dense file (10 M records, K = 16), cut by aasm_partition_contigs(8)
+    and solved by aasm_solve_batch_multi(n_devices = 8) - device ordinals wrapped around the devices of this box, so the eight
+    shards take turns on it (alignasm.cpp:346-361: contigs are independent tasks).  Checked: the cuts are contiguous, cover the
+    file and balance the cost model within 3 %; chain properties of the whole result; shard 0 byte for byte against the
+    one-device solve of the same contigs generated on their own (aasm_synth_paf_range: what a rank of `bench.py --workload c5
+    --gpus 8` holds - the `c5` fixture's 1 250-contig share when the cut falls there); windows of a randomly chosen shard
+    against the oracle."""
+    from alignasm_amd import shard
+    from alignasm_amd._abi import HostBatch
+    api = T.api()
+    NC = 10000
+    whole = api.Paf.synth(NC, 1000, 31, dense=True, no_cs=True)
+    cuts = shard.partition_contigs(whole, 8)
+    assert cuts[0] == 0 and cuts[-1] == NC and len(cuts) == 9 and all(b > a for a, b in zip(cuts, cuts[1:]))
+    ro = api.Paf.synth(NC, 1000, 31, dense=True, records_only=True)
+    assert shard.partition_contigs(ro, 8) == cuts                     # what a rank cuts from (no ranges) gives the same blocks
+    ro.close()
+    cost = shard.contig_costs(whole)
+    loads = np.array([cost[a:b].sum() for a, b in zip(cuts, cuts[1:])])
+    assert loads.max() <= 1.03 * loads.mean(), loads
+    assert max(b - a for a, b in zip(cuts, cuts[1:])) <= 1400
+    got = api.solve_batch(whole, max_paths=16, n_devices=8, wrap_devices=True)
+    assert got["n_contigs"] == NC
+    _chain_properties(whole, got, got["stats"], NC)
+    assert got["stats"]["n_edges"] > 40 * got["stats"]["n_vertices"] / 3
+    # shard 0 = the contigs a rank generates for itself, solved on one device
+    n0 = cuts[1]
+    mine = api.Paf.synth(NC, 1000, 31, dense=True, no_cs=True, first=0, count=n0)
+    if n0 == 1250:
+        paf5, db5, out5, st5 = c5                                     # ... which IS the per-GPU share the other C5 tests solve
+        one = out5
+    else:
+        one = api.solve_batch(mine, max_paths=16)
+    mo, ao, po, eo = got["main_off"], got["alt_off"], got["all_path_off"], got["all_elem_off"]
+    assert np.array_equal(one["main"], got["main"][:mo[n0]]) and np.array_equal(one["main_off"], mo[:n0 + 1])
+    assert np.array_equal(one["alt"], got["alt"][:ao[n0]]) and np.array_equal(one["alt_off"], ao[:n0 + 1])
+    assert np.array_equal(one["all"], got["all"][:eo[po[n0]]]) and np.array_equal(one["all_path_off"], po[:n0 + 1])
+    mine.close()
+    # windows of one of the other shards against the oracle
+    print("sample seed (AASM_TEST_SEED reproduces it):", SAMPLE_SEED)
+    rng = np.random.default_rng(SAMPLE_SEED + 2)
+    sh = int(rng.integers(1, 8))
+    for c0 in sorted(int(x) for x in rng.choice(np.arange(cuts[sh], cuts[sh + 1] - 3), size=4, replace=False)):
+        hb = HostBatch.from_view_range(whole.view(), c0, c0 + 3)
+        want = T.oracle_solve(hb, 16)
+        assert np.array_equal(want["main"], got["main"][mo[c0]:mo[c0 + 3]]), (SAMPLE_SEED, sh, c0)
+        assert np.array_equal(want["alt"], got["alt"][ao[c0]:ao[c0 + 3]]), (SAMPLE_SEED, sh, c0)
+        assert np.array_equal(want["all"], got["all"][eo[po[c0]]:eo[po[c0 + 3]]]), (SAMPLE_SEED, sh, c0)
+        assert np.array_equal(want["main_off"], mo[c0:c0 + 4] - mo[c0]), (SAMPLE_SEED, sh, c0)
+    whole.close()
 
 
 def test_two_devices_match_oracle(T):
@@ -222,7 +284,8 @@ def test_c3_variants_at_full_size(T, variant):
     else:                                                            # duplicates: two records may share a query interval, the chain is non-decreasing
         assert (out["status"] == 0).all() and st["n_internal_errors"] == 0
     sizes = np.diff(paf.batch().arrays["ctg_rec_off"])
-    rng = np.random.default_rng(11)
+    print("sample seed (AASM_TEST_SEED reproduces it):", SAMPLE_SEED)
+    rng = np.random.default_rng(SAMPLE_SEED + 3)
     pick = set(int(c) for c in np.argsort(-sizes)[:2]) | set(int(c) for c in rng.choice(5000, size=24, replace=False))
     if variant == "heavy_tail":
         assert sizes.max() > 5000 and sizes.min() <= 20

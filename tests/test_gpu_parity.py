@@ -53,6 +53,55 @@ def test_hip_intermediates_match_oracle(T, case):
     res.close(); db.close()
 
 
+# ---- the chain class (aasm_k67_chain: sweep, pre-pass and heaps of a contig beside each other).  By default it takes every sparse
+# contig of a batch of <= 1 280 contigs - i.e. every sparse case above - and the long tail of bigger ones; here the other forms
+@pytest.mark.parametrize("chain", ["none", "half", "all"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9], CASES[11], CASES[14], CASES[16]], ids=_id)
+def test_chain_class_forms_match_oracle(T, case, chain):
+    """none: the three launches (K6 sweep, K7 pre-pass, K7 heaps) for every contig; half: the contigs of at least the mean size in
+    the class, the others in the three launches, both at the same time; all: the class for every sparse contig."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, chain=chain)
+    assert T.diff_outputs(want, got) == []
+
+
+@pytest.mark.parametrize("chain", ["none", "half", "all"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[5], CASES[8], CASES[9]], ids=_id)
+def test_chain_class_forms_leave_the_same_intermediates(T, case, chain):
+    """... and every intermediate (both sweeps' orders, d / best, every heap node and root in the reference's allocation order,
+    the K distances) equals the oracle's whichever form built it."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    db = api.DeviceBatch(hb)
+    res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, chain=chain)
+    assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+    res.close(); db.close()
+
+
+def test_chain_class_beyond_one_residency_round_and_as_the_long_tail(T):
+    """More contigs of the class than the chip holds at once (a second round of workgroups starts as the first ones end), and
+    the default rule on a big batch: only the contigs of >= 4x the mean and >= 2 048 records form the class."""
+    api = T.api()
+    hb = T.synth(3000, 30, 5, dup_every=6)
+    want = T.oracle_solve(hb, 4)
+    assert T.diff_outputs(want, api.solve_batch(hb, max_paths=4, chain="all")) == []
+    hb = T.synth(1400, 300, 9, heavy_tail=True)                      # 420 k records, the longest contigs ~2 400: the default rule picks a handful
+    sizes = np.diff(hb.arrays["ctg_rec_off"])
+    assert 0 < (sizes >= max(2048, 4 * 300)).sum() < 40
+    want = T.oracle_solve(hb, 4)
+    db = api.DeviceBatch(hb)
+    res = db.solve(max_paths=4, keep_debug=True)
+    n_class = int(res.debug("counters", np.int64)[17])
+    got = res.fetch(); got["stats"] = res.stats()
+    res.close(); db.close()
+    assert n_class == int((sizes >= max(2048, 4 * 300)).sum())
+    assert T.diff_outputs(want, got) == []
+
+
 def test_repeat_solve_is_deterministic(T):
     api = T.api()
     hb = T.synth(50, 200, 77, dup_every=5, shuffle=True)

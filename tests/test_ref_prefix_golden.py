@@ -54,15 +54,17 @@ def test_kernel_bodies_match_recorded_reference_prefix(T, V):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("heap_waves", ["auto", "all", "none"])
-def test_hip_intermediates_match_recorded_reference_prefix(T, V, heap_waves):
-    """The HIP path's intermediates on the card against what the reference's own statements computed."""
+@pytest.mark.parametrize("heap_waves,chain", [("auto", "auto"), ("all", "auto"), ("none", "auto"), ("auto", "none"), ("auto", "half")])
+def test_hip_intermediates_match_recorded_reference_prefix(T, V, heap_waves, chain):
+    """The HIP path's intermediates on the card against what the reference's own statements computed - with either K7 kernel
+    forced, and with the sparse contigs in the chain class (aasm_k67_chain; the default for batches this small), in the three
+    launches, or split between the two."""
     api = T.api()
     for tag in V.tags:
         hb, nsl, full = V.batch(tag)
         db = api.DeviceBatch(hb)
         for K in ((10000, 4) if full else (64, 1)):
-            res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves=heap_waves)
+            res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, heap_waves=heap_waves, chain=chain)
             bad = T.diff_intermediates(hb, res.debug, K, nsl, expect=lambda c: V.contig(tag, c))
             res.close()
             assert bad == [], (tag, K, bad[:6])

@@ -136,3 +136,29 @@ def test_bench_without_launcher_starts_its_own_ranks():
     if alignasm_amd.device_count() < 1:
         assert r.returncode != 0
         assert r.stderr.count("no CPU fallback") >= 2, r.stderr[-1500:]
+
+
+def test_a_contig_range_of_the_synthetic_file_equals_the_same_contigs_of_the_whole(T):
+    """aasm_synth_paf_range: a rank of a sharded run (bench.py --workload c5 --gpus N) generates only ITS block of the one file -
+    every array of the block equals the slice of the whole file, for every generator option; the records-only form gives the
+    same contig costs and therefore the same cuts as the whole file."""
+    import alignasm_amd as A
+    from alignasm_amd import shard
+    from alignasm_amd._abi import HostBatch
+    for kw in ({}, {"dense": True}, {"heavy_tail": True, "dup_every": 4, "shuffle": True}):
+        whole = A.Paf.synth(30, 50, 19, **kw)
+        for first, count in ((0, 30), (0, 7), (7, 12), (29, 1)):
+            part = A.Paf.synth(30, 50, 19, first=first, count=count, **kw)
+            a, b = HostBatch.from_view_range(whole.view(), first, first + count).arrays, part.batch().arrays
+            assert sorted(a) == sorted(b)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (kw, first, count, k)
+            assert part.to_text() == b"".join(whole.to_text().splitlines(keepends=True)[int(whole.batch().arrays["ctg_rec_off"][first]):int(whole.batch().arrays["ctg_rec_off"][first + count])])
+            part.close()
+        ro = A.Paf.synth(30, 50, 19, records_only=True, **kw)
+        assert int(ro.view().n_ranges) == 0
+        assert np.array_equal(shard.contig_costs(ro), shard.contig_costs(whole))
+        assert shard.partition_contigs(ro, 8) == shard.partition_contigs(whole, 8)
+        ro.close(); whole.close()
+    with pytest.raises(A.AlignasmError):
+        A.Paf.synth(30, 50, 19, first=25, count=6)
