@@ -358,7 +358,9 @@ __global__ void __launch_bounds__(SCAN_TPB) aasm_scan_chain(const T *in, int64_t
     int64_t wave_off = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_TPB / 64; i++) { const int64_t t = sh_wave[i]; if (i < wv) wave_off += t; total += t; }
-    if (wv == 0) {                                                   // the first wave publishes and looks back
+    // (a ticket beyond the last tile - the counter was left dirty by an aborted launch - has no elements and no slot among the
+    // words the last tile clears: it publishes nothing and waits for nobody)
+    if (wv == 0 && tile < nt) {                                      // the first wave publishes and looks back
         int64_t prefix = 0;
         if (tile > 0) {
             if (lane == 0) __hip_atomic_store(&words[tile], (SCAN_AGG << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -586,6 +588,7 @@ struct GpuBackend {
     // only extends it), and whatever touches the stream next issues the list first - as ONE launch (aasm_multi_fill), or a plain
     // memset when it is a single span.  A step of the pipeline had 19 fillBufferAligned dispatches.
     FillSegs fs_;
+    bool fs_fresh_[FILL_MAX] = {false};                              // span i is made of WHOLE fresh allocations only (may be extended over the allocator's padding)
     int n_fs = 0;
     void flush_zero() {
         if (n_fs == 0) return;
@@ -608,14 +611,17 @@ struct GpuBackend {
         if (!p || n == 0 || fail) return;
         char *c = (char *)p;
         const uint32_t vv = (uint32_t)(v & 0xff) * 0x01010101u;
-        if (fresh && n_fs > 0 && fs_.v[n_fs - 1] == vv) {           // a WHOLE fresh allocation right behind the last span (the gap is the
-            char *hi = (char *)fs_.p[n_fs - 1] + fs_.n[n_fs - 1];   // allocator's alignment padding: nobody's data): one longer span
-            if (c >= hi && (size_t)(c - hi) <= 256) { fs_.n[n_fs - 1] = (uint64_t)(c + n - (char *)fs_.p[n_fs - 1]); return; }
-        }
         bool overlap = false;                                        // spans of one launch are written concurrently: an overlapping request waits for the list
         for (int i = 0; i < n_fs; i++) overlap |= c < (char *)fs_.p[i] + fs_.n[i] && (char *)fs_.p[i] < c + n;
+        // A WHOLE fresh allocation right behind the last span - itself made of whole fresh allocations, so that the gap between the
+        // two is nothing but the allocator's alignment padding, nobody's data - becomes one longer span.  (A partial fill as the last
+        // span - zero(counters + CNT_POOL, 8) - must never be stretched over its neighbours' live bytes.)
+        if (fresh && !overlap && n_fs > 0 && fs_fresh_[n_fs - 1] && fs_.v[n_fs - 1] == vv) {
+            char *hi = (char *)fs_.p[n_fs - 1] + fs_.n[n_fs - 1];
+            if (c >= hi && (size_t)(c - hi) <= 256) { fs_.n[n_fs - 1] = (uint64_t)(c + n - (char *)fs_.p[n_fs - 1]); return; }
+        }
         if (overlap || n_fs == FILL_MAX || n >= ((size_t)4000 << 20) * 64) flush_zero();   // (a span's block count must fit 32 bits)
-        fs_.p[n_fs] = p; fs_.n[n_fs] = n; fs_.v[n_fs] = vv; n_fs++;
+        fs_.p[n_fs] = p; fs_.n[n_fs] = n; fs_.v[n_fs] = vv; fs_fresh_[n_fs] = fresh; n_fs++;
     }
     void zero_alloc(void *p, size_t n) { add_fill(p, 0, n, true); }  // a WHOLE fresh allocation
     void zero(void *p, size_t n) { add_fill(p, 0, n, false); }
@@ -753,9 +759,10 @@ static int solve_on_device(DevCtx &cx, const aasm_batch_in &dev_in, const aasm_o
         g_bad_record = res->sz.bad_record;
         set_last_error("malformed cs:Z tag in record " + std::to_string(res->sz.bad_record) + " of the batch");
     }
-    if (rc == AASM_E_HIP || rc == AASM_E_NOMEM) {
+    if (rc == AASM_E_HIP || rc == AASM_E_NOMEM || be->failed() || cx.pinned[SCAN_STALL_SLOT] != 0) {
         // a scan that did not run to its end (failed launch, aborted kernel) leaves tickets / tile words behind, and the single-pass
         // scan of the NEXT solve on this context relies on finding them zero: wipe both scratch buffers before anybody else comes
+        // (whatever code the solve itself ends with: a raised stall flag left behind would fail every later solve on the context)
         (void)hipDeviceSynchronize();
         if (cx.d_scratch) (void)hipMemset(cx.d_scratch, 0, cx.d_scratch_cap * 8);
         if (cx.d_scratch2) (void)hipMemset(cx.d_scratch2, 0, cx.d_scratch2_cap * 8);
@@ -1050,8 +1057,15 @@ int aasm_sssp_dial(int64_t n_graphs, const int64_t *g_voff, const int64_t *rowpt
     if (rc != AASM_OK) return rc;
     hipSetDevice(device);
     const int nb = lim + 1;
-    const int64_t VT = g_voff[n_graphs], ET = rowptr[VT];
-    if (VT <= 0 || g_voff[0] != 0 || rowptr[0] != 0) { set_last_error("inconsistent graph offsets"); return AASM_E_INVAL; }
+    // the offsets first, before anything is read THROUGH them: graph starts strictly increasing from 0, row pointers non-decreasing from 0
+    if (g_voff[0] != 0) { set_last_error("inconsistent graph offsets"); return AASM_E_INVAL; }
+    for (int64_t g = 0; g < n_graphs; g++)
+        if (g_voff[g + 1] <= g_voff[g]) { set_last_error("graph " + std::to_string(g) + ": empty, or graph offsets not increasing"); return AASM_E_INVAL; }
+    const int64_t VT = g_voff[n_graphs];
+    if (VT <= 0 || rowptr[0] != 0) { set_last_error("inconsistent graph offsets"); return AASM_E_INVAL; }
+    for (int64_t v = 0; v < VT; v++)
+        if (rowptr[v + 1] < rowptr[v]) { set_last_error("row pointers decrease at vertex " + std::to_string(v)); return AASM_E_INVAL; }
+    const int64_t ET = rowptr[VT];
     std::vector<int64_t> soff((size_t)n_graphs + 1, 0);
     for (int64_t g = 0; g < n_graphs; g++) {
         const int64_t v0 = g_voff[g], v1 = g_voff[g + 1];

@@ -592,7 +592,8 @@ static int parse_text_mt(const char *text, int64_t len, aasm_paf &paf, int flags
 //      without such a row contributes its first row of maximal positive ratio instead (and a piece whose ratios are all
 //      <= 0 a zeroed record, as the reference's value-initialised PafReadData, :243,:314);
 //   4. a joining row carries the qry_total of its contig's last record at the time it was read (:269-274): the contig's
-//      own, unless a zeroed record went in before it.
+//      own, unless a zeroed record is the last one at that moment.  The reference appends a piece's stand-in record only
+//      when the NEXT piece's first row has been read (:305-306 after :269), so that row never sees it.
 struct AltRec {
     int64_t qs = 0, qe = 0, rs = 0, re = 0, qtot = 0, rtot = 0;
     int32_t chr = 0, mat = 0, aln = 0, row = 0;
@@ -682,23 +683,30 @@ static int merge_alt_text(const char *text, int64_t len, double baseline, aasm_p
     std::vector<std::vector<AltRec>> added(C);
     std::vector<int64_t> qtot_now(C);                                               // qry_total of each contig's last record so far
     for (int64_t c = 0; c < C; c++) qtot_now[c] = paf.qry_total[paf.ctg_rec_off[c + 1] - 1];
+    // qtot_now follows the reference's `paf_data[...].back().qry_total_length` (:269-274) through the same events in the same
+    // order: a row reads it when the row is read; a row above the baseline goes in at once (and becomes the last record); a piece's
+    // stand-in - its best row, or the zeroed record - goes in only when the NEXT piece's first row has been read (:305-306).
+    int32_t pend_c = -1;                                                            // contig and qry_total of the stand-in that has not gone in yet
+    int64_t pend_qtot = 0;
     for (size_t g0 = 0, g1; g0 < rows.size(); g0 = g1) {
         for (g1 = g0 + 1; g1 < rows.size() && rows[g1].shift == rows[g0].shift && rows[g1].piece == rows[g0].piece;) g1++;
         const int32_t c = rows[g0].ctg;
         size_t over = 0, top = g1;                                                  // rows above the baseline; first row of the largest positive ratio
         for (size_t i = g0; i < g1; i++) {
             rows[i].qtot = qtot_now[c];
-            if (rows[i].ratio > baseline) over++;
+            if (i == g0 && pend_c >= 0) { qtot_now[pend_c] = pend_qtot; pend_c = -1; }
+            if (rows[i].ratio > baseline) { over++; qtot_now[c] = rows[i].qtot; }
             if (rows[i].ratio > (top == g1 ? 0.0 : rows[top].ratio)) top = i;
         }
         if (over) {
             for (size_t i = g0; i < g1; i++)
                 if (rows[i].ratio > baseline) added[c].push_back(std::move(rows[i]));
         } else if (top != g1) {
+            pend_c = c; pend_qtot = rows[top].qtot;
             added[c].push_back(std::move(rows[top]));
         } else {
             added[c].emplace_back();                                                // every ratio <= 0: the zeroed record
-            qtot_now[c] = 0;
+            pend_c = c; pend_qtot = 0;
         }
     }
     // rebuild the flat arrays: every contig = its main records followed by the appended ones

@@ -102,6 +102,8 @@ typedef struct aasm_opts {
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);
                                 *     bit 1: aasm_solve_batch_multi wraps device ordinals around the devices that exist;
+                                *     bit 2: the next scan finds its ticket counter as an aborted launch would leave it (its look-back
+                                *            must give up after 10 s with AASM_E_HIP, and the next solve on the context must succeed);
                                 *     bits 8-15: d + 1 = the sort replay of duplicate-key contigs takes its heap sort
                                 *            fallback after d partition levels instead of 2 lg N                          */
 } aasm_opts;

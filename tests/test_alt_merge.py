@@ -32,8 +32,8 @@ def _expected(main, alt_text, ctg_names, chr_names, baseline):
     tar_flag, tar_ratio, best = False, 0.0, None
 
     def flush():
-        if grp is not None and not tar_flag:
-            added[paf_map.get(grp[0], 0)].append(best)
+        if grp is not None and not tar_flag:                 # (no row with a positive ratio: the value-initialised PafReadData, :240,:314)
+            added[paf_map.get(grp[0], 0)].append(best if best is not None else dict(qs=0, qe=0, rs=0, re=0, qtot=0, chr=0, fwd=0, mq=0, row=0))
     for row, line in enumerate(alt_text.decode().splitlines()):
         f = line.split("\t")
         name, rest = f[0].split(":", 1)
@@ -139,3 +139,51 @@ def test_alt_merge_with_device_side_ranges(T):
     assert T.diff_outputs(want, got) == []
     n = int(hv.n_ranges)
     assert np.array_equal(T.k0_ranges(T.emul_debug)["rql_w"][:n], host.batch().arrays["rng_qry_l"])
+
+
+def test_zeroed_stand_in_is_seen_one_row_late(T):
+    """A piece whose rows all have aln_len 0 contributes the reference's value-initialised record (alignasm.cpp:240,:248-251), and
+    it goes in when the NEXT piece's first row has already read its contig's last record (:269 before :305-306): on the same contig
+    that first row keeps the old qry_total, the rows after it read 0; on another contig nothing is late."""
+    api = T.api()
+    paf = api.Paf.synth(2, 6, 11)
+    text = paf.to_text()
+    lines = text.decode().splitlines()
+    names = []
+    for line in lines:
+        if not names or names[-1] != line.split("\t")[0]:
+            names.append(line.split("\t")[0])
+    chr_first = []
+    for line in lines:
+        if line.split("\t")[5] not in chr_first:
+            chr_first.append(line.split("\t")[5])
+
+    def row(src, name, start, kind):                 # kind: "zero" (aln_len 0), "low" (positive ratio under the baseline), "high" (above it)
+        f = lines[src].split("\t")
+        f[1] = str(int(f[10]) * (4 if kind == "low" else 1) + 10)
+        f[0] = f"{name}:{start}-{start + int(f[1]) - 1}"
+        if kind == "zero":
+            f[10] = "0"
+        return "\t".join(f)
+    alt = "\n".join([row(0, names[0], 101, "zero"), row(1, names[0], 101, "zero"),      # piece A on contig 0: no positive ratio -> zeroed record, in at B's first row
+                     row(2, names[0], 5001, "low"), row(3, names[0], 5001, "low"),      # piece B, same contig: first row reads the old qry_total, second row the zeroed record's 0
+                     row(4, names[0], 7001, "high"), row(5, names[0], 7001, "low"),     # piece C: its first row goes in at once, behind B's stand-in
+                     row(6, names[1], 301, "zero"),                                     # piece D on contig 1: zeroed record ...
+                     row(7, names[0], 9001, "low"),                                     # piece E on contig 0
+                     row(9, names[1], 701, "high"), row(10, names[1], 701, "high")]) + "\n"   # piece F on contig 1: D's stand-in went in at E's first row
+    again = api.Paf.parse(text)
+    main = {k: v.copy() for k, v in again.batch().arrays.items()}
+    exp = _expected(main, alt.encode(), names, chr_first, 0.5)
+    again.merge_alt(alt.encode(), 0.5)
+    got = again.batch().arrays
+    off_m, off_g = main["ctg_rec_off"], got["ctg_rec_off"]
+    q0 = int(main["qry_total"][off_m[1] - 1])
+    assert len(exp[0]) == 4 and len(exp[1]) == 3 and [r["qtot"] for r in exp[1]] == [0, 0, 0]
+    assert exp[0][0]["qtot"] == 0 and exp[0][0]["qs"] == 0 and {r["qtot"] for r in exp[0][1:]} <= {0, q0} and any(r["qtot"] == 0 for r in exp[0][1:])
+    for c in range(2):
+        nm = off_m[c + 1] - off_m[c]
+        assert off_g[c + 1] - off_g[c] == nm + len(exp[c]), c
+        for t, rec in enumerate(exp[c]):
+            g = off_g[c] + nm + t
+            assert (got["qry_str"][g], got["qry_end"][g], got["ref_str"][g], got["ref_end"][g], got["qry_total"][g], got["ref_chr"][g], got["aln_fwd"][g], got["map_qul"][g]) == \
+                   (rec["qs"], rec["qe"], rec["rs"], rec["re"], rec["qtot"], rec["chr"], rec["fwd"], rec["mq"]), (c, t)
