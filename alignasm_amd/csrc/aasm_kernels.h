@@ -1858,12 +1858,21 @@ AASM_DEV void sidetrack_vertex(const WS &w, int64_t gv) {
     }
     w.st_n[gv] = n_ins;
     if (bad) w.status[c] = -6;                                       // must not happen (see above)
-    I4 t;                                                            // best[] is final here (K6 done)
-    t.x = bu;
+}
+// the next four vertices along best[] (final once K6 is done): the 4-hop jump record of a vertex
+AASM_DEV void tnx_vertex(const WS &w, int64_t gv) {
+    const int64_t vb = w.voff[w.v_ctg[gv]];
+    I4 t;
+    t.x = w.sp_best[gv];
     t.y = t.x >= 0 ? w.sp_best[vb + t.x] : -1;
     t.z = t.y >= 0 ? w.sp_best[vb + t.y] : -1;
     t.w = t.z >= 0 ? w.sp_best[vb + t.z] : -1;
     w.tnx[gv] = t;
+}
+AASM_DEV void kb_tnx(const KCtx &k, const WS &w) {                  // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;       // (the chain class: its prep wave, kb_chain)
+    tnx_vertex(w, gv);
 }
 AASM_DEV void kb_sidetrack(const KCtx &k, const WS &w) {
     const int64_t gv = k.bid * k.nthreads + k.tid;
@@ -1930,24 +1939,19 @@ AASM_DEV void kb_sidetrack_w(const KCtx &k, const WS &w) {          // wave per 
         }
         wave_lds_sync();
     }
-    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) {
-        w.st_n[row0 + t] = L->cnt[t];
-        const int64_t vb = L->vb[t];
-        I4 j;                                                        // the next four vertices along best[] (as kb_sidetrack)
-        j.x = L->bu[t];
-        j.y = j.x >= 0 ? w.sp_best[vb + j.x] : -1;
-        j.z = j.y >= 0 ? w.sp_best[vb + j.y] : -1;
-        j.w = j.z >= 0 ? w.sp_best[vb + j.z] : -1;
-        w.tnx[row0 + t] = j;
-    }
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) w.st_n[row0 + t] = L->cnt[t];
     if (bad) w.status[w.v_ctg[row0 + bad_row]] = -6;                 // must not happen (see kb_sidetrack)
 }
 // K7 pre-pass 2, thread per vertex u: what the heap wave reads per vertex, 32 bytes:
 //   vhdr  = {so, #keys, #children, first child}          so = start of u's keys, relative to the contig's first edge
-//   vhdr2 = {child-list start (2 words), so(first child), #keys(first child)}
-// and per child-list slot cinfo = {child, so(child), #keys(child), -}.  A parent hands every child the place
+//   vhdr2 = {child-list start (2 words), so(first child), row length of the first child}
+// and per child-list slot cinfo = {child, so(child), row length(child), -}.  A parent hands every child the place
 // of its keys, so the wave fetches a vertex's header AND keys while it still works on the vertex before it
-// (the queue front; in a path-like tree the first child of the vertex at hand).
+// (the queue front; in a path-like tree the first child of the vertex at hand).  What a parent knows of a child is the
+// LENGTH OF ITS ROW, an upper bound of its key count (the keys sit compacted at the front of the row): the count itself is
+// in the child's own header, which arrives with the keys.  So a header depends on no other vertex's pre-pass, and the child
+// list, the keys and the header of a vertex are one thread's work in one launch (kb_k7_prep; round 5 - the counts used to
+// come from st_n[child], a second launch).
 // (returns the two header quads: kb_chain's prep wave publishes them only after everything else the vertex's step reads is in memory)
 AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b) {
     const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
@@ -1955,29 +1959,48 @@ AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b) {
     const int32_t fc = (c1 > c0) ? w.cval[c0] : -1;
     a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;
     b.x = (int32_t)(uint32_t)(uint64_t)c0; b.y = (int32_t)((uint64_t)c0 >> 32);
-    b.z = fc >= 0 ? (int32_t)(w.rowptr[vb + fc] - e_base) : 0; b.w = fc >= 0 ? w.st_n[vb + fc] : 0;
-    {   // sixteen tree hops = four 4-hop records chained (kb_sidetrack wrote those; -1 past dest)
-        I4 neg; neg.x = neg.y = neg.z = neg.w = -1;
-        I4 *o = (I4 *)(w.tnx16 + 16 * gv);
-        I4 j = w.tnx[gv];
-        o[0] = j;
-        AASM_UNROLL
-        for (int t = 1; t < 4; t++) { const int32_t nx = j.w; j = neg; if (nx >= 0) j = w.tnx[vb + nx]; o[t] = j; }   // (a select between two structs would go through scratch memory)
-    }
-    for (int64_t t0 = c0; t0 < c1; t0 += 4) {                        // four children per round (their two gathers each issued together)
-        int32_t ch[4], sn[4];
-        int64_t rp[4];
+    b.z = 0; b.w = 0;
+    if (fc >= 0) { const int64_t rp0 = w.rowptr[vb + fc]; b.z = (int32_t)(rp0 - e_base); b.w = (int32_t)(w.rowptr[vb + fc + 1] - rp0); }
+    for (int64_t t0 = c0; t0 < c1; t0 += 4) {                        // four children per round (their gathers issued together)
+        int32_t ch[4];
+        int64_t rp[4], rq[4];
         AASM_UNROLL
         for (int i = 0; i < 4; i++) ch[i] = (t0 + i < c1) ? w.cval[t0 + i] : -1;
         AASM_UNROLL
-        for (int i = 0; i < 4; i++) { rp[i] = 0; sn[i] = 0; if (ch[i] >= 0) { rp[i] = w.rowptr[vb + ch[i]]; sn[i] = w.st_n[vb + ch[i]]; } }
+        for (int i = 0; i < 4; i++) { rp[i] = 0; rq[i] = 0; if (ch[i] >= 0) { rp[i] = w.rowptr[vb + ch[i]]; rq[i] = w.rowptr[vb + ch[i] + 1]; } }
         AASM_UNROLL
         for (int i = 0; i < 4; i++) {
             if (ch[i] < 0) continue;
-            I4 ci; ci.x = ch[i]; ci.y = (int32_t)(rp[i] - e_base); ci.z = sn[i]; ci.w = 0;
+            I4 ci; ci.x = ch[i]; ci.y = (int32_t)(rp[i] - e_base); ci.z = (int32_t)(rq[i] - rp[i]); ci.w = 0;
             w.cinfo[t0 + i] = ci;
         }
     }
+}
+// sixteen tree hops = four 4-hop records chained (kb_sidetrack wrote those; -1 past dest): what K9's recovery reads, one 64-byte
+// record per sixteen tree edges.  It needs the 4-hop records of OTHER vertices, hence a launch of its own (side stream: only K9 waits for it)
+AASM_DEV void tnx16_vertex(const WS &w, int64_t gv) {
+    const int64_t vb = w.voff[w.v_ctg[gv]];
+    I4 neg; neg.x = neg.y = neg.z = neg.w = -1;
+    I4 *o = (I4 *)(w.tnx16 + 16 * gv);
+    I4 j = w.tnx[gv];
+    o[0] = j;
+    AASM_UNROLL
+    for (int t = 1; t < 4; t++) { const int32_t nx = j.w; j = neg; if (nx >= 0) j = w.tnx[vb + nx]; o[t] = j; }   // (a select between two structs would go through scratch memory)
+}
+AASM_DEV void kb_tnx16(const KCtx &k, const WS &w) {                // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;       // (the chain class: its prep wave, kb_chain)
+    tnx16_vertex(w, gv);
+}
+// child list + sidetrack keys + header of a vertex, one thread, one launch (sparse batches)
+AASM_DEV void kb_k7_prep(const KCtx &k, const WS &w) {              // thread per vertex
+    const int64_t gv = k.bid * k.nthreads + k.tid;
+    if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;
+    children_vertex(w, gv);
+    sidetrack_vertex(w, gv);
+    I4 a, b;
+    heap_hdr_vertex(w, gv, a, b);                                    // (reads back this thread's own child list and key count)
+    w.vhdr[gv] = a; w.vhdr2[gv] = b;
 }
 AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
     const int64_t gv = k.bid * k.nthreads + k.tid;
@@ -2316,17 +2339,18 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
     wave_lds_sync();
     int32_t pend_u = -1, pend_root = -1;                             // finished root of the previous vertex (lane 0), stored at the start of the next step
     int32_t staged = -1;                                             // the vertex whose keys are parked in L->stage and whose header words are in c_* (-1: none)
-    int32_t c_nch = 0, c_fc = -1, c_sofc = 0, c_nfc = 0, c_c0lo = 0, c_c0hi = 0;   // {#children, first child, its key offset / #keys, child-list start}
+    int32_t c_nch = 0, c_fc = -1, c_sofc = 0, c_nfc = 0, c_c0lo = 0, c_c0hi = 0, c_n = 0;   // {#children, first child, its key offset / row length, child-list start}, the staged vertex's own #keys
     while (!hs.ovf && !chain_lost) {
         HeapStage *St = &L->stage;
         if (staged != u) {                                           // not staged (the root, a spilled queue entry; CHAIN: a header that was not there yet when it was prefetched): fetch now
             if (CHAIN && !chain_wait_hdr(S, vh, vh2, u)) { chain_lost = true; break; }
             const I4 ha = vh[u], hb = vh2[u];
-            if (CHAIN) { so = uni(ha.x); n = uni(ha.y); }            // (a spilled entry's pop could not read them yet)
-            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; St->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
+            so = uni(ha.x); c_n = uni(ha.y);                         // (what the parent handed over is the row's start and its LENGTH)
+            FOR_LANE(t, (c_n < HEAP_KMAX ? c_n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; St->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
             c_nch = uni(ha.z); c_fc = uni(ha.w); c_sofc = uni(hb.z); c_nfc = uni(hb.w); c_c0lo = uni(hb.x); c_c0hi = uni(hb.y);
             wave_lds_sync();
         }
+        n = c_n;                                                     // the vertex's key count: from its own header (staged with its keys, or just read)
         const int32_t nch = c_nch, fc = c_fc, so_fc = c_sofc, n_fc = c_nfc, c0lo = c_c0lo, c0hi = c_c0hi;
         KPROF_STAMP(0);                                              // context of this vertex
         // ---- every global store of this step, ahead of its loads: the root of the vertex before, the staged nodes
@@ -2365,8 +2389,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
         bool v2_ok = v2 >= 0;
         if (CHAIN && v2_ok && (uni(pa.x) == -1 || uni(pb.y) == -1)) v2_ok = false;   // its header was not written yet: the step that takes it waits (staged != u)
         if (v2_ok) {                                                 // (header words: straight into scalars - the loads are back by now)
-            c_nch = uni(pa.z); c_fc = uni(pa.w); c_sofc = uni(pb.z); c_nfc = uni(pb.w); c_c0lo = uni(pb.x); c_c0hi = uni(pb.y);
-            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) St->key[t] = pk.at(t);
+            c_nch = uni(pa.z); c_fc = uni(pa.w); c_sofc = uni(pb.z); c_nfc = uni(pb.w); c_c0lo = uni(pb.x); c_c0hi = uni(pb.y); c_n = uni(pa.y);
+            FOR_LANE(t, (n2 < HEAP_KMAX ? n2 : HEAP_KMAX), k.lane) St->key[t] = pk.at(t);   // (n2 = the row's length: slots past the key count hold nothing anybody reads)
         }
         staged = v2_ok ? v2 : -1;
         // ---- children adopt the heap (:213)
@@ -2468,6 +2492,7 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
             if (k.lane < n1) {
                 v = q[done1 + k.lane];
                 sidetrack_vertex(w, vb + v);
+                tnx_vertex(w, vb + v);
                 r0 = w.rowptr[vb + v]; deg = (int32_t)(w.rowptr[vb + v + 1] - r0);
                 self = w.rptr[vb + v + 1] == w.rptr[vb + v];        // no in-neighbour (src): nothing to wait for
             }
@@ -2514,7 +2539,7 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
             wave_fence();                                            // (the header pass reads the child list back)
             I4 a, b;
             a.x = a.y = a.z = a.w = 0; b = a;
-            if (k.lane < n2) heap_hdr_vertex(w, vb + u, a, b);
+            if (k.lane < n2) { heap_hdr_vertex(w, vb + u, a, b); tnx16_vertex(w, vb + u); }
             wave_fence();                                            // child slots, jump records: in memory before the marker words
             if (k.lane < n2) { w.vhdr2[vb + u] = b; w.vhdr[vb + u] = a; }
             r2_head += n2;

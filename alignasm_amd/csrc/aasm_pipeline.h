@@ -23,8 +23,8 @@ namespace aasm {
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
-    KN_CHILDREN, KN_CHILD_SIDE, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
-    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN
+    KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -53,7 +53,6 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_REV_SWEEP_G: kb_rev_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_FWD_SWEEP_G: kb_fwd_sweep<AASM_SWEEP_G>(k, w); break;
         case KN_CHILDREN: kb_children(k, w); break;
-        case KN_CHILD_SIDE: kb_children(k, w); kb_sidetrack(k, w); break;   // both a thread per vertex, nothing of one feeds the other: one launch
         case KN_HEAP_CAP: kb_heap_cap(k, w); break;
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_SIDETRACK_W: kb_sidetrack_w(k, w); break;
@@ -79,6 +78,9 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SEL_CONVERT: kb_sel_convert(k, w); break;
         case KN_SEL_FINAL: kb_sel_final(k, w); break;
         case KN_CHAIN: kb_chain(k, w); break;
+        case KN_K7_PREP: kb_k7_prep(k, w); break;
+        case KN_TNX: kb_tnx(k, w); break;
+        case KN_TNX16: kb_tnx16(k, w); break;
         default: break;
     }
 }
@@ -309,13 +311,24 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.phase_end(AASM_PH_SPTREE);
 
         // ---- K7 heaps
+        // the jump records of K9's recovery (the next 4 and the next 16 vertices along best[]) need nothing but the tree: they go to the
+        // side stream, which finishes its topological copy about when the reverse sweep ends, and run beside the heap pre-pass
+        be.fork_again();
+        be.use_side(true);
+        be.launch(KN_TNX, cdiv(VT, 256), 256, w);
+        be.launch(KN_TNX16, cdiv(VT, 256), 256, w);
+        be.use_side(false);
         be.phase_begin(AASM_PH_HEAP_PREP);
         if (ET > 6 * VT) {
             be.launch(KN_CHILDREN, cdiv(VT, 256), 256, w);
             be.launch(KN_SIDETRACK_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
-        } else be.launch(KN_CHILD_SIDE, cdiv(VT, 256), 256, w);
-        be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
+            be.launch(KN_HEAP_HDR, cdiv(VT, 256), 256, w);
+        } else be.launch(KN_K7_PREP, cdiv(VT, 256), 256, w);         // child list + keys + header of a vertex: one thread, one launch
         be.phase_end(AASM_PH_HEAP_PREP);
+        // Nothing may START beside the heap kernel: all its workgroups are resident for the whole launch, so whatever share of the CUs a
+        // second queue holds while they are dealt out skews their placement for good (measured: the 0.2 ms jump-record kernel started
+        // beside it cost it 1.8 ms, 4.05 -> 5.8; the forward sweep beside it 0.5-0.9 ms in round 4).  The side stream is done by now.
+        be.join();
         be.phase_begin(AASM_PH_HEAP);
         be.launch(KN_HEAP, C, AASM_WAVE, w);
         // contigs of the wide-tree class (kb_heap skips them): 16, 8 or 4 waves each, by how many of them share the chip's ~8 k wave slots

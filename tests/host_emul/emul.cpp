@@ -69,6 +69,7 @@ struct EmuBackend {
     void fork() {}
     void join() {}
     void use_side(bool) {}
+    void fork_again() {}
     void fork2() {}
     void join2() {}
     void use_side2(bool) {}
