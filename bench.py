@@ -67,6 +67,9 @@ def kernel_bytes(st):
     V, E, H = st["n_vertices"], st["n_edges"], st["n_heap_nodes"]
     dense = E > 6 * V                                               # (the pipeline's own rule: wide SP trees get the several-waves heap kernel)
     return {
+        # the chain class (aasm_k67_chain: sweep + pre-pass + heaps of a contig in one workgroup; small batches and the long tail): the
+        # bytes of the two kernels it stands for.  On a batch where only the tail is in the class the figure is an upper bound
+        "chain": ("aasm_k67_chain", 24 * E + 2 * 40 * V + 24 * E + 40 * V + 24 * H),
         "sptree": ("aasm_k6_rev_sweep", 24 * E + 2 * 40 * V),
         "fwd": ("aasm_k5_fwd_sweep", 24 * E + 2 * 8 * V),
         "heap": ("aasm_k7_heap_mw" if dense else "aasm_k7_heap", 24 * E + 40 * V + 24 * H),
