@@ -438,6 +438,39 @@ __global__ void __launch_bounds__(256) aasm_multi_fill(FillSegs s) {
     }
 }
 
+// ---- short scans: ONE workgroup, no tickets, no look-back --------------------------------------------------------------
+// Seven of a step's thirteen scans run over per-contig or per-conversion counts (5 000 - 11 000 elements on C3): two tiles of the
+// single-pass scan above, which then spends 30 us on its ticket, its look-back across two workgroups and the reset of its words.
+// One workgroup of 1 024 threads walks such an array 4 096 elements at a time instead; up to two arrays of the same length per
+// launch (heap capacities + several-waves capacities, the conversions' two scratch sizes, main + alt output lengths).
+#define SCAN_SMALL_MAX 131072
+__global__ void __launch_bounds__(1024) aasm_scan_small(const int32_t *in_a, int64_t *out_a, const int32_t *in_b, int64_t *out_b, int64_t n) {
+    __shared__ int64_t sh_w[2][16];
+    __shared__ int64_t sh_carry[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 2) sh_carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+        int64_t va[4], vb[4], sa = 0, sb = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { va[i] = (i0 + i < n) ? (int64_t)in_a[i0 + i] : 0; sa += va[i]; vb[i] = (in_b && i0 + i < n) ? (int64_t)in_b[i0 + i] : 0; sb += vb[i]; }
+        const int64_t ia = scan_wave_incl(sa, lane), ib = scan_wave_incl(sb, lane);
+        if (lane == 63) { sh_w[0][wv] = ia; sh_w[1][wv] = ib; }
+        __syncthreads();
+        int64_t oa = sh_carry[0], ob = sh_carry[1], ta = 0, tb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int64_t xa = sh_w[0][i], xb = sh_w[1][i]; if (i < wv) { oa += xa; ob += xb; } ta += xa; tb += xb; }
+        int64_t ra = oa + ia - sa, rb = ob + ib - sb;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { if (i0 + i < n) { out_a[i0 + i] = ra; if (in_b) out_b[i0 + i] = rb; } ra += va[i]; rb += vb[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) { sh_carry[0] += ta; sh_carry[1] += tb; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_a[n] = sh_carry[0]; if (in_b) out_b[n] = sh_carry[1]; }
+}
+
 // ---- scalar read-back: up to eight device words -> the host-mapped pinned words, ONE launch (it was a copyBuffer per word) ----
 struct ScalarSrc { const int64_t *p[8]; };
 __global__ void aasm_read_scalars(ScalarSrc src, int n, int64_t *dst) {
@@ -674,7 +707,22 @@ struct GpuBackend {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) hip_fail("scan launch", e);
     }
-    void scan_i32(const int32_t *in, int64_t n, int64_t *out) { scan_t<int32_t>(in, n, out); }
+    void scan_small(const int32_t *a, int64_t *oa, const int32_t *b, int64_t *ob, int64_t n) {
+        flush_zero();
+        if (fail) return;
+        hipLaunchKernelGGL(aasm_scan_small, dim3(1), dim3(1024), 0, stream, a, oa, b, ob, n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) hip_fail("scan launch", e);
+    }
+    void scan_i32(const int32_t *in, int64_t n, int64_t *out) {
+        if (n > 0 && n <= SCAN_SMALL_MAX && !test_dirty_scan) scan_small(in, out, nullptr, nullptr, n);
+        else scan_t<int32_t>(in, n, out);
+    }
+    // two arrays of the same length: one launch when they are short
+    void scan_i32_pair(const int32_t *a, int64_t *oa, const int32_t *b, int64_t *ob, int64_t n) {
+        if (n > 0 && n <= SCAN_SMALL_MAX && !test_dirty_scan) scan_small(a, oa, b, ob, n);
+        else { scan_t<int32_t>(a, n, oa); scan_t<int32_t>(b, n, ob); }
+    }
     void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { scan_t<uint8_t>(in, n, out); }
     int64_t read_i64(const int64_t *p) { int64_t v = 0; read_i64s({p}, &v); return v; }
     // several scalars, ONE launch and ONE wait: the kernel queues up behind the kernels that produce them and stores into the

@@ -220,8 +220,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_ROW_COUNT, cdiv(VT, 256), 256, w);
         be.scan_i32(w.deg, VT, w.rowptr);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
-        be.scan_i32(w.hcap_cnt, C, w.hoff);
-        be.scan_i32(w.mw_cap, C, w.mw_off);
+        be.scan_i32_pair(w.hcap_cnt, w.hoff, w.mw_cap, w.mw_off, C);
         int64_t et_mv[7];
         be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN}, et_mv);
         const int64_t ET = et_mv[0], MAXV_OVER = et_mv[1];            // (MAXV_OVER: 0, or the largest contig of more than REV_ORD_MAXV vertices)
@@ -394,8 +393,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             AZ(cv_n, int32_t, NCONV, "cv_n"); AZ(cv_err, int32_t, NCONV, "cv_err"); AZ(cv_cov, int64_t, NCONV, "cv_cov"); A(cv_la, int32_t, NCONV, "cv_la");
             CHECK_ALLOC();
             be.launch(KN_SEL_PLANFILL, C, AASM_WAVE, w);
-            be.scan_i32(w.cv_szr, NCONV, w.cv_roff);
-            be.scan_i32(w.cv_szv, NCONV, w.cv_voff);
+            be.scan_i32_pair(w.cv_szr, w.cv_roff, w.cv_szv, w.cv_voff, NCONV);
             int64_t sv[2];
             be.read_i64s({w.cv_roff + NCONV, w.cv_voff + NCONV}, sv);
             SR = sv[0]; SV = sv[1];
@@ -462,8 +460,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
     // ---- output compaction
     be.phase_begin(AASM_PH_GATHER);
-    be.scan_i32(w.main_len, C, w.main_off);
-    be.scan_i32(w.alt_len, C, w.alt_off);
+    be.scan_i32_pair(w.main_len, w.main_off, w.alt_len, w.alt_off, C);
     int64_t nm[2];
     be.read_i64s({w.main_off + C, w.alt_off + C}, nm);
     const int64_t NM = nm[0], NA = nm[1];

@@ -61,6 +61,7 @@ struct EmuBackend {
         }
     }
     void scan_i32(const int32_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
+    void scan_i32_pair(const int32_t *a, int64_t *oa, const int32_t *b, int64_t *ob, int64_t n) { scan_i32(a, n, oa); scan_i32(b, n, ob); }
     void scan_u8(const uint8_t *in, int64_t n, int64_t *out) { int64_t s = 0; for (int64_t i = 0; i < n; i++) { out[i] = s; s += in[i]; } out[n] = s; }
     int64_t read_i64(const int64_t *p) { return *p; }
     void read_i64s(std::initializer_list<const int64_t *> ps, int64_t *out) { int i = 0; for (auto p : ps) out[i++] = *p; }
