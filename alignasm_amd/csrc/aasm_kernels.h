@@ -125,6 +125,7 @@ struct WS {
     // ---- the chain class (kb_chain): contigs whose K6 sweep, K7 pre-pass and K7 heaps run BESIDE each other in one workgroup
     int32_t chain_mode;                  // 0: by batch shape, 1: every sparse one-wave contig, 2: none (tests, probes)
     int32_t chain_all, chain_minN;       // mode 0: every contig of the batch (small batches) / contigs of at least this many records (the long tail)
+    int32_t chain_test;                  // test hooks (opts.reserved[2] bits 3, 4): 1 = the prep wave of contig 0 never publishes dest's header; 2 = ... and never says it is done (the heap wave's patience is 1 s then)
     int32_t *chain_flag, *chain_list;    // per contig: in the class; the contigs of the class, in any order
     int32_t *pend;                       // per vertex: in-neighbours whose keys are not written yet (the prep wave counts them down)
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
@@ -2279,7 +2280,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
 struct KProfNone { int64_t acc[8]; };   // (acc: only touched by the -DAASM_KPROF diagnostic build)
 // kb_chain's heap wave: the header of vertex u is in memory (the prep wave writes the two marker words last, after everything a
 // step reads through them); false: the prep wave is gone and the header never came, or 30 s passed (AASM_E_INTERNAL, not a hang)
-AASM_DEV bool chain_wait_hdr(ChainSync *S, const I4 *vh, const I4 *vh2, int32_t u) {
+AASM_DEV bool chain_wait_hdr(ChainSync *S, const I4 *vh, const I4 *vh2, int32_t u, int64_t patience) {
     const int64_t t0 = wave_realtime();
     int64_t guard = 0;
     for (;;) {
@@ -2287,7 +2288,7 @@ AASM_DEV bool chain_wait_hdr(ChainSync *S, const I4 *vh, const I4 *vh2, int32_t 
         const int32_t x = uni(ld_shared_i32(&vh[u].x)), y = uni(ld_shared_i32(&vh2[u].y));
         if (x != -1 && y != -1) { wave_fence(); return true; }
         if (pd) return false;
-        if ((++guard & 1023) == 0 && wave_realtime() - t0 > (int64_t)30 * 100000000) return false;
+        if ((++guard & 1023) == 0 && wave_realtime() - t0 > patience) return false;
         wave_sleep();
     }
 }
@@ -2321,6 +2322,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
     if (w.status[c] != 0) return;
     if (!CHAIN && dist_is_max(w.sp_d[vb + src])) { if (k.lane == 0) set_status(w, c, -6); return; }   // :188-189: no path (must not happen)  (CHAIN: the sweep is still running - checked at the end)
     bool chain_lost = false;                                         // CHAIN: a header never came
+    const int64_t patience = (CHAIN && w.chain_test == 2) ? (int64_t)100000000 : (int64_t)30 * 100000000;   // 100 MHz ticks: 30 s (test hook: 1 s)
     int32_t head = 0, tail = 0, lds_hi = 0;                          // BFS queue positions; [head, lds_hi) live in the LDS window
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
@@ -2331,7 +2333,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
     KProfNone kp;
 #endif
     int32_t u = dest, hu = -1, so = 0, n = 0;                        // the vertex at hand: id, inherited heap, key offset, #keys
-    if (CHAIN && !chain_wait_hdr(S, vh, vh2, dest)) chain_lost = true;
+    if (CHAIN && !chain_wait_hdr(S, vh, vh2, dest, patience)) chain_lost = true;
     else {
         const I4 a0 = vh[dest];
         so = uni(a0.x); n = uni(a0.y);
@@ -2343,7 +2345,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
     while (!hs.ovf && !chain_lost) {
         HeapStage *St = &L->stage;
         if (staged != u) {                                           // not staged (the root, a spilled queue entry; CHAIN: a header that was not there yet when it was prefetched): fetch now
-            if (CHAIN && !chain_wait_hdr(S, vh, vh2, u)) { chain_lost = true; break; }
+            if (CHAIN && !chain_wait_hdr(S, vh, vh2, u, patience)) { chain_lost = true; break; }
             const I4 ha = vh[u], hb = vh2[u];
             so = uni(ha.x); c_n = uni(ha.y);                         // (what the parent handed over is the row's start and its LENGTH)
             FOR_LANE(t, (c_n < HEAP_KMAX ? c_n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; St->key[t] = kk; }   // (rare path: no need to overlap it with the header reads)
@@ -2434,7 +2436,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
         const int64_t t0 = wave_realtime();
         int64_t guard = 0;
         while (!chain_lost && !uni(ld_shared_i32(&S->sweep_done))) {
-            if ((++guard & 1023) == 0 && wave_realtime() - t0 > (int64_t)30 * 100000000) chain_lost = true;
+            if ((++guard & 1023) == 0 && wave_realtime() - t0 > patience) chain_lost = true;
             wave_sleep();
         }
         wave_fence();
@@ -2541,7 +2543,7 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
             a.x = a.y = a.z = a.w = 0; b = a;
             if (k.lane < n2) { heap_hdr_vertex(w, vb + u, a, b); tnx16_vertex(w, vb + u); }
             wave_fence();                                            // child slots, jump records: in memory before the marker words
-            if (k.lane < n2) { w.vhdr2[vb + u] = b; w.vhdr[vb + u] = a; }
+            if (k.lane < n2 && !(w.chain_test && c == 0 && u == (int32_t)w.ctgV[c] - 1)) { w.vhdr2[vb + u] = b; w.vhdr[vb + u] = a; }   // (test hook: contig 0's root never gets its header)
             r2_head += n2;
             did = true;
             wave_fence();
@@ -2553,7 +2555,7 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
         }
     }
     store_drain();
-    st_shared_i32(&S->prep_done, result);
+    if (!(w.chain_test == 2 && c == 0)) st_shared_i32(&S->prep_done, result);   // (test hook 2: the heap wave of contig 0 is left to its own patience)
 }
 
 // The three roles share one kernel, hence one register allocation: with every role reading its pointers from the kernel's

@@ -104,6 +104,9 @@ typedef struct aasm_opts {
                                 *     bit 1: aasm_solve_batch_multi wraps device ordinals around the devices that exist;
                                 *     bit 2: the next scan finds its ticket counter as an aborted launch would leave it (its look-back
                                 *            must give up after 10 s with AASM_E_HIP, and the next solve on the context must succeed);
+                                *     bit 3: the chain class's pre-pass wave of contig 0 never publishes the root's header (the contig must end with
+                                *            AASM_E_INTERNAL, nothing may hang); bit 4: ... and never reports that it is done (the heap wave gives up
+                                *            after 1 s instead of its 30 s);
                                 *     bits 8-15: d + 1 = the sort replay of duplicate-key contigs takes its heap sort
                                 *            fallback after d partition levels instead of 2 lg N                          */
 } aasm_opts;

@@ -102,6 +102,26 @@ def test_chain_class_beyond_one_residency_round_and_as_the_long_tail(T):
     assert T.diff_outputs(want, got) == []
 
 
+@pytest.mark.parametrize("how", [1, 2], ids=["header_never_comes", "prep_wave_never_reports"])
+def test_chain_class_waits_end_in_an_error_not_a_hang(T, how):
+    """Every wait of aasm_k67_chain has an exit every wave reaches.  Test hooks (opts.reserved[2] bits 3 / 4): the pre-pass wave of
+    contig 0 never publishes the root's header - the heap wave learns from `prep_done` that it will not come; or it does not even
+    report that it is done - the heap wave's own patience (1 s under the hook, 30 s otherwise) ends the wait.  Either way contig 0
+    ends with AASM_E_INTERNAL, every other contig with the oracle's result, the launch drains, and the next solve is clean."""
+    import time
+    api = T.api()
+    hb = T.synth(12, 90, 7, dup_every=5)
+    want = T.oracle_solve(hb, 16)
+    t0 = time.time()
+    got = api.solve_batch(hb, max_paths=16, chain="all", test_chain_lost=how)
+    assert time.time() - t0 < 20
+    assert got["status"][0] == -6 and (got["status"][1:] == 0).all()
+    mo, ao = want["main_off"], want["alt_off"]
+    gmo, gao = got["main_off"], got["alt_off"]
+    assert np.array_equal(want["main"][mo[1]:], got["main"][gmo[1]:]) and np.array_equal(want["alt"][ao[1]:], got["alt"][gao[1]:])
+    assert T.diff_outputs(want, api.solve_batch(hb, max_paths=16, chain="all")) == []
+
+
 def test_repeat_solve_is_deterministic(T):
     api = T.api()
     hb = T.synth(50, 200, 77, dup_every=5, shuffle=True)
