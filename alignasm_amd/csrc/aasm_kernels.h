@@ -131,7 +131,7 @@ struct WS {
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_MIDV, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // the chain class (kb_chain): contigs whose sweep, K7 pre-pass and heaps run in one workgroup; the one-stage kernels skip them
@@ -969,6 +969,7 @@ AASM_DEV void kb_ov_merge(const KCtx &k, const WS &w) {             // thread pe
 }
 
 #define REV_ORD_MAXV 12288               // most vertices of a contig that kb_rev_fill_ord can count in LDS
+#define REV_ORD_MIDV 3072                // ... in the form that keeps 6 waves per SIMD resident (6.7 KB of LDS instead of 25 KB: 2 per SIMD)
 AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread per contig
     const int64_t c = k.bid * k.nthreads + k.tid;
     if (c >= w.C) return;
@@ -982,6 +983,7 @@ AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread pe
     }
     w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
     if (N + P + 2 > REV_ORD_MAXV) atomic_max_i64(&w.counters[CNT_MAXV], N + P + 2);   // (kb_rev_fill_ord keeps a counter per vertex of a contig in LDS)
+    if (N + P + 2 > REV_ORD_MIDV) atomic_max_i64(&w.counters[CNT_MIDV], N + P + 2);
     if (N > 4096) atomic_max_i64(&w.counters[CNT_MAXN], N);         // longest contig of the batch (K8 picks its queue form by it; short ones need not report)
 }
 
@@ -1344,8 +1346,9 @@ AASM_DEV void kb_rev_fill_w(const KCtx &k, const WS &w) {           // wave per 
 // in-list is the number of edges with that head so far: a counter per vertex in LDS plus - heads are distinct inside a row -
 // nothing else, if the rows of a step take their turns one after the other (a step of 64 edges holds ~3 rows at out-degree 21).
 #define REV_ORD_U 4
-struct RevOrdLds { int64_t ptr[AASM_WAVE_MAX + 1]; uint16_t cnt[REV_ORD_MAXV]; };
-#define AASM_REVO_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REV_ORD_MAXV * 2)
+struct RevOrdLds { int64_t ptr[AASM_WAVE_MAX + 1]; uint16_t cnt[REV_ORD_MAXV]; };   // (the launch for batches of contigs of <= REV_ORD_MIDV vertices declares only that many counters)
+#define AASM_REVO_LDS_BYTES_V(maxv) ((AASM_WAVE_MAX + 1) * 8 + (maxv) * 2)
+#define AASM_REVO_LDS_BYTES AASM_REVO_LDS_BYTES_V(REV_ORD_MAXV)
 static_assert(sizeof(RevOrdLds) <= AASM_REVO_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_rev_fill_ord(const KCtx &k, const WS &w) {         // one wave per contig
     RevOrdLds *L = (RevOrdLds *)k.lds;

@@ -22,7 +22,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16
 };
@@ -45,7 +45,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_ROW_FILL: kb_row_fill(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_REV_FILL_W: kb_rev_fill_w(k, w); break;
-        case KN_REV_FILL_ORD: kb_rev_fill_ord(k, w); break;
+        case KN_REV_FILL_ORD: case KN_REV_FILL_ORD_S: kb_rev_fill_ord(k, w); break;
         case KN_SORT_ROWS_REV: kb_rev_place(k, w); break;
         case KN_REV_HDR: kb_rev_hdr(k, w); break;
         case KN_REV_SWEEP: kb_rev_sweep<AASM_WAVE>(k, w); break;
@@ -222,8 +222,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.scan_i32(w.deg, VT, w.rowptr);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32_pair(w.hcap_cnt, w.hoff, w.mw_cap, w.mw_off, C);
-        int64_t et_mv[7];
-        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN}, et_mv);
+        int64_t et_mv[8];
+        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN, w.counters + CNT_MIDV}, et_mv);
         const int64_t ET = et_mv[0], MAXV_OVER = et_mv[1];            // (MAXV_OVER: 0, or the largest contig of more than REV_ORD_MAXV vertices)
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
@@ -240,7 +240,9 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
-        if (ET > 6 * VT && MAXV_OVER == 0) be.launch(KN_REV_FILL_ORD, C, AASM_WAVE, w);   // dense, no giant contig: the in-lists in order from one pass per contig
+        // dense, no giant contig: the in-lists in order from one pass per contig (every contig of <= REV_ORD_MIDV vertices - C5's have 2 500 -: the
+        // launch with 6.7 KB of LDS counters instead of 25 KB, i.e. 6 waves per SIMD instead of 2)
+        if (ET > 6 * VT && MAXV_OVER == 0) be.launch(et_mv[7] == 0 ? KN_REV_FILL_ORD_S : KN_REV_FILL_ORD, C, AASM_WAVE, w);
         else {
             if (ET > 6 * VT) be.launch(KN_REV_FILL_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
             else be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
