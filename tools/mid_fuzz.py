@@ -12,7 +12,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     K = rnd.choice([1, 4, 16, 300]); nsl = rnd.random() < 0.25
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
     want = T.oracle_solve(hb, K, nsl)
-    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl)
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, chain=os.environ.get("AASM_FUZZ_CHAIN", "auto"))   # (the chain class: auto / all / half / none)
     d = T.diff_outputs(want, got)
     assert d == [], (nc, nr, seed, dense, dup, shuf, heavy, K, nsl, d)
     n += 1
