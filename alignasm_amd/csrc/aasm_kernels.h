@@ -2076,18 +2076,31 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
 //   ring (LDS)    the newest HEAP_RING nodes: staging for the flush + read cache for that pointer chase
 //   bq (LDS)      BFS queue window: {vertex, inherited heap root, key offset, #keys}; entries beyond the
 //                 window spill to global memory (wide trees)
-#define HEAP_RING 64
+#define HEAP_RING 64                      // ring of the several-waves kernel (per wave); the flush unit everywhere (a flush = one node per lane)
 #define HEAP_QN 128
 #define HEAP_KMAX 16                      // sidetrack keys of a vertex that travel through the staging slot
-#define AASM_HEAP_LDS_BYTES 5696
 struct HeapStage { Dist key[HEAP_KMAX]; };   // the first keys of one vertex
-struct HeapLds {
-    HNode ring[HEAP_RING];
-    I4 bq[HEAP_QN];
+// What the walk past the cached spine prefix reads (heap_read) is a node of an EARLIER insert: from the ring while it is among the
+// newest `rn` nodes, else from global memory.  Measured in round 5 with stamps inside the insert (1 000-record contigs): 1.28 such steps
+// per insert - the walk is NOT the rare path earlier rounds took it for, it is a quarter to a third of K7's time - of which 22 % missed
+// the 64-node ring (ages 64-127: 8 %, 128-511: 8 %, older: 6 %).  A bigger ring catches them (399 -> 238 -> 79 global steps per contig
+// with 128 / 512 nodes) but buys only 3-5 % of the kernel: a step costs ~700 cycles either way (its ~60 dependent instructions, not its
+// load).  The chain class has the LDS to spare (27 KB, its 5 three-wave workgroups per CU fit) and takes 512 nodes; the one-wave kernel
+// stays at 64 + a 128-entry queue window: with 128 + 64 (7.7 KB, on paper 20 workgroups per CU as before) C3's launch no longer fit one
+// residency round and took 5.5 ms instead of 4.06.
+template <int RING, int QN> struct HeapLdsT {
+    HNode ring[RING];
+    I4 bq[QN];
     HeapStage stage;                      // keys of the vertex popped next, parked here at the end of a step
     HNode bounce;                         // a node chased in global memory passes through here (heap_read)
 };
-static_assert(sizeof(HeapLds) <= AASM_HEAP_LDS_BYTES, "LDS budget");
+#define HEAP_RING_1W 64
+#define HEAP_QN_1W 128
+#define HEAP_RING_CH 512
+#define HEAP_QN_CH 128
+#define AASM_HEAP_LDS_BYTES_T(RING, QN) ((RING) * 48 + (QN) * 16 + HEAP_KMAX * 32 + 48)
+#define AASM_HEAP_LDS_BYTES AASM_HEAP_LDS_BYTES_T(HEAP_RING_1W, HEAP_QN_1W)
+static_assert(sizeof(HeapLdsT<HEAP_RING_1W, HEAP_QN_1W>) <= AASM_HEAP_LDS_BYTES && sizeof(HeapLdsT<HEAP_RING_CH, HEAP_QN_CH>) <= AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH), "LDS budget");
 struct Spine {
     LaneArr<NodeQ> n;          // cached nodes, position j in lane j
     LaneArr<int32_t> idx;      // their arena indices
@@ -2097,7 +2110,8 @@ struct Spine {
 };
 struct HeapState {
     HNode *nodes;
-    HNode *ring;                   // HEAP_RING nodes of LDS, this wave's
+    HNode *ring;                   // `rn` nodes of LDS, this wave's (rn: a power of two >= HEAP_RING)
+    int32_t rn;
     HNode *bounce;                 // one node of LDS, this wave's (heap_read)
     int32_t alloc, flushed, cap;   // arena: next index; nodes below `flushed` are in global memory, [flushed, alloc) only in the ring
     int32_t ring_lo;               // nodes below it were never in this wave's ring (0, or the start of the vertex region being filled)
@@ -2110,8 +2124,8 @@ struct HeapState {
 AASM_DEV const HNode *heap_arena(const WS &w, int64_t c) { return (w.mw_flag[c] && !w.mw_compact) ? w.hprov + w.mw_off[c] : w.hnodes + w.hoff[c]; }
 AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
     NodeQ n;
-    const HNode *src = &hs.ring[a & (HEAP_RING - 1)];                                  // ds_read, lgkmcnt only
-    if (!(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo)) {
+    const HNode *src = &hs.ring[a & (hs.rn - 1)];                                  // ds_read, lgkmcnt only
+    if (!(a >= hs.alloc - hs.rn && a >= hs.ring_lo)) {
         // an old node, in global memory (a few per cent of the chase steps): it goes to LDS first, so that what the caller keeps
         // in its spine registers has ONE kind of source - with a global load as the other one the compiler guards every later
         // use of the spine with vmcnt(0), and the inserts wait for the next vertex's prefetch instead of running beside it
@@ -2139,7 +2153,7 @@ AASM_DEV void heap_flush(HeapState &hs, int lane) {
     const int32_t m = hs.alloc - hs.flushed;
     if (m > 0) {
         wave_lds_sync();
-        FOR_LANE(t, m, lane) { const int32_t a = hs.flushed + t; nodeq_store(&hs.nodes[a], nodeq_load(&hs.ring[a & (HEAP_RING - 1)])); }
+        FOR_LANE(t, m, lane) { const int32_t a = hs.flushed + t; nodeq_store(&hs.nodes[a], nodeq_load(&hs.ring[a & (hs.rn - 1)])); }
         hs.flushed = hs.alloc;
     }
 }
@@ -2169,7 +2183,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
             // right pointer are the same in all of them.  The lane that will cache the node only notes its index; the nodes come
             // into the spine registers after the walk, all lanes at once - the loop carries scalars, not the sixteen spine registers.
             if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
-            const bool in_ring = a >= hs.alloc - HEAP_RING && a >= hs.ring_lo;
+            const bool in_ring = a >= hs.alloc - hs.rn && a >= hs.ring_lo;
             const NodeQ n = heap_read(hs, a);
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
             if (lane == 0) kp.acc[in_ring ? 7 : 6] += 1;                            // diagnostic: chase steps served by the ring / by global memory
@@ -2192,7 +2206,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         (void)d0; (void)my_a;
 #else
         if (depth > d0 && my_a >= 0) {                                              // the chased nodes that sit in the ring: all lanes at once
-            const NodeQ n = nodeq_load(&hs.ring[my_a & (HEAP_RING - 1)]);
+            const NodeQ n = nodeq_load(&hs.ring[my_a & (hs.rn - 1)]);
             sp.n.r = n; sp.idx.r = my_a; sp.sum.r = nodeq_key(n).qry + nodeq_key(n).ref;
         }
         // (measured: with the old nodes deferred too - no spine write inside the walk at all - K7 4.03 -> 4.08 ms)
@@ -2210,7 +2224,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
             FOR_LANE_EQ(j, depth, lane) {
                 const NodeQ n = heap_read(hs, a);
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
-                kp.acc[(a >= hs.alloc - HEAP_RING && a >= hs.ring_lo) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
+                kp.acc[(a >= hs.alloc - hs.rn && a >= hs.ring_lo) ? 7 : 6] += 1;                  // diagnostic: chase steps served by the ring / by global memory
 #endif
                 const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
                 sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum;
@@ -2223,7 +2237,7 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         a_stop = a;
     }
     if (hs.alloc + depth + 1 > hs.cap) { hs.ovf = true; return -1; }
-    if (hs.alloc + depth + 1 - hs.flushed > HEAP_RING) heap_flush(hs, lane);        // the new nodes must not overwrite unflushed ring slots
+    if (hs.alloc + depth + 1 - hs.flushed > HEAP_RING) heap_flush(hs, lane);        // a flush moves at most one node per lane (and the new nodes must not overwrite unflushed ring slots)
     // ---- rank chain (:34-38).  Bottom-up the recursion computes, with R = rank of the subtree
     // below and R_depth = 1 (the new leaf, :31):  swap iff l == null or rank(l) < R;  rank of the
     // copy R_j = 0 if l == null (the copy then has no right child) else min(rank(l), R) + 1.
@@ -2261,12 +2275,12 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         n.q2.x = leaf ? a_stop : (sw ? below : l); n.q2.y = leaf ? -1 : (sw ? l : below);
         n.q2.z = leaf ? eu : old.q2.z; n.q2.w = leaf ? ev : old.q2.w;
 #if defined(AASM_HOST_EMUL)
-        nodeq_store(&hs.ring[ni & (HEAP_RING - 1)], n);
+        nodeq_store(&hs.ring[ni & (hs.rn - 1)], n);
         sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;
         if (!leaf && sw) swm |= 1ull << j;
 #else
         if (in) {
-            nodeq_store(&hs.ring[ni & (HEAP_RING - 1)], n);
+            nodeq_store(&hs.ring[ni & (hs.rn - 1)], n);
             sp.n.at(j) = n; sp.idx.at(j) = ni; if (leaf) sp.sum.at(j) = ksum;       // position j of the NEW spine (valid up to the first swap)
         }
         swm = wave_ballot(in && !leaf && sw);
@@ -2295,19 +2309,19 @@ AASM_DEV bool chain_wait_hdr(ChainSync *S, const I4 *vh, const I4 *vh2, int32_t 
         wave_sleep();
     }
 }
-template <bool CHAIN = false>
+template <bool CHAIN = false, int RING = HEAP_RING_1W, int QN = HEAP_QN_1W>
 AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   // one wave per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
     if (V == 0) return;
     if (!CHAIN && in_chain_class(w, c)) return;                      // (built inside kb_chain)
-    HeapLds *L = (HeapLds *)k.lds;
+    HeapLdsT<RING, QN> *L = (HeapLdsT<RING, QN> *)k.lds;
     const int64_t vb = w.voff[c];
     int32_t *h = w.h_root + vb, *q = w.bq + vb;
     const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
     const Dist *sk = w.st_cost + w.rowptr[vb];                      // the contig's compacted sidetrack keys (kb_sidetrack)
     HeapState hs;
-    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.bounce = &L->bounce; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.rn = RING; hs.bounce = &L->bounce; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (w.mw_flag[c]) return;                                        // wide trees: kb_heap_mw
@@ -2365,7 +2379,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
         // ---- the vertex after this one: the queue front, or - the queue is empty, the tree path-like - the first child
         int32_t v2 = -1, so2 = 0, n2 = 0, hu2 = -1;
         bool peeked = false;                                         // the queue front has been read (the pop below takes it from here)
-        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; v2 = uni(e.x); hu2 = uni(e.y); so2 = uni(e.z); n2 = uni(e.w); peeked = true; } }
+        if (head < tail) { if (head < lds_hi) { const I4 e = L->bq[head & (QN - 1)]; v2 = uni(e.x); hu2 = uni(e.y); so2 = uni(e.z); n2 = uni(e.w); peeked = true; } }
         else if (nch > 0) { v2 = fc; so2 = so_fc; n2 = n_fc; }
         I4 pa, pb;
         LaneArr<Dist> pk;
@@ -2406,11 +2420,11 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
         }
         if (nch > 0) {                                               // they enter the LDS queue window while it has room
             int32_t ncache = 0;
-            if (lds_hi == tail) { ncache = HEAP_QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
+            if (lds_hi == tail) { ncache = QN - (tail - head); if (ncache > nch) ncache = nch; if (ncache < 0) ncache = 0; }
             const int64_t c0 = (int64_t)(((uint64_t)(uint32_t)c0hi << 32) | (uint32_t)c0lo);
             for (int32_t t = k.lane; t < nch; t += AASM_WAVE) {
                 const I4 ci = w.cinfo[c0 + t];
-                if (t < ncache) { I4 e; e.x = ci.x; e.y = hu; e.z = ci.y; e.w = ci.z; L->bq[(tail + t) & (HEAP_QN - 1)] = e; }
+                if (t < ncache) { I4 e; e.x = ci.x; e.y = hu; e.z = ci.y; e.w = ci.z; L->bq[(tail + t) & (QN - 1)] = e; }
                 else { h[ci.x] = hu; q[tail + t] = ci.x; }           // window full: spill (wide trees)
             }
             lds_hi += ncache;
@@ -2421,7 +2435,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
         // ---- pop
         if (head >= tail) break;
         if (peeked) { u = v2; hu = hu2; so = so2; n = n2; }
-        else if (head < lds_hi) { const I4 e = L->bq[head & (HEAP_QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
+        else if (head < lds_hi) { const I4 e = L->bq[head & (QN - 1)]; u = uni(e.x); hu = uni(e.y); so = uni(e.z); n = uni(e.w); }
         else {                                                       // spilled entry (the window was full when it was pushed)
             wave_fence();
             u = uni(q[head]); hu = uni(h[u]);
@@ -2469,10 +2483,10 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
 // it: the heap wave - the slowest of the three - finds what it needs and the contig costs max(K6, K7) instead of the sum.
 // Every wait ends: the sweep waits for nobody; the pre-pass only for the sweep (`sweep_done`); the heap wave only for the
 // pre-pass (`prep_done`), and gives up with AASM_E_INTERNAL after 30 s rather than sit.
-#define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES + 16)
+#define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH) + 16)
 #define CHAIN_WAVES 3
 #define CHAIN_LONG_ROW 8
-struct ChainLds { RevQ rq; HeapLds hl; ChainSync s; };
+struct ChainLds { RevQ rq; HeapLdsT<HEAP_RING_CH, HEAP_QN_CH> hl; ChainSync s; };
 static_assert(sizeof(ChainLds) <= AASM_CHAIN_LDS_BYTES, "LDS budget");
 
 AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
@@ -2595,7 +2609,7 @@ AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAV
         __builtin_amdgcn_s_setprio(1);                               // the heap wave is the contig's critical path
 #endif
         k2.lds = (char *)&L->hl;
-        kb_heap<true>(k2, w, &L->s);
+        kb_heap<true, HEAP_RING_CH, HEAP_QN_CH>(k2, w, &L->s);
     }
 }
 
@@ -2706,7 +2720,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     const int32_t nv = uni(ld_shared_i32(&L->n_total));
     // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
     HeapState hs;
-    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
+    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.rn = HEAP_RING; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     KProfNone kp;
     for (int i_ = 0; i_ < 8; i_++) kp.acc[i_] = 0;

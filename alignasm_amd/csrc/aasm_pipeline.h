@@ -57,7 +57,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_SIDETRACK: kb_sidetrack(k, w); break;
         case KN_SIDETRACK_W: kb_sidetrack_w(k, w); break;
         case KN_HEAP_HDR: kb_heap_hdr(k, w); break;
-        case KN_HEAP: kb_heap<false>(k, w); break;
+        case KN_HEAP: kb_heap<false, HEAP_RING_1W, HEAP_QN_1W>(k, w); break;
         case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: kb_heap_mw(k, w); break;
         case KN_MW_RANK: kb_mw_rank(k, w); break;
 #if defined(AASM_HOST_EMUL)
