@@ -2196,7 +2196,8 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
             if (in_ring) { if (lane == depth) my_a = a; }
             else if (lane == depth) { sp.n.r = n; sp.idx.r = a; sp.sum.r = nsum; }                      // (an old node, from global memory through the bounce slot - a few per cent: kept at once)
 #endif
-            const bool lt = uni((nsum < ksum) | ((nsum == ksum) & key_tie_lt(n, key)));
+            bool lt = uni(nsum < ksum);
+            if (!lt && uni(nsum == ksum)) lt = uni(key_tie_lt(n, key));             // (the tie order's two 32 x 32 -> 64 multiplies only when the sums are equal: the values are wave-uniform, the branch is scalar)
             if (!lt) { a_rank = uni(n.q1.w) & 0xff; break; }                        // the stop node (the new leaf takes its place in lane `depth`)
             a = uni(n.q2.y);                                                        // ->right
             depth++;
