@@ -2088,17 +2088,19 @@ struct HeapStage { Dist key[HEAP_KMAX]; };   // the first keys of one vertex
 // load).  The chain class has the LDS to spare (27 KB, its 5 three-wave workgroups per CU fit) and takes 512 nodes; the one-wave kernel
 // stays at 64 + a 128-entry queue window: with 128 + 64 (7.7 KB, on paper 20 workgroups per CU as before) C3's launch no longer fit one
 // residency round and took 5.5 ms instead of 4.06.
+#define HEAP_OLDN 8
 template <int RING, int QN> struct HeapLdsT {
     HNode ring[RING];
     I4 bq[QN];
     HeapStage stage;                      // keys of the vertex popped next, parked here at the end of a step
     HNode bounce;                         // a node chased in global memory passes through here (heap_read)
+    HNode oldn[HEAP_OLDN];                // ... and stays here until the walk is over (heap_insert)
 };
 #define HEAP_RING_1W 64
 #define HEAP_QN_1W 128
 #define HEAP_RING_CH 512
 #define HEAP_QN_CH 128
-#define AASM_HEAP_LDS_BYTES_T(RING, QN) ((RING) * 48 + (QN) * 16 + HEAP_KMAX * 32 + 48)
+#define AASM_HEAP_LDS_BYTES_T(RING, QN) ((RING) * 48 + (QN) * 16 + HEAP_KMAX * 32 + 48 + HEAP_OLDN * 48)
 #define AASM_HEAP_LDS_BYTES AASM_HEAP_LDS_BYTES_T(HEAP_RING_1W, HEAP_QN_1W)
 static_assert(sizeof(HeapLdsT<HEAP_RING_1W, HEAP_QN_1W>) <= AASM_HEAP_LDS_BYTES && sizeof(HeapLdsT<HEAP_RING_CH, HEAP_QN_CH>) <= AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH), "LDS budget");
 struct Spine {
@@ -2113,6 +2115,7 @@ struct HeapState {
     HNode *ring;                   // `rn` nodes of LDS, this wave's (rn: a power of two >= HEAP_RING)
     int32_t rn;
     HNode *bounce;                 // one node of LDS, this wave's (heap_read)
+    HNode *oldn;                   // HEAP_OLDN nodes of LDS, this wave's (one-wave kernel): walked nodes that have left the ring wait here for the lanes that will cache them
     int32_t alloc, flushed, cap;   // arena: next index; nodes below `flushed` are in global memory, [flushed, alloc) only in the ring
     int32_t ring_lo;               // nodes below it were never in this wave's ring (0, or the start of the vertex region being filled)
     bool ovf;
@@ -2122,17 +2125,18 @@ struct HeapState {
 // provisional one: its regions lie in BFS order of the vertices and a region is filled in allocation order, so the order of the
 // indices there IS the reference's allocation order (all that K8's tie-break asks of an index); only the indices have gaps
 AASM_DEV const HNode *heap_arena(const WS &w, int64_t c) { return (w.mw_flag[c] && !w.mw_compact) ? w.hprov + w.mw_off[c] : w.hnodes + w.hoff[c]; }
-AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a) {
+AASM_DEV NodeQ heap_read(const HeapState &hs, int32_t a, HNode *slot = nullptr) {   // slot: where a node from global memory is parked (default: the bounce slot)
     NodeQ n;
     const HNode *src = &hs.ring[a & (hs.rn - 1)];                                  // ds_read, lgkmcnt only
+    if (!slot) slot = hs.bounce;
     if (!(a >= hs.alloc - hs.rn && a >= hs.ring_lo)) {
         // an old node, in global memory (a few per cent of the chase steps): it goes to LDS first, so that what the caller keeps
         // in its spine registers has ONE kind of source - with a global load as the other one the compiler guards every later
         // use of the spine with vmcnt(0), and the inserts wait for the next vertex's prefetch instead of running beside it
         const NodeQ g = nodeq_load(&hs.nodes[a]);
         asm volatile("" ::: "memory");                                                 // keep it a global_load (no flat access)
-        nodeq_store(hs.bounce, g);
-        src = hs.bounce;
+        nodeq_store(slot, g);
+        src = slot;
     }
     n = nodeq_load(src);
     return n;
@@ -2176,25 +2180,32 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
         depth = sp.len;
         int32_t a = sp.tail;
         const int32_t d0 = depth;
-        int32_t my_a = -1;                                                          // lane j in [d0, depth): the ring node it will cache
+        int32_t my_a = -1, my_slot = -1;                                            // lane j in [d0, depth): the node it will cache; its place in `oldn` when it has left the ring
+        int32_t nold = 0;
         if (a >= 0) wave_lds_sync();                                                // ring writes of earlier inserts before the ring reads
         while (a >= 0) {
             // The walk itself is wave-uniform: every lane reads the node at `a` (one address: an LDS broadcast), the outcome and the
-            // right pointer are the same in all of them.  The lane that will cache the node only notes its index; the nodes come
-            // into the spine registers after the walk, all lanes at once - the loop carries scalars, not the sixteen spine registers.
+            // right pointer are the same in all of them.  The lane that will cache the node only notes where it is; the nodes come
+            // into the spine registers after the walk, all lanes at once - the loop carries scalars, not the sixteen spine registers
+            // (round 5: the nodes from global memory too - they wait in `oldn`; written into the spine inside the loop they gave it
+            // a second register set, and every step of every walk paid twenty copies between the two).
             if (depth >= AASM_WAVE_MAX - 2) { hs.ovf = true; return -1; }
             const bool in_ring = a >= hs.alloc - hs.rn && a >= hs.ring_lo;
+#if defined(AASM_HOST_EMUL)
             const NodeQ n = heap_read(hs, a);
+#else
+            const NodeQ n = heap_read(hs, a, (!in_ring && nold < HEAP_OLDN) ? &hs.oldn[nold] : nullptr);
+#endif
 #if defined(AASM_KPROF) && !defined(AASM_HOST_EMUL)
             if (lane == 0) kp.acc[in_ring ? 7 : 6] += 1;                            // diagnostic: chase steps served by the ring / by global memory
 #endif
             const int64_t nsum = nodeq_key(n).qry + nodeq_key(n).ref;
 #if defined(AASM_HOST_EMUL)
             FOR_LANE_EQ(j, depth, lane) { sp.n.at(j) = n; sp.idx.at(j) = a; sp.sum.at(j) = nsum; }
-            (void)in_ring;
+            (void)in_ring; (void)nold; (void)my_slot;
 #else
-            if (in_ring) { if (lane == depth) my_a = a; }
-            else if (lane == depth) { sp.n.r = n; sp.idx.r = a; sp.sum.r = nsum; }                      // (an old node, from global memory through the bounce slot - a few per cent: kept at once)
+            if (lane == depth) { my_a = a; my_slot = in_ring ? -1 : (nold < HEAP_OLDN ? nold : -2); }
+            if (!in_ring) nold++;
 #endif
             bool lt = uni(nsum < ksum);
             if (!lt && uni(nsum == ksum)) lt = uni(key_tie_lt(n, key));             // (the tie order's two 32 x 32 -> 64 multiplies only when the sums are equal: the values are wave-uniform, the branch is scalar)
@@ -2206,11 +2217,12 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
 #if defined(AASM_HOST_EMUL)
         (void)d0; (void)my_a;
 #else
-        if (depth > d0 && my_a >= 0) {                                              // the chased nodes that sit in the ring: all lanes at once
-            const NodeQ n = nodeq_load(&hs.ring[my_a & (hs.rn - 1)]);
+        if (depth > d0 && my_a >= 0) {                                              // the walked nodes, all lanes at once: from the ring, or from where heap_read parked them
+            const HNode *src = my_slot >= 0 ? &hs.oldn[my_slot] : &hs.ring[my_a & (hs.rn - 1)];
+            NodeQ n = nodeq_load(src);
+            if (my_slot == -2) { n = nodeq_load(&hs.nodes[my_a]); asm volatile("" ::: "memory"); }   // (more than HEAP_OLDN old nodes in one walk: never on the bench's graphs)
             sp.n.r = n; sp.idx.r = my_a; sp.sum.r = nodeq_key(n).qry + nodeq_key(n).ref;
         }
-        // (measured: with the old nodes deferred too - no spine write inside the walk at all - K7 4.03 -> 4.08 ms)
 #endif
     }
     if (depth < 0 && !UNI_CHASE) {                                                  // the walk lane by lane (the several-waves kernel: dense heaps, where the uniform form measured 4 % slower)
@@ -2322,7 +2334,7 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
     const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
     const Dist *sk = w.st_cost + w.rowptr[vb];                      // the contig's compacted sidetrack keys (kb_sidetrack)
     HeapState hs;
-    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.rn = RING; hs.bounce = &L->bounce; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.rn = RING; hs.bounce = &L->bounce; hs.oldn = L->oldn; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
     const int32_t src = (int32_t)(V - 2), dest = (int32_t)(V - 1);
     if (w.mw_flag[c]) return;                                        // wide trees: kb_heap_mw
@@ -2727,7 +2739,7 @@ AASM_DEV void kb_heap_mw(const KCtx &k, const WS &w) {              // MW_WAVES 
     const int32_t nv = uni(ld_shared_i32(&L->n_total));
     // ---- phase 1: the heaps, into per-vertex regions of the provisional arena
     HeapState hs;
-    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.rn = HEAP_RING; hs.bounce = &L->bounce[wv]; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
+    hs.nodes = w.hprov + w.mw_off[c]; hs.ring = L->ring[wv]; hs.rn = HEAP_RING; hs.bounce = &L->bounce[wv]; hs.oldn = nullptr; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.cap = 0; hs.ovf = false;
     Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
     KProfNone kp;
     for (int i_ = 0; i_ < 8; i_++) kp.acc[i_] = 0;
