@@ -2085,7 +2085,8 @@ struct HeapStage { Dist key[HEAP_KMAX]; };   // the first keys of one vertex
 // per insert - the walk is NOT the rare path earlier rounds took it for, it is a quarter to a third of K7's time - of which 22 % missed
 // the 64-node ring (ages 64-127: 8 %, 128-511: 8 %, older: 6 %).  A bigger ring catches them (399 -> 238 -> 79 global steps per contig
 // with 128 / 512 nodes) but buys only 3-5 % of the kernel: a step costs ~700 cycles either way (its ~60 dependent instructions, not its
-// load).  The chain class has the LDS to spare (27 KB, its 5 three-wave workgroups per CU fit) and takes 512 nodes; the one-wave kernel
+// load).  The chain class has LDS to spare and takes 256 nodes (18 KB a workgroup; with 512 - 30 KB - only four of its
+// three-wave workgroups fit a CU, and a batch of 1 280 contigs, five per CU, took a second residency round: 6.9 ms against 6.5 with the class off); the one-wave kernel
 // stays at 64 + a 128-entry queue window: with 128 + 64 (7.7 KB, on paper 20 workgroups per CU as before) C3's launch no longer fit one
 // residency round and took 5.5 ms instead of 4.06.
 #define HEAP_OLDN 8
@@ -2098,7 +2099,7 @@ template <int RING, int QN> struct HeapLdsT {
 };
 #define HEAP_RING_1W 64
 #define HEAP_QN_1W 128
-#define HEAP_RING_CH 512
+#define HEAP_RING_CH 256
 #define HEAP_QN_CH 128
 #define AASM_HEAP_LDS_BYTES_T(RING, QN) ((RING) * 48 + (QN) * 16 + HEAP_KMAX * 32 + 48 + HEAP_OLDN * 48)
 #define AASM_HEAP_LDS_BYTES AASM_HEAP_LDS_BYTES_T(HEAP_RING_1W, HEAP_QN_1W)
