@@ -131,6 +131,12 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     AZ(status, int32_t, C, "status");
     AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel");
     AZ(counters, int64_t, CNT_N, "counters");
+    // every zero-initialised per-contig array of the pipeline, one behind the other: one fill for all of them (they used to be zeroed where
+    // they were first needed: five more fill dispatches per step)
+    AZ(dupflag, int32_t, C, "dupflag");
+    AZ(main_len, int32_t, C, "main_len"); AZ(alt_len, int32_t, C, "alt_len"); AZ(all_gen, int32_t, C, "all_gen"); AZ(all_seq, int32_t, C, "all_seq");
+    AZ(kfound, int32_t, C, "kfound"); AZ(anom_dest, int32_t, C, "anom_dest"); AZ(h_cnt, int32_t, C, "h_cnt");
+    AZ(nconv, int32_t, C, "nconv");
 
     // ---- K0 (optional): match ranges from the cs tags, on the device
     if (!in.rng_qry_l && in.cs_text && in.rec_cs_off) {
@@ -153,7 +159,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
     // ---- K1 sort + parts
     be.phase_begin(AASM_PH_SORT);
-    A(perm, int32_t, R, "perm"); AZ(dupflag, int32_t, C, "dupflag"); A(np, int32_t, C, "np"); A(pstart, int32_t, R + C, "pstart");
+    A(perm, int32_t, R, "perm"); A(np, int32_t, C, "np"); A(pstart, int32_t, R + C, "pstart");
     A(s_qs, int64_t, R, "s_qs"); A(s_qe, int64_t, R, "s_qe"); A(s_rs, int64_t, R, "s_rs"); A(s_re, int64_t, R, "s_re");
     A(s_qt, int64_t, R, "s_qt"); A(s_rb, int64_t, R, "s_rb"); A(s_rn, int32_t, R, "s_rn"); A(s_chr, int32_t, R, "s_chr");
     A(s_orig, int32_t, R, "s_orig"); A(s_ctg, int32_t, R, "s_ctg"); A(s_pid, int32_t, R, "s_pid"); A(s_fl, uint8_t, R, "s_fl");
@@ -193,9 +199,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
     // main/alt outputs exist even when no contig has a graph (all single-record contigs)
     A(cur_out, OutElem, R, "cur_out"); A(main_out, OutElem, R, "main_out"); A(alt_out, OutElem, R, "alt_out");
-    AZ(main_len, int32_t, C, "main_len"); AZ(alt_len, int32_t, C, "alt_len"); AZ(all_gen, int32_t, C, "all_gen"); AZ(all_seq, int32_t, C, "all_seq");
     A(main_off, int64_t, C + 1, "main_off"); A(alt_off, int64_t, C + 1, "alt_off");
-    AZ(kfound, int32_t, C, "kfound"); AZ(anom_dest, int32_t, C, "anom_dest"); AZ(h_cnt, int32_t, C, "h_cnt");
     w.pool_cap = R + 1024; w.ar_cap = C + R / 4 + 1024;
     A(pool, OutElem, w.pool_cap, "pool");
     A(ar_ctg, int32_t, w.ar_cap, "ar_ctg"); A(ar_gen, int32_t, w.ar_cap, "ar_gen"); A(ar_seq, int32_t, w.ar_cap, "ar_seq");
@@ -229,14 +233,14 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         const int64_t NCHAIN = et_mv[6];
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
-        AZ(indeg, int32_t, VT, "indeg");
+        AZ(indeg, int32_t, VT, "indeg"); AZ(rcur, int32_t, VT, "rcur");   // (two fills in one)
         CHECK_ALLOC();
         be.launch(KN_ROW_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         be.phase_end(AASM_PH_EDGES);
 
         // ---- reversed CSR
         be.phase_begin(AASM_PH_REVCSR);
-        A(rptr, int64_t, VT + 1, "rptr"); AZ(rcur, int32_t, VT, "rcur");
+        A(rptr, int64_t, VT + 1, "rptr");
         A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
@@ -379,7 +383,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     // sequential one-wave-per-contig kernel when the per-conversion scratch would not fit
     // (tie-heavy inputs at large K) or when opts.reserved[0] bit 0 asks for it (tests).
     A(mark_time, int32_t, R, "mark_time");
-    AZ(nconv, int32_t, C, "nconv"); A(conv_off, int64_t, C + 1, "conv_off"); A(plan_kk, int32_t, C * 2 * SEL_PLAN_KEEP, "plan_kk");
+    A(conv_off, int64_t, C + 1, "conv_off"); A(plan_kk, int32_t, C * 2 * SEL_PLAN_KEEP, "plan_kk");
     CHECK_ALLOC();
     be.fill_byte(w.mark_time, 0x7F, sizeof(int32_t) * (size_t)R);
     bool sequential = (opts.reserved[0] & 1) != 0;
