@@ -388,6 +388,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     be.fill_byte(w.mark_time, 0x7F, sizeof(int32_t) * (size_t)R);
     bool sequential = (opts.reserved[0] & 1) != 0;
     int64_t NCONV = 0, SR = 0, SV = 0;
+    bool nm_ready = false;                                           // the output totals have been read with the pick's pool demand
+    int64_t nm[2] = {0, 0};
     if (!sequential) {
         be.phase_begin(AASM_PH_MISC);
         if (VT > 0) be.launch(KN_SEL_PLAN, C, AASM_WAVE, w);
@@ -422,9 +424,13 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         }
         be.phase_begin(AASM_PH_FINAL);
         be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
-        int64_t np2[2];
-        be.read_i64s({w.counters + CNT_POOL, w.counters + CNT_AR}, np2);
+        // the output lengths are final with the pick: their offsets are scanned at once, and ONE read-back brings the pool demand and the
+        // two totals (it was a wait for the demand, then the scans, then a wait for the totals)
+        be.scan_i32_pair(w.main_len, w.main_off, w.alt_len, w.alt_off, C);
+        int64_t np2[4];
+        be.read_i64s({w.counters + CNT_POOL, w.counters + CNT_AR, w.main_off + C, w.alt_off + C}, np2);
         const int64_t need_pool = np2[0], need_ar = np2[1];
+        nm_ready = true; nm[0] = np2[2]; nm[1] = np2[3];
         if (need_pool > w.pool_cap || need_ar > w.ar_cap) {         // .all pool overflow: exact-size re-run of the pick only
             w.pool_cap = need_pool + 16; w.ar_cap = need_ar + 16;
             A(pool, OutElem, w.pool_cap, "pool");
@@ -434,6 +440,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.zero(w.all_seq, sizeof(int32_t) * (size_t)C);
             be.zero(w.counters + CNT_POOL, sizeof(int64_t)); be.zero(w.counters + CNT_AR, sizeof(int64_t)); be.zero(w.counters + CNT_OVF, sizeof(int64_t));
             be.launch(KN_SEL_FINAL, C, AASM_WAVE, w);
+            nm_ready = false;                                        // (the same lengths again, but keep the one code path: scanned and read below)
         }
         be.phase_end(AASM_PH_FINAL);
     } else {
@@ -467,9 +474,10 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
     // ---- output compaction
     be.phase_begin(AASM_PH_GATHER);
-    be.scan_i32_pair(w.main_len, w.main_off, w.alt_len, w.alt_off, C);
-    int64_t nm[2];
-    be.read_i64s({w.main_off + C, w.alt_off + C}, nm);
+    if (!nm_ready) {
+        be.scan_i32_pair(w.main_len, w.main_off, w.alt_len, w.alt_off, C);
+        be.read_i64s({w.main_off + C, w.alt_off + C}, nm);
+    }
     const int64_t NM = nm[0], NA = nm[1];
     A(main_c, OutElem, NM, "main_c"); A(alt_c, OutElem, NA, "alt_c");
     CHECK_ALLOC();

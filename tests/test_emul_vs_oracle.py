@@ -84,3 +84,13 @@ def test_chain_class_forms(T, case, chain):
         assert n_class == int((sizes > 1).sum())
     else:
         assert n_class == int(((sizes >= -(-int(sizes.sum()) // len(sizes))) & (sizes > 1)).sum())
+
+
+def test_all_pool_overflow_reruns_the_pick(T):
+    """Every record duplicated: hundreds of co-optimal walks per contig, the `.all` lists hold 130x the records - far beyond the pool the
+    first pick is given (R + 1 024 elements).  The pick is re-run with the exact size (one read-back brings the demand and the output
+    totals; the totals are read again after the re-run)."""
+    hb = T.synth(3, 30, 5, dup_every=1)
+    want = T.oracle_solve(hb, 10000)
+    assert len(want["all"]) > len(hb.arrays["qry_str"]) + 1024
+    assert T.diff_outputs(want, T.emul_solve(hb, 10000)) == []

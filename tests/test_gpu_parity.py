@@ -122,6 +122,16 @@ def test_chain_class_waits_end_in_an_error_not_a_hang(T, how):
     assert T.diff_outputs(want, api.solve_batch(hb, max_paths=16, chain="all")) == []
 
 
+def test_all_pool_overflow_reruns_the_pick(T):
+    """Every record duplicated: hundreds of co-optimal walks per contig, `.all` lists 130x the records - beyond the pool of the first
+    pick (R + 1 024 elements): the pick is re-run with the exact size, and the output totals are read again after it."""
+    api = T.api()
+    hb = T.synth(3, 30, 5, dup_every=1)
+    want = T.oracle_solve(hb, 10000)
+    assert len(want["all"]) > len(hb.arrays["qry_str"]) + 1024
+    assert T.diff_outputs(want, api.solve_batch(hb, max_paths=10000)) == []
+
+
 def test_repeat_solve_is_deterministic(T):
     api = T.api()
     hb = T.synth(50, 200, 77, dup_every=5, shuffle=True)
