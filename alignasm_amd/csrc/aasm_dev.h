@@ -58,7 +58,7 @@ AASM_DEV void atomic_max_i64(int64_t *p, int64_t v) { if (v > *p) *p = v; }
 AASM_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 AASM_DEV int ffs64(uint64_t m) { return __builtin_ffsll((long long)m); }
 #else
-AASM_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+AASM_DEV uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 AASM_DEV int wave_bcast(int x, int src) { return __shfl(x, src, 64); }
 AASM_DEV int64_t wave_bcast(int64_t x, int src) {
     int lo = __shfl((int)(x & 0xffffffffll), src, 64), hi = __shfl((int)(x >> 32), src, 64);
@@ -77,6 +77,7 @@ AASM_DEV int64_t wave_shfl_idx(int64_t x, int src) {                // src may d
     const int lo = __shfl((int)(uint32_t)(uint64_t)x, src, 64), hi = __shfl((int)((uint64_t)x >> 32), src, 64);
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
+AASM_DEV int wave_shfl_idx(int x, int src) { return __shfl(x, src, 64); }
 AASM_DEV int wave_shfl_xor(int x, int m) { return __shfl_xor(x, m, 64); }
 AASM_DEV int64_t wave_shfl_xor(int64_t x, int m) {
     int lo = __shfl_xor((int)(x & 0xffffffffll), m, 64), hi = __shfl_xor((int)(x >> 32), m, 64);

@@ -62,6 +62,7 @@ AASM_DEF_KERNEL(aasm_k2_vfill_slot, KN_VFILL_SLOT, 256)
 AASM_DEF_KERNEL(aasm_k4_nsl, KN_NSL, 256)
 AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
+AASM_DEF_KERNEL_LDS(aasm_k46_graph, KN_GRAPH, GB_TPB, AASM_GB_LDS_BYTES, 2)   // rows + reversed CSR + sweep headers of one contig: 30 KB of LDS, 5 workgroups (20 waves) per CU
 AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_w, KN_REV_FILL_W, 64, AASM_REVF_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_ord, KN_REV_FILL_ORD, 64, AASM_REVO_LDS_BYTES, 2)   // 25 KB of LDS per block: 6 blocks per CU, i.e. at most 2 waves per SIMD
@@ -675,7 +676,7 @@ struct GpuBackend {
             L(KN_CS_RANGES, aasm_k0_cs_ranges) L(KN_SORT, aasm_k1_sort) L(KN_SORT_RANK, aasm_k1_sort_rank) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
             L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
-            L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord) L(KN_REV_FILL_ORD_S, aasm_k6_rev_fill_ord_s)
+            L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_GRAPH, aasm_k46_graph) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord) L(KN_REV_FILL_ORD_S, aasm_k6_rev_fill_ord_s)
             L(KN_SORT_ROWS_REV, aasm_k6_rev_place) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
             L(KN_CHILDREN, aasm_k7_children)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)

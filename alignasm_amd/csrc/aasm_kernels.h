@@ -101,7 +101,7 @@ struct WS {
     // ---- status / counters
     int32_t *status;
     int64_t *counters;
-    int64_t *prof_heap, *prof_sel;    // [C * 8] cycle sums per section (diagnostic build only)
+    int64_t *prof_heap, *prof_sel, *prof_gb;    // [C * 8] cycle sums per section (diagnostic build only)
     // ---- K7 pre-pass: compacted sidetrack keys and the packed per-vertex header
     Dist *st_cost;                       // per vertex, at the front of its CSR row: its sidetrack keys in list order, edge head in .pad
     int32_t *st_n;                       // ... and how many
@@ -131,7 +131,7 @@ struct WS {
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_MIDV, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_MAXE, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // the chain class (kb_chain): contigs whose sweep, K7 pre-pass and heaps run in one workgroup; the one-stage kernels skip them
@@ -982,8 +982,7 @@ AASM_DEV void kb_vcount(const KCtx &k, const WS &w) {               // thread pe
         return;
     }
     w.ctgV[c] = (int32_t)(N + P + 2);                               // + src, dest (:699-700)
-    if (N + P + 2 > REV_ORD_MAXV) atomic_max_i64(&w.counters[CNT_MAXV], N + P + 2);   // (kb_rev_fill_ord keeps a counter per vertex of a contig in LDS)
-    if (N + P + 2 > REV_ORD_MIDV) atomic_max_i64(&w.counters[CNT_MIDV], N + P + 2);
+    atomic_max_i64(&w.counters[CNT_MAXV], N + P + 2);               // most vertices of a contig (kb_rev_fill_ord and kb_graph_build keep a counter per vertex of a contig in LDS)
     if (N > 4096) atomic_max_i64(&w.counters[CNT_MAXN], N);         // longest contig of the batch (K8 picks its queue form by it; short ones need not report)
 }
 
@@ -1074,11 +1073,10 @@ struct RowPlan {
     int64_t nx0, nx1;     // (k,k) range in the next part
     int64_t stq;          // lft.qry_str of this vertex
 };
-AASM_DEV RowPlan plan_row(const WS &w, int64_t gv) {
+// (plan_row_c: the contig and its constants are the caller's - kb_graph_build's workgroup has them; two dependent round trips fewer)
+AASM_DEV RowPlan plan_row_c(const WS &w, int64_t gv, int64_t c, int64_t b, int64_t N, int64_t V, int64_t vb) {
     RowPlan r;
-    r.c = w.v_ctg[gv];
-    r.b = w.rec_off[r.c] - w.R0; r.N = w.rec_off[r.c + 1] - w.rec_off[r.c];
-    r.V = w.ctgV[r.c]; r.vb = w.voff[r.c];
+    r.c = c; r.b = b; r.N = N; r.V = V; r.vb = vb;
     const int64_t v = gv - r.vb;
     r.i = w.v_i[gv]; r.j = w.v_j[gv]; r.slot = w.v_slot[gv];
     r.has_dest = false; r.ov0 = r.ovn = 0; r.dis0 = r.dis1 = r.nx0 = r.nx1 = 0; r.stq = 0;
@@ -1101,6 +1099,10 @@ AASM_DEV RowPlan plan_row(const WS &w, int64_t gv) {
     if (!p.last) { r.nx0 = p.pr; r.nx1 = w.nsl ? p.pr + w.next_cnt[r.b + p.pr] : p.nr; }
     r.stq = (r.slot < 0) ? w.s_qs[gj] : w.ov_stq[r.slot];
     return r;
+}
+AASM_DEV RowPlan plan_row(const WS &w, int64_t gv) {
+    const int64_t c = w.v_ctg[gv];
+    return plan_row_c(w, gv, c, w.rec_off[c] - w.R0, w.rec_off[c + 1] - w.rec_off[c], w.ctgV[c], w.voff[c]);
 }
 // pair edge (.., j) -> (j, k) exists iff the pair vertex exists and lft.qry_str < rht.qry_str (:433-436)
 AASM_DEV bool pair_edge_ok(const WS &w, const RowPlan &r, int64_t t) {
@@ -1154,9 +1156,10 @@ AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, 
     fl = edge_flags(anom, (w.s_fl[gr] & 2) ? 1 : 0, 1);                             // :518-519
 }
 
-AASM_DEV void emit_edge(const WS &w, int64_t e, int64_t vb, int32_t col, int64_t wq, int32_t wr, uint8_t fl) {
+// (ib: the in-degree counters of the row's contig - w.indeg + vb, or kb_graph_build's copy in LDS)
+AASM_DEV void emit_edge(const WS &w, int64_t e, int32_t *ib, int32_t col, int64_t wq, int32_t wr, uint8_t fl) {
     w.e_col[e] = col; w.e_wq[e] = wq; w.e_wr[e] = wr; w.e_fl[e] = fl;
-    atomic_add(&w.indeg[vb + col], (int32_t)1);
+    atomic_add(&ib[col], (int32_t)1);
 }
 
 // fills rows: each lane owns one vertex of a 64-vertex tile (short rows); rows longer than
@@ -1164,14 +1167,14 @@ AASM_DEV void emit_edge(const WS &w, int64_t e, int64_t vb, int32_t col, int64_t
 #define AASM_LONG_ROW 16
 #define AASM_MID_ROW 96
 // G lanes (the whole wave, or 16 of it for rows of up to a few dozen edges: four rows at a time) work on the row; lane = 0 .. G - 1
-template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane, int gbase) {
+template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int64_t e0, int lane, int gbase, int32_t *ib) {
     const int nl = G;
     // segments: [dest][pairs][disjoint][next]; lanes stride over each segment
     int64_t e = e0;
     if (r.kind == 1) {                                              // src (:552-561)
         for (int64_t t = r.nx0 + lane; t < r.nx1; t += nl) {
             const int64_t g = r.b + t;
-            emit_edge(w, e + (t - r.nx0), r.vb, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0,
+            emit_edge(w, e + (t - r.nx0), ib, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0,
                       edge_flags(0, (w.s_fl[g] & 2) ? 1 : 0, 1));
         }
         return;
@@ -1179,7 +1182,7 @@ template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int6
     if (r.has_dest) {                                               // :577-585,591
         if (lane == 0) {
             const int64_t gj = r.b + r.j;
-            emit_edge(w, e, r.vb, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0,
+            emit_edge(w, e, ib, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0,
                       edge_flags(0, 0, 0));
         }
         e += 1;
@@ -1193,61 +1196,63 @@ template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int6
             const int64_t s = r.ov0 + t, pos = e + popc64(m & lanemask_lt(lane));
             int64_t wq; int32_t wr; uint8_t fl;
             score_edge(w, r, r.j + 1 + t, s, wq, wr, fl);
-            emit_edge(w, pos, r.vb, w.ov_vid[s], wq, wr, fl);
+            emit_edge(w, pos, ib, w.ov_vid[s], wq, wr, fl);
         }
         e += popc64(m);
     }
     for (int64_t t = r.dis0 + lane; t < r.dis1; t += nl) {
         int64_t wq; int32_t wr; uint8_t fl;
         score_edge(w, r, t, -1, wq, wr, fl);
-        emit_edge(w, e + (t - r.dis0), r.vb, (int32_t)t, wq, wr, fl);
+        emit_edge(w, e + (t - r.dis0), ib, (int32_t)t, wq, wr, fl);
     }
     if (r.dis1 > r.dis0) e += r.dis1 - r.dis0;
     for (int64_t t = r.nx0 + lane; t < r.nx1; t += nl) {
         int64_t wq; int32_t wr; uint8_t fl;
         score_edge(w, r, t, -1, wq, wr, fl);
-        emit_edge(w, e + (t - r.nx0), r.vb, (int32_t)t, wq, wr, fl);
+        emit_edge(w, e + (t - r.nx0), ib, (int32_t)t, wq, wr, fl);
     }
 }
-AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 64 vertices
-    const int64_t gv = k.bid * AASM_WAVE + k.lane;
-    const bool act = gv < w.VT;
+// one tile of AASM_WAVE rows [gv0, gv0 + AASM_WAVE) below gv_end; LDSI: the in-degree counters of the tile's (one) contig are `lcnt`, in LDS (else w.indeg)
+template <bool LDSI> AASM_DEV void row_fill_tile(const WS &w, int lane, int64_t gv0, int64_t gv_end, int32_t *lcnt) {
+    const int64_t gv = gv0 + lane;
+    const bool act = gv < gv_end;
     int32_t d = act ? w.deg[gv] : 0;
     RowPlan r;
     if (act && d > 0) r = plan_row(w, gv);
     const bool small = act && d > 0 && d <= AASM_LONG_ROW;
     const bool big = act && d > AASM_LONG_ROW;
 #if defined(AASM_HOST_EMUL)
-    if (small || big) fill_row_part<1>(w, r, w.rowptr[gv], 0, 0);
+    if (small || big) fill_row_part<1>(w, r, w.rowptr[gv], 0, 0, LDSI ? lcnt : w.indeg + r.vb);
 #else
     // short rows: run with a single logical lane (ballot of a lone lane is its own bit)
     if (small) {
         int64_t e = w.rowptr[gv];
+        int32_t *ib = LDSI ? lcnt : w.indeg + r.vb;
         if (r.kind == 1) {
             for (int64_t t = r.nx0; t < r.nx1; t++) {
                 const int64_t g = r.b + t;
-                emit_edge(w, e++, r.vb, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, (w.s_fl[g] & 2) ? 1 : 0, 1));
+                emit_edge(w, e++, ib, (int32_t)t, w.s_qs[g] * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, (w.s_fl[g] & 2) ? 1 : 0, 1));
             }
         } else {
             if (r.has_dest) {
                 const int64_t gj = r.b + r.j;
-                emit_edge(w, e++, r.vb, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, 0, 0));
+                emit_edge(w, e++, ib, (int32_t)(r.V - 1), (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT, 0, edge_flags(0, 0, 0));
             }
             for (int64_t t = 0; t < r.ovn; t++)
                 if (pair_edge_ok(w, r, t)) {
                     int64_t wq; int32_t wr; uint8_t fl;
                     score_edge(w, r, r.j + 1 + t, r.ov0 + t, wq, wr, fl);
-                    emit_edge(w, e++, r.vb, w.ov_vid[r.ov0 + t], wq, wr, fl);
+                    emit_edge(w, e++, ib, w.ov_vid[r.ov0 + t], wq, wr, fl);
                 }
             for (int64_t t = r.dis0; t < r.dis1; t++) {
                 int64_t wq; int32_t wr; uint8_t fl;
                 score_edge(w, r, t, -1, wq, wr, fl);
-                emit_edge(w, e++, r.vb, (int32_t)t, wq, wr, fl);
+                emit_edge(w, e++, ib, (int32_t)t, wq, wr, fl);
             }
             for (int64_t t = r.nx0; t < r.nx1; t++) {
                 int64_t wq; int32_t wr; uint8_t fl;
                 score_edge(w, r, t, -1, wq, wr, fl);
-                emit_edge(w, e++, r.vb, (int32_t)t, wq, wr, fl);
+                emit_edge(w, e++, ib, (int32_t)t, wq, wr, fl);
             }
         }
     }
@@ -1259,12 +1264,12 @@ AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 
         for (int g = 0; g < 4; g++) {
             const int sg = midmask ? ffs64(midmask) - 1 : -1;
             if (midmask) midmask &= midmask - 1;
-            if ((k.lane >> 4) == g) src = sg;
+            if ((lane >> 4) == g) src = sg;
         }
         if (src >= 0) {
-            const int64_t gv2 = k.bid * AASM_WAVE + src;
+            const int64_t gv2 = gv0 + src;
             const RowPlan r2 = plan_row(w, gv2);
-            fill_row_part<16>(w, r2, w.rowptr[gv2], k.lane & 15, k.lane & ~15);
+            fill_row_part<16>(w, r2, w.rowptr[gv2], lane & 15, lane & ~15, LDSI ? lcnt : w.indeg + r2.vb);
         }
     }
     // longer rows: all 64 lanes cooperate on one row at a time
@@ -1272,11 +1277,99 @@ AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) {             // wave per 
     while (bigmask) {
         const int src = ffs64(bigmask) - 1;
         bigmask &= bigmask - 1;
-        const int64_t gv2 = k.bid * AASM_WAVE + src;
+        const int64_t gv2 = gv0 + src;
         const RowPlan r2 = plan_row(w, gv2);
-        fill_row_part<AASM_WAVE>(w, r2, w.rowptr[gv2], k.lane, 0);
+        fill_row_part<AASM_WAVE>(w, r2, w.rowptr[gv2], lane, 0, LDSI ? lcnt : w.indeg + r2.vb);
     }
 #endif
+}
+AASM_DEV void kb_row_fill(const KCtx &k, const WS &w) { row_fill_tile<false>(w, k.lane, k.bid * AASM_WAVE, w.VT, nullptr); }   // wave per 64 vertices
+
+// The same rows, one lane per CANDIDATE edge (kb_graph_build).  With a lane per row a wave runs as many turns as its longest row
+// (6-10 at a mean out-degree of 2.1, each turn two dependent round trips: the pair test, then the score's operands) for a third
+// of its lanes.  Here the lanes first plan their rows, as above; a row's candidates are [-> dest][its overlap slots][the disjoint
+// records of its part][the records of the next part] - every edge of the row is one of them, in row order, and only a slot can fail
+// (pair_edge_ok) - and the tile's candidates are numbered through (prefix sums of the rows' counts, in LDS).  Then 64 candidates a
+// turn: a lane finds its candidate's row (binary search in the prefix sums), takes that row's plan from the lane that made it,
+// evaluates the candidate, and its place in the row is the number of candidates of the row that passed before it (ballot +
+// a count per row carried from turn to turn).  All rows of the tile belong to the contig of `r0` (vertex gv0).
+// P: AASM_WAVE + 1 words of LDS, this wave's;  src16: the source of contig-local edge e (kb_graph_build's step 3), or null.
+template <bool LDSI> AASM_DEV void row_fill_tile_par(const WS &w, int lane, int64_t gv0, int64_t gv_end, int32_t *lcnt, int32_t *P, uint16_t *src16, int64_t eb, int64_t cc, int64_t cb, int64_t cN, int64_t cV, int64_t cvb) {
+    const int64_t gv = gv0 + lane;
+    const bool act = gv < gv_end;
+    const int32_t d = act ? w.deg[gv] : 0;
+    RowPlan r;
+    r.c = 0; r.b = 0; r.N = 0; r.V = 0; r.vb = 0; r.kind = 2; r.i = 0; r.j = 0; r.slot = -1; r.has_dest = false;
+    r.ov0 = r.ovn = 0; r.dis0 = r.dis1 = r.nx0 = r.nx1 = 0; r.stq = 0;
+    if (act) r = plan_row_c(w, gv, cc, cb, cN, cV, cvb);
+    int32_t ncand = 0;
+    if (act && d > 0 && r.kind == 1) ncand = (int32_t)(r.nx1 - r.nx0);
+    if (act && d > 0 && r.kind == 0) ncand = (r.has_dest ? 1 : 0) + (int32_t)r.ovn + (int32_t)(r.dis1 > r.dis0 ? r.dis1 - r.dis0 : 0) + (int32_t)(r.nx1 - r.nx0);
+    const int32_t incl = wave_incl_add(ncand);
+    wave_lds_sync();                                                 // (the tile before: its reads of P are done)
+    P[lane] = incl - ncand;
+    if (lane == AASM_WAVE - 1) P[AASM_WAVE] = incl;
+    wave_lds_sync();
+    const int32_t M = P[AASM_WAVE];
+    const int32_t my_p0 = incl - ncand;
+    const int64_t e_row = act ? w.rowptr[gv] : 0;
+    const int32_t hd = (r.kind & 3) | (r.has_dest ? 4 : 0);
+    int32_t carry = 0;                                               // candidates of MY row that passed in earlier turns
+    for (int32_t c0 = 0; c0 < M; c0 += AASM_WAVE) {
+        const int32_t g = c0 + lane;
+        const bool in = g < M;
+        int32_t lo = 0, hi = AASM_WAVE;                              // P[lo] <= g < P[hi]  (rows without candidates share a value: the last of them is taken, the one that has some)
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (P[mid] <= g) lo = mid; else hi = mid; }
+        const int rr = in ? lo : 0;
+        // the row's plan, from the lane that made it
+        RowPlan q;
+        const int32_t qhd = wave_shfl_idx(hd, rr);
+        q.c = 0; q.b = cb; q.N = 0; q.V = cV; q.vb = cvb; q.kind = qhd & 3; q.has_dest = (qhd & 4) != 0; q.i = 0;
+        q.j = wave_shfl_idx((int32_t)r.j, rr); q.slot = wave_shfl_idx(r.slot, rr);
+        q.ov0 = wave_shfl_idx(r.ov0, rr); q.ovn = wave_shfl_idx((int32_t)r.ovn, rr);
+        q.dis0 = wave_shfl_idx((int32_t)r.dis0, rr); q.dis1 = wave_shfl_idx((int32_t)r.dis1, rr);
+        q.nx0 = wave_shfl_idx((int32_t)r.nx0, rr); q.nx1 = wave_shfl_idx((int32_t)r.nx1, rr);
+        q.stq = wave_shfl_idx(r.stq, rr);
+        const int64_t q_e = wave_shfl_idx(e_row, rr);
+        const int32_t q_p0 = wave_shfl_idx(my_p0, rr), q_carry = wave_shfl_idx(carry, rr);
+        const int32_t jc = g - q_p0;                                 // candidate jc of its row
+        // which candidate
+        const int32_t n_dest = q.has_dest ? 1 : 0, n_ov = (int32_t)q.ovn, n_dis = (int32_t)(q.dis1 > q.dis0 ? q.dis1 - q.dis0 : 0);
+        bool ok = in;
+        int32_t col = 0;
+        int64_t wq = 0; int32_t wr = 0; uint8_t fl = 0;
+        if (in) {
+            if (q.kind == 1) {                                       // src (:552-561)
+                const int64_t t = q.nx0 + jc, gg = q.b + t;
+                col = (int32_t)t; wq = w.s_qs[gg] * AASM_SV_FRONT_END_COEFFICIENT; wr = 0; fl = edge_flags(0, (w.s_fl[gg] & 2) ? 1 : 0, 1);
+            } else if (jc < n_dest) {                                // :577-585,591
+                const int64_t gj = q.b + q.j;
+                col = (int32_t)(q.V - 1); wq = (w.s_qt[gj] - w.s_qe[gj] - 1) * AASM_SV_FRONT_END_COEFFICIENT; wr = 0; fl = edge_flags(0, 0, 0);
+            } else if (jc < n_dest + n_ov) {                         // a pair (j, k)
+                const int64_t t = jc - n_dest, sl = q.ov0 + t;
+                col = w.ov_vid[sl];                                  // (the score's operands are fetched whether the pair passes or not: one round trip, not two)
+                score_edge(w, q, q.j + 1 + t, sl, wq, wr, fl);
+                ok = col >= 0 && q.stq < w.ov_stq[sl];               // pair_edge_ok (:433-436)
+            } else {
+                const int64_t t = jc < n_dest + n_ov + n_dis ? q.dis0 + (jc - n_dest - n_ov) : q.nx0 + (jc - n_dest - n_ov - n_dis);
+                score_edge(w, q, t, -1, wq, wr, fl);
+                col = (int32_t)t;
+            }
+        }
+        const uint64_t okm = wave_ballot(ok);
+        if (ok) {
+            const int32_t first = q_p0 - c0 > 0 ? q_p0 - c0 : 0;     // my row's first lane of this turn
+            const int64_t e = q_e + q_carry + popc64(okm & lanemask_lt(lane) & ~lanemask_lt(first));
+            emit_edge(w, e, LDSI ? lcnt : w.indeg + q.vb, col, wq, wr, fl);
+            if (src16) src16[e - eb] = (uint16_t)(gv0 - q.vb + rr);
+        }
+        // rows (their owner lanes) count what passed of theirs in this turn
+        {
+            const int32_t a0 = my_p0 - c0 > 0 ? my_p0 - c0 : 0;
+            const int32_t a1 = my_p0 + ncand - c0 < AASM_WAVE ? my_p0 + ncand - c0 : AASM_WAVE;
+            if (a1 > a0) carry += popc64(okm & lanemask_lt(a1) & ~lanemask_lt(a0));
+        }
+    }
 }
 
 // ====================================================================================
@@ -1492,6 +1585,32 @@ struct RevEnt { I4 hdr; Dist d; I4 rec[2]; };                        // hdr = {i
 struct RevQ { RevEnt e[REVQ_N]; };
 #define AASM_REV_LDS_BYTES (REVQ_N * 80)
 static_assert(sizeof(RevQ) <= AASM_REV_LDS_BYTES, "LDS budget");
+// the forward sweep's vertex header and both sweeps' per-vertex state (kb_rev_hdr, kb_graph_build)
+// {-, head 0, head 1, anomaly weight 0 | weight 1 << 8} of the row [o0, o1)
+AASM_DEV I4 fwd_hdr_heads(const WS &w, int64_t o0, int64_t o1) {
+    I4 f1;
+    f1.x = 0; f1.y = (o1 > o0) ? w.e_col[o0] : 0; f1.z = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0;
+    f1.w = ((o1 > o0) ? (w.e_fl[o0] & 3) : 0) | (((o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0) << 8);
+    return f1;
+}
+AASM_DEV void sweep_vertex_store(const WS &w, int64_t gv, int32_t ideg, int64_t o0, int64_t o1, const I4 &f1, int64_t vend) {   // vend: dest = vend - 1, src = vend - 2
+    // the forward sweep's header: {row start (2 words), out-degree, -} + f1
+    I4 f0;
+    f0.x = (int32_t)(uint32_t)(uint64_t)o0; f0.y = (int32_t)((uint64_t)o0 >> 32); f0.z = (int32_t)(o1 - o0); f0.w = 0;
+    w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
+    // the sweeps' per-vertex state (:139-141, paf_data.cpp:704-713): pending degrees, d = max() except d[dest] = 0, no best edge; anomaly distance -1 except src = 0
+    w.cnt_tmp[gv] = (int32_t)(o1 - o0);
+    w.cnt_tmp2[gv] = ideg;
+    w.sp_d[gv] = (gv == vend - 1) ? dist_zero() : dist_max();
+    w.sp_best[gv] = -1;
+    w.an[gv] = (gv == vend - 2) ? 0 : -1;
+    if (w.pend) w.pend[gv] = ideg;                                   // (kb_chain's prep wave: in-neighbours still without keys)
+}
+AASM_DEV void sweep_vertex_init(const WS &w, int64_t gv, int32_t ideg) {
+    const int64_t o0 = w.rowptr[gv], o1 = w.rowptr[gv + 1];
+    sweep_vertex_store(w, gv, ideg, o0, o1, fwd_hdr_heads(w, o0, o1), w.voff[w.v_ctg[gv] + 1]);
+}
+
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
@@ -1529,21 +1648,131 @@ AASM_UNROLL
         h[2] = w.r_pk[r0 + 1];
     }
     for (int t = 0; t < 3; t++) w.rvh[3 * gv + t] = h[t];
-    // the same for the forward sweep: {row start (2 words), out-degree, -} {-, head 0, head 1, anomaly weight 0 | weight 1 << 8}
-    const int64_t o0 = w.rowptr[gv], o1 = w.rowptr[gv + 1];
-    I4 f0, f1;
-    f0.x = (int32_t)(uint32_t)(uint64_t)o0; f0.y = (int32_t)((uint64_t)o0 >> 32); f0.z = (int32_t)(o1 - o0); f0.w = 0;
-    f1.x = 0; f1.y = (o1 > o0) ? w.e_col[o0] : 0; f1.z = (o1 > o0 + 1) ? w.e_col[o0 + 1] : 0;
-    f1.w = ((o1 > o0) ? (w.e_fl[o0] & 3) : 0) | (((o1 > o0 + 1) ? (w.e_fl[o0 + 1] & 3) : 0) << 8);
-    w.fvh[2 * gv] = f0; w.fvh[2 * gv + 1] = f1;
-    // the sweeps' per-vertex state (:139-141, paf_data.cpp:704-713): pending degrees, d = max() except d[dest] = 0, no best edge; anomaly distance -1 except src = 0
-    const int64_t vend = w.voff[w.v_ctg[gv] + 1];                    // dest = vend - 1, src = vend - 2
-    w.cnt_tmp[gv] = (int32_t)(o1 - o0);
-    w.cnt_tmp2[gv] = (int32_t)(r1 - r0);
-    w.sp_d[gv] = (gv == vend - 1) ? dist_zero() : dist_max();
-    w.sp_best[gv] = -1;
-    w.an[gv] = (gv == vend - 2) ? 0 : -1;
-    if (w.pend) w.pend[gv] = (int32_t)(r1 - r0);                    // (kb_chain's prep wave: in-neighbours still without keys)
+    sweep_vertex_init(w, gv, (int32_t)(r1 - r0));
+}
+
+// ====================================================================================
+// K4 rows + reversed CSR + sweep headers of ONE contig in one workgroup (kb_graph_build)
+// ====================================================================================
+// Sparse batches whose contigs are all small (a 1 000-record contig: ~1 400 vertices, ~3 000 edges).  The launches this replaces -
+// kb_row_fill (one global atomic per edge on indeg), the scan of indeg, kb_rev_fill (one more global atomic per edge and the
+// entries in landing order through r_e / tmp_pk), kb_rev_place, kb_rev_hdr - were 1.75 ms of a 12.1 ms step at 5 000 contigs and
+// a chain of six launches for a single contig.  Nothing in them crosses a contig: an in-list holds edges of its own contig and
+// a contig's in-lists occupy exactly its edge range (rptr[vb] = rowptr[vb]).  So a workgroup takes a contig and keeps the
+// counters in LDS:
+//   1  rows as kb_row_fill writes them, a lane per candidate edge (row_fill_tile_par), the in-degree counts by LDS atomics;
+//   2  in-list starts: a workgroup scan of the counts (rptr = the contig's edge base + the local start);
+//   3  every edge notes {contig-local edge id, source} in its head's list - LDS, landing order (a lane per edge: step 1 left the sources in LDS);
+//   4  every list entry finds its place (the number of smaller edge ids in its list - they are distinct -, k_shortest_walks.hpp:180-183:
+//      ascending (source, list position)) and writes its 16-byte record there, the first two of a list into the vertex header too;
+//   5  the headers and the sweeps' state per vertex (kb_rev_hdr's).
+// r_pk / rvh / fvh / rptr and the state arrays come out exactly as from the launches above.
+#define GB_TPB 256
+#define GB_U 4                           // list entries / vertices of a thread whose loads leave together (steps 4 and 5)
+#define GB_MAXV 1792
+#define GB_MAXE 4096                     // (both far below 65 536: an entry is edge id | source << 16)
+#define AASM_GB_LDS_BYTES (GB_MAXV * 4 + (GB_MAXV + 4) * 4 + 16 * 4 + (GB_TPB / 64) * (AASM_WAVE_MAX + 1) * 4 + GB_MAXE * 6)
+struct GbLds { int32_t cnt[GB_MAXV]; int32_t rp[GB_MAXV + 4]; int32_t aux[16]; int32_t P[GB_TPB / 64][AASM_WAVE_MAX + 1]; uint32_t ks[GB_MAXE]; uint16_t src[GB_MAXE]; };
+static_assert(sizeof(GbLds) <= AASM_GB_LDS_BYTES, "LDS budget");
+AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup per contig
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    GbLds *L = (GbLds *)k.lds;
+    const int64_t vb = w.voff[c], eb = w.rowptr[vb];
+    const int64_t cb = w.rec_off[c] - w.R0, cN = w.rec_off[c + 1] - w.rec_off[c];
+    const int32_t E = (int32_t)(w.rowptr[vb + V] - eb);
+    const int nth = k.nthreads, tid = k.tid;
+    const int nw = nth / AASM_WAVE, wv = tid / AASM_WAVE;            // (the host emulation: one thread, one wave of one lane)
+    for (int32_t v = tid; v < V; v += nth) L->cnt[v] = 0;
+    block_barrier();
+    KPROF_DECL;
+    KPROF_START();
+    // ---- 1: rows (paf_data.cpp:531-696), a tile of AASM_WAVE vertices per wave and turn
+    for (int64_t t0 = (int64_t)wv * AASM_WAVE; t0 < V; t0 += (int64_t)nw * AASM_WAVE) row_fill_tile_par<true>(w, k.lane, vb + t0, vb + V, L->cnt, L->P[wv], L->src, eb, c, cb, cN, V, vb);
+    block_barrier();                                                 // (the rows are read again below: workgroup-scope release / acquire)
+    KPROF_STAMP(0);
+    // ---- 2: in-list starts
+    {
+        const int32_t K = (int32_t)((V + nth - 1) / nth);
+        const int32_t a0 = tid * K < (int32_t)V ? tid * K : (int32_t)V, a1 = a0 + K < (int32_t)V ? a0 + K : (int32_t)V;
+        int32_t sum = 0;
+        for (int32_t v = a0; v < a1; v++) sum += L->cnt[v];
+        const int32_t incl = wave_incl_add(sum);
+        if (k.lane == AASM_WAVE - 1) L->aux[wv] = incl;
+        block_barrier();
+        int32_t base = incl - sum;
+        for (int i = 0; i < wv; i++) base += L->aux[i];
+        for (int32_t v = a0; v < a1; v++) { const int32_t d = L->cnt[v]; L->rp[v] = base; L->cnt[v] = 0; base += d; }   // (cnt: the cursors of step 3)
+        if (tid == 0) { L->rp[V] = E; w.rptr[vb + V] = eb + E; }     // (= the next contig's first start: the same value from both)
+        block_barrier();
+    }
+    KPROF_STAMP(1);
+    // ---- 3: the edges into their heads' lists
+    for (int32_t el = tid; el < E; el += nth) {
+        const int32_t hv = w.e_col[eb + el];
+        const int32_t cur = atomic_add(&L->cnt[hv], (int32_t)1);
+        L->ks[L->rp[hv] + cur] = (uint32_t)el | ((uint32_t)L->src[el] << 16);
+    }
+    block_barrier();
+    KPROF_STAMP(2);
+    // ---- 4: list order, records, the two header records
+    // (GB_U entries of a thread at a time: their loads leave together - one round trip for the four, where a loop over single entries
+    // waits for each one's loads behind the stores of the entry before)
+    for (int32_t p0 = tid; p0 < E; p0 += GB_U * nth) {
+        uint32_t en[GB_U]; int32_t hv[GB_U], wr[GB_U]; int64_t wq[GB_U]; uint8_t fl[GB_U];
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) { const int32_t p = p0 + i * nth; en[i] = p < E ? L->ks[p] : 0u; }
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) {
+            const int64_t e = eb + (en[i] & 0xffffu);
+            const bool in = p0 + i * nth < E;
+            hv[i] = in ? w.e_col[e] : 0; wq[i] = in ? w.e_wq[e] : 0; wr[i] = in ? w.e_wr[e] : 0; fl[i] = in ? w.e_fl[e] : 0;
+        }
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) {
+            if (p0 + i * nth >= E) break;
+            const uint32_t key = en[i] & 0xffffu;
+            const I4 rec = pack_in_edge((int32_t)(en[i] >> 16), wq[i], wr[i], fl[i]);
+            const int32_t l0 = L->rp[hv[i]], l1 = L->rp[hv[i] + 1];
+            int32_t rank = 0, j = l0;
+            for (; j + 4 <= l1; j += 4) {
+                const uint32_t k0 = L->ks[j] & 0xffffu, k1 = L->ks[j + 1] & 0xffffu, k2 = L->ks[j + 2] & 0xffffu, k3 = L->ks[j + 3] & 0xffffu;
+                rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
+            }
+            for (; j < l1; j++) rank += ((L->ks[j] & 0xffffu) < key) ? 1 : 0;
+            w.r_pk[eb + l0 + rank] = rec;
+            if (rank < 2) w.rvh[3 * (vb + hv[i]) + 1 + rank] = rec;
+        }
+    }
+    KPROF_STAMP(3);
+    // ---- 5: headers + state (kb_rev_hdr)
+    for (int32_t v0 = tid; v0 < V; v0 += GB_U * nth) {
+        int64_t o0[GB_U], o1[GB_U];
+        I4 f1[GB_U];
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) { const int32_t v = v0 + i * nth; const bool in = v < V; o0[i] = in ? w.rowptr[vb + v] : 0; o1[i] = in ? w.rowptr[vb + v + 1] : 0; }
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) f1[i] = fwd_hdr_heads(w, o0[i], o1[i]);
+        AASM_UNROLL
+        for (int i = 0; i < GB_U; i++) {
+            const int32_t v = v0 + i * nth;
+            if (v >= V) break;
+            const int64_t gv = vb + v;
+            const int32_t ideg = L->rp[v + 1] - L->rp[v];
+            const int64_t r0 = eb + L->rp[v];
+            I4 h, z;
+            z.x = z.y = z.z = z.w = 0;
+            h.x = (int32_t)(uint32_t)(uint64_t)r0; h.y = (int32_t)((uint64_t)r0 >> 32); h.z = ideg; h.w = 0;
+            w.rptr[gv] = r0;
+            w.rvh[3 * gv] = h;
+            if (ideg < 1) w.rvh[3 * gv + 1] = z;
+            if (ideg < 2) w.rvh[3 * gv + 2] = z;
+            sweep_vertex_store(w, gv, ideg, o0[i], o1[i], f1[i], vb + V);
+        }
+    }
+    KPROF_STAMP(4);
+    KPROF_FLUSH(w.prof_gb, c, tid);
 }
 
 // Contigs per wave: the graphs are long chains (~1.4 vertices per Kahn level, in-degree ~2), so a wave that
@@ -2025,6 +2254,7 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     if (V == 0) { w.hcap_cnt[c] = 0; return; }
     const int64_t vb = w.voff[c];
     const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
+    atomic_max_i64(&w.counters[CNT_MAXE], E);                        // most edges of a contig (kb_graph_build's lists in LDS)
     if (E > (int64_t)INT32_MAX - 64) { w.status[c] = -5; w.hcap_cnt[c] = 0; return; }   // contig-local edge ids are int32 (AASM_E_OVERFLOW)  (not in the chain class either)
     int64_t I = E - (V - 1);
     if (I < 0) I = 0;
@@ -2208,8 +2438,8 @@ AASM_DEV int32_t heap_insert(HeapState &hs, Spine &sp, int32_t hu, const Dist ke
             if (lane == depth) { my_a = a; my_slot = in_ring ? -1 : (nold < HEAP_OLDN ? nold : -2); }
             if (!in_ring) nold++;
 #endif
-            bool lt = uni(nsum < ksum);
-            if (!lt && uni(nsum == ksum)) lt = uni(key_tie_lt(n, key));             // (the tie order's two 32 x 32 -> 64 multiplies only when the sums are equal: the values are wave-uniform, the branch is scalar)
+            bool lt = wave_any(nsum < ksum);                                        // (wave-uniform values: any lane = every lane)
+            if (!lt && wave_any(nsum == ksum)) lt = wave_any(key_tie_lt(n, key));             // (the tie order's two 32 x 32 -> 64 multiplies only when the sums are equal: the values are wave-uniform, the branch is scalar)
             if (!lt) { a_rank = uni(n.q1.w) & 0xff; break; }                        // the stop node (the new leaf takes its place in lane `depth`)
             a = uni(n.q2.y);                                                        // ->right
             depth++;

@@ -22,7 +22,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_GRAPH, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16
 };
@@ -43,6 +43,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_NSL: kb_nsl(k, w); break;
         case KN_ROW_COUNT: kb_row_count(k, w); break;
         case KN_ROW_FILL: kb_row_fill(k, w); break;
+        case KN_GRAPH: kb_graph_build(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_REV_FILL_W: kb_rev_fill_w(k, w); break;
         case KN_REV_FILL_ORD: case KN_REV_FILL_ORD_S: kb_rev_fill_ord(k, w); break;
@@ -129,7 +130,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 #define CHECK_ALLOC() do { if (be.oom()) return AASM_E_NOMEM; if (be.failed()) return AASM_E_HIP; } while (0)
 
     AZ(status, int32_t, C, "status");
-    AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel");
+    AZ(prof_heap, int64_t, C * 8, "prof_heap"); AZ(prof_sel, int64_t, C * 8, "prof_sel"); AZ(prof_gb, int64_t, C * 8, "prof_gb");
     AZ(counters, int64_t, CNT_N, "counters");
     // every zero-initialised per-contig array of the pipeline, one behind the other: one fill for all of them (they used to be zeroed where
     // they were first needed: five more fill dispatches per step)
@@ -227,12 +228,25 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32_pair(w.hcap_cnt, w.hoff, w.mw_cap, w.mw_off, C);
         int64_t et_mv[8];
-        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN, w.counters + CNT_MIDV}, et_mv);
-        const int64_t ET = et_mv[0], MAXV_OVER = et_mv[1];            // (MAXV_OVER: 0, or the largest contig of more than REV_ORD_MAXV vertices)
+        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN, w.counters + CNT_MAXE}, et_mv);
+        const int64_t ET = et_mv[0], MAXV = et_mv[1], MAXE = et_mv[7];   // (most vertices / edges of one contig)
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
+        A(rptr, int64_t, VT + 1, "rptr"); A(r_pk, I4, ET, "r_pk");
+        A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
+        A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
+        if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); }
+        // sparse, every contig small: rows, reversed CSR and the sweeps' headers of a contig by ONE workgroup (kb_graph_build)
+        const bool one_wg = ET <= 6 * VT && MAXV <= GB_MAXV && MAXE <= GB_MAXE && !(opts.reserved[0] & 0x10000);   // (bit 16: the separate launches, for tests and probes)
+        if (one_wg) {
+            CHECK_ALLOC();
+            be.launch(KN_GRAPH, C, GB_TPB, w);
+            be.phase_end(AASM_PH_EDGES);
+            be.phase_begin(AASM_PH_REVCSR);
+            be.phase_end(AASM_PH_REVCSR);
+        } else {
         AZ(indeg, int32_t, VT, "indeg"); AZ(rcur, int32_t, VT, "rcur");   // (two fills in one)
         CHECK_ALLOC();
         be.launch(KN_ROW_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
@@ -240,24 +254,20 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
 
         // ---- reversed CSR
         be.phase_begin(AASM_PH_REVCSR);
-        A(rptr, int64_t, VT + 1, "rptr");
-        A(r_e, int32_t, ET, "r_e"); A(r_pk, I4, ET, "r_pk"); A(tmp_pk, I4, ET, "tmp_pk");
+        A(r_e, int32_t, ET, "r_e"); A(tmp_pk, I4, ET, "tmp_pk");
         CHECK_ALLOC();
         be.scan_i32(w.indeg, VT, w.rptr);
         // dense, no giant contig: the in-lists in order from one pass per contig (every contig of <= REV_ORD_MIDV vertices - C5's have 2 500 -: the
         // launch with 6.7 KB of LDS counters instead of 25 KB, i.e. 6 waves per SIMD instead of 2)
-        if (ET > 6 * VT && MAXV_OVER == 0) be.launch(et_mv[7] == 0 ? KN_REV_FILL_ORD_S : KN_REV_FILL_ORD, C, AASM_WAVE, w);
+        if (ET > 6 * VT && MAXV <= REV_ORD_MAXV) be.launch(MAXV <= REV_ORD_MIDV ? KN_REV_FILL_ORD_S : KN_REV_FILL_ORD, C, AASM_WAVE, w);
         else {
             if (ET > 6 * VT) be.launch(KN_REV_FILL_W, cdiv(VT, AASM_WAVE), AASM_WAVE, w);   // dense: lanes over the edges of 64 rows
             else be.launch(KN_REV_FILL, cdiv(VT, 256), 256, w);
             be.launch(KN_SORT_ROWS_REV, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         }
-        A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
-        A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
-        if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); }
-        CHECK_ALLOC();
         be.launch(KN_REV_HDR, cdiv(VT, 256), 256, w);
         be.phase_end(AASM_PH_REVCSR);
+        }
 
         // ---- K6 / K5 sweeps.  The forward sweep + the topologically ordered CSR copy only feed
         // K9, so they run on a second stream beside rev_sweep -> heaps -> enumeration.

@@ -98,6 +98,8 @@ typedef struct aasm_opts {
                                 *            bits 8-15: 1 = the several-waves heap kernel launched in input order, a block per contig of
                                 *            the batch (default: a block per contig of its class, largest node bound first); 4 / 8 / 16 =
                                 *            that many waves per contig of the class (default: by how many contigs share the chip)
+                                *            bit 16: rows, reversed CSR and sweep headers by the separate launches even where every contig is small
+                                *            enough for one workgroup to build its graph (aasm_k46_graph)
                                 * [1] > 0:   pretend that contig ranges longer than this do not fit in device
                                 *            memory (exercises the range split of aasm_solve_batch)
                                 * [2] bit 0: inject one failing kernel launch (must surface as AASM_E_HIP);

@@ -86,6 +86,27 @@ def test_chain_class_forms(T, case, chain):
         assert n_class == int(((sizes >= -(-int(sizes.sum()) // len(sizes))) & (sizes > 1)).sum())
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[4], CASES[5], CASES[7], CASES[8], CASES[14]], ids=lambda c: "graph_c%dx%d_s%d%s" % (c[0], c[1], c[2], "_nsl" if c[8] else ""))
+def test_graph_build_forms(T, case):
+    """Rows, reversed CSR and the sweeps' vertex headers of a contig by one workgroup (kb_graph_build: the default where the batch is
+    sparse and every contig has at most 1 792 vertices and 4 096 edges) against the separate launches (row_fill, scan, rev_fill,
+    rev_place, rev_hdr): the outputs, and every array the later kernels read, byte for byte."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    names = [("csr_col", np.int32), ("csr_w_qry", np.int64), ("csr_w_ref", np.int32), ("csr_w_flags", np.uint8), ("rptr", np.int64), ("r_pk", np.int32),
+             ("rvh", np.int32), ("fvh", np.int32), ("cnt_tmp2", np.int32)]
+    got = {}
+    for form in (False, True):
+        out = T.emul_solve(hb, K, nsl, graph_launches=form)
+        assert T.diff_outputs(want, out) == []
+        assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+        got[form] = {n: T.emul_debug(n, dt).copy() for n, dt in names}
+        assert (T.emul().emul_debug_fetch(b"indeg", None, 0) >= 0) == form       # (the one-workgroup form has no global in-degree counters)
+    for n, _ in names:
+        assert np.array_equal(got[False][n], got[True][n]), n
+
+
 def test_all_pool_overflow_reruns_the_pick(T):
     """Every record duplicated: hundreds of co-optimal walks per contig, the `.all` lists hold 130x the records - far beyond the pool the
     first pick is given (R + 1 024 elements).  The pick is re-run with the exact size (one read-back brings the demand and the output

@@ -53,6 +53,36 @@ def test_hip_intermediates_match_oracle(T, case):
     res.close(); db.close()
 
 
+# ---- rows + reversed CSR + sweep headers of a contig by one workgroup (aasm_k46_graph): the default for sparse batches whose contigs all have
+# at most 1 792 vertices and 4 096 edges - most sparse cases above; here against the separate launches (row_fill, scan, rev_fill, rev_place, rev_hdr)
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9], CASES[12], (5, 1250, 3, 4, False, 0, False, False, False), (3, 1200, 8, 4, False, 7, True, False, True)], ids=_id)
+def test_graph_build_forms(T, case):
+    """Outputs and intermediates against the oracle in both forms, and every array the later kernels read byte for byte between them
+    (in-lists in list order, the two header records, in-list starts, the forward headers, the pending counts)."""
+    nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
+    api = T.api()
+    hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
+    want = T.oracle_solve(hb, K, nsl)
+    names = [("csr_col", np.int32), ("csr_w_qry", np.int64), ("csr_w_ref", np.int32), ("csr_w_flags", np.uint8), ("rptr", np.int64), ("r_pk", np.int32),
+             ("rvh", np.int32), ("fvh", np.int32), ("cnt_tmp2", np.int32)]
+    db = api.DeviceBatch(hb)
+    kept = {}
+    for form in (False, True):
+        res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, graph_launches=form)
+        assert T.diff_outputs(want, res.fetch()) == []
+        assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+        kept[form] = {n: res.debug(n, dt).copy() for n, dt in names}
+        st = res.stats()
+        kept[form]["sizes"] = (st["n_edges"], st["n_vertices"])
+        res.close()
+    db.close()
+    ET, VT = kept[True]["sizes"]
+    for n, _ in names:
+        a, b = kept[False][n], kept[True][n]
+        m = {"rptr": VT + 1, "r_pk": 4 * ET, "rvh": 12 * VT, "fvh": 8 * VT, "cnt_tmp2": VT}.get(n, ET)   # (allocations are padded: the cells the kernels own)
+        assert np.array_equal(a[:m], b[:m]), n
+
+
 # ---- the chain class (aasm_k67_chain: sweep, pre-pass and heaps of a contig beside each other).  By default it takes every sparse
 # contig of a batch of <= 1 280 contigs - i.e. every sparse case above - and the long tail of bigger ones; here the other forms
 @pytest.mark.parametrize("chain", ["none", "half", "all"])

@@ -9,5 +9,5 @@ rows = rows[starts[-1]:]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    if d >= 0.05:
+    if d >= 0.0:
         print("%8.3f %8.3f  %7.3f ms  q%s  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6, d, r.get("Queue_Id", "?"), r["Kernel_Name"][:50]))
