@@ -62,7 +62,7 @@ AASM_DEF_KERNEL(aasm_k2_vfill_slot, KN_VFILL_SLOT, 256)
 AASM_DEF_KERNEL(aasm_k4_nsl, KN_NSL, 256)
 AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
-AASM_DEF_KERNEL_LDS(aasm_k46_graph, KN_GRAPH, GB_TPB, AASM_GB_LDS_BYTES, 2)   // rows + reversed CSR + sweep headers of one contig: 30 KB of LDS, 5 workgroups (20 waves) per CU
+AASM_DEF_KERNEL_LDS(aasm_k46_graph, KN_GRAPH, GB_TPB, AASM_GB_LDS_BYTES, 5)   // rows + reversed CSR + sweep headers of one contig: 31.8 KB of LDS, 5 workgroups (20 waves) per CU
 AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_w, KN_REV_FILL_W, 64, AASM_REVF_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_ord, KN_REV_FILL_ORD, 64, AASM_REVO_LDS_BYTES, 2)   // 25 KB of LDS per block: 6 blocks per CU, i.e. at most 2 waves per SIMD

@@ -1125,10 +1125,19 @@ AASM_DEV void kb_row_count(const KCtx &k, const WS &w) {            // thread pe
 }
 
 // get_score (paf_data.cpp:449-521).  lft = this row's vertex, rht = (k,k) or the pair in slot `ps`.
-AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, int64_t &wq, int32_t &wr, uint8_t &fl) {
-    const int64_t gl = r.b + r.j, gr = r.b + kk;
-    int64_t l_qe = w.s_qe[gl], l_re = w.s_re[gl];
-    const int64_t l_rs = (r.slot < 0) ? w.s_rs[gl] : w.ov_str[r.slot];
+struct EdgeL { int64_t qe, re, rs; int32_t chr; int32_t f; };         // what the score reads of the row's own record (the same for every edge of the row)
+AASM_DEV EdgeL edge_left(const WS &w, const RowPlan &r) {
+    const int64_t gl = r.b + r.j;
+    EdgeL l;
+    l.qe = w.s_qe[gl]; l.re = w.s_re[gl];
+    l.rs = (r.slot < 0) ? w.s_rs[gl] : w.ov_str[r.slot];
+    l.f = w.s_fl[gl] & 1; l.chr = w.s_chr[gl];
+    return l;
+}
+AASM_DEV void score_edge_l(const WS &w, const EdgeL &l, int64_t b, int64_t kk, int64_t ps, int64_t &wq, int32_t &wr, uint8_t &fl) {
+    const int64_t gr = b + kk;
+    int64_t l_qe = l.qe, l_re = l.re;
+    const int64_t l_rs = l.rs;
     int64_t r_qs, r_rs;
     const int64_t r_re = w.s_re[gr];
     if (ps >= 0) { l_qe = w.ov_peq[ps]; l_re = w.ov_per[ps]; r_qs = w.ov_stq[ps]; r_rs = w.ov_str[ps]; }   // :460-465
@@ -1136,8 +1145,9 @@ AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, 
     const int64_t qry_diff = r_qs - l_qe - 1;
     int64_t ref_diff = 0;
     int anom = 0;
-    const bool lf = w.s_fl[gl] & 1, rf = w.s_fl[gr] & 1;
-    const bool same_chr = w.s_chr[gl] == w.s_chr[gr];
+    const uint8_t rfl = w.s_fl[gr];
+    const bool lf = l.f != 0, rf = rfl & 1;
+    const bool same_chr = l.chr == w.s_chr[gr];
     if (same_chr && lf == rf) {                                                     // :475-490
         const int64_t gap = lf ? r_rs - (l_re + 1) : l_re - (r_rs + 1);
         ref_diff += gap < 0 ? -gap * AASM_REF_NEGATIVE_PENALTY : gap;
@@ -1153,7 +1163,10 @@ AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, 
         ref_diff = AASM_SV_TRANS_PENALTY;
     }
     wq = qry_diff; wr = (int32_t)ref_diff;
-    fl = edge_flags(anom, (w.s_fl[gr] & 2) ? 1 : 0, 1);                             // :518-519
+    fl = edge_flags(anom, (rfl & 2) ? 1 : 0, 1);                                    // :518-519
+}
+AASM_DEV void score_edge(const WS &w, const RowPlan &r, int64_t kk, int64_t ps, int64_t &wq, int32_t &wr, uint8_t &fl) {
+    score_edge_l(w, edge_left(w, r), r.b, kk, ps, wq, wr, fl);
 }
 
 // (ib: the in-degree counters of the row's contig - w.indeg + vb, or kb_graph_build's copy in LDS)
@@ -1314,6 +1327,10 @@ template <bool LDSI> AASM_DEV void row_fill_tile_par(const WS &w, int lane, int6
     const int32_t my_p0 = incl - ncand;
     const int64_t e_row = act ? w.rowptr[gv] : 0;
     const int32_t hd = (r.kind & 3) | (r.has_dest ? 4 : 0);
+    EdgeL el;                                                        // the row's own record, once per row (not once per candidate)
+    el.qe = el.re = el.rs = 0; el.chr = 0; el.f = 0;
+    if (act && d > 0 && r.kind == 0) el = edge_left(w, r);
+    const int32_t el_cf = (el.chr << 1) | el.f;
     int32_t carry = 0;                                               // candidates of MY row that passed in earlier turns
     for (int32_t c0 = 0; c0 < M; c0 += AASM_WAVE) {
         const int32_t g = c0 + lane;
@@ -1331,6 +1348,9 @@ template <bool LDSI> AASM_DEV void row_fill_tile_par(const WS &w, int lane, int6
         q.nx0 = wave_shfl_idx((int32_t)r.nx0, rr); q.nx1 = wave_shfl_idx((int32_t)r.nx1, rr);
         q.stq = wave_shfl_idx(r.stq, rr);
         const int64_t q_e = wave_shfl_idx(e_row, rr);
+        EdgeL ql;
+        ql.qe = wave_shfl_idx(el.qe, rr); ql.re = wave_shfl_idx(el.re, rr); ql.rs = wave_shfl_idx(el.rs, rr);
+        { const int32_t cf = wave_shfl_idx(el_cf, rr); ql.chr = cf >> 1; ql.f = cf & 1; }
         const int32_t q_p0 = wave_shfl_idx(my_p0, rr), q_carry = wave_shfl_idx(carry, rr);
         const int32_t jc = g - q_p0;                                 // candidate jc of its row
         // which candidate
@@ -1348,11 +1368,11 @@ template <bool LDSI> AASM_DEV void row_fill_tile_par(const WS &w, int lane, int6
             } else if (jc < n_dest + n_ov) {                         // a pair (j, k)
                 const int64_t t = jc - n_dest, sl = q.ov0 + t;
                 col = w.ov_vid[sl];                                  // (the score's operands are fetched whether the pair passes or not: one round trip, not two)
-                score_edge(w, q, q.j + 1 + t, sl, wq, wr, fl);
+                score_edge_l(w, ql, q.b, q.j + 1 + t, sl, wq, wr, fl);
                 ok = col >= 0 && q.stq < w.ov_stq[sl];               // pair_edge_ok (:433-436)
             } else {
                 const int64_t t = jc < n_dest + n_ov + n_dis ? q.dis0 + (jc - n_dest - n_ov) : q.nx0 + (jc - n_dest - n_ov - n_dis);
-                score_edge(w, q, t, -1, wq, wr, fl);
+                score_edge_l(w, ql, q.b, t, -1, wq, wr, fl);
                 col = (int32_t)t;
             }
         }
@@ -1662,7 +1682,7 @@ AASM_UNROLL
 // counters in LDS:
 //   1  rows as kb_row_fill writes them, a lane per candidate edge (row_fill_tile_par), the in-degree counts by LDS atomics;
 //   2  in-list starts: a workgroup scan of the counts (rptr = the contig's edge base + the local start);
-//   3  every edge notes {contig-local edge id, source} in its head's list - LDS, landing order (a lane per edge: step 1 left the sources in LDS);
+//   3  every edge notes its contig-local id in its head's list - LDS, landing order (a lane per edge: step 1 left the sources in LDS);
 //   4  every list entry finds its place (the number of smaller edge ids in its list - they are distinct -, k_shortest_walks.hpp:180-183:
 //      ascending (source, list position)) and writes its 16-byte record there, the first two of a list into the vertex header too;
 //   5  the headers and the sweeps' state per vertex (kb_rev_hdr's).
@@ -1670,9 +1690,9 @@ AASM_UNROLL
 #define GB_TPB 256
 #define GB_U 4                           // list entries / vertices of a thread whose loads leave together (steps 4 and 5)
 #define GB_MAXV 1792
-#define GB_MAXE 4096                     // (both far below 65 536: an entry is edge id | source << 16)
-#define AASM_GB_LDS_BYTES (GB_MAXV * 4 + (GB_MAXV + 4) * 4 + 16 * 4 + (GB_TPB / 64) * (AASM_WAVE_MAX + 1) * 4 + GB_MAXE * 6)
-struct GbLds { int32_t cnt[GB_MAXV]; int32_t rp[GB_MAXV + 4]; int32_t aux[16]; int32_t P[GB_TPB / 64][AASM_WAVE_MAX + 1]; uint32_t ks[GB_MAXE]; uint16_t src[GB_MAXE]; };
+#define GB_MAXE 4096                     // (both far below 65 536: edge ids and sources are 16-bit words in LDS)
+#define AASM_GB_LDS_BYTES (GB_MAXV * 4 + (GB_MAXV + 4) * 4 + 16 * 4 + (GB_TPB / 64) * (AASM_WAVE_MAX + 1) * 4 + GB_MAXE * 4)
+struct GbLds { int32_t cnt[GB_MAXV]; int32_t rp[GB_MAXV + 4]; int32_t aux[16]; int32_t P[GB_TPB / 64][AASM_WAVE_MAX + 1]; uint16_t ks[GB_MAXE]; uint16_t src[GB_MAXE]; };   // 31.8 KB: five workgroups per CU
 static_assert(sizeof(GbLds) <= AASM_GB_LDS_BYTES, "LDS budget");
 AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup per contig
     const int64_t c = k.bid;
@@ -1712,7 +1732,7 @@ AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup
     for (int32_t el = tid; el < E; el += nth) {
         const int32_t hv = w.e_col[eb + el];
         const int32_t cur = atomic_add(&L->cnt[hv], (int32_t)1);
-        L->ks[L->rp[hv] + cur] = (uint32_t)el | ((uint32_t)L->src[el] << 16);
+        L->ks[L->rp[hv] + cur] = (uint16_t)el;
     }
     block_barrier();
     KPROF_STAMP(2);
@@ -1720,9 +1740,9 @@ AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup
     // (GB_U entries of a thread at a time: their loads leave together - one round trip for the four, where a loop over single entries
     // waits for each one's loads behind the stores of the entry before)
     for (int32_t p0 = tid; p0 < E; p0 += GB_U * nth) {
-        uint32_t en[GB_U]; int32_t hv[GB_U], wr[GB_U]; int64_t wq[GB_U]; uint8_t fl[GB_U];
+        uint32_t en[GB_U]; int32_t hv[GB_U], wr[GB_U]; int64_t wq[GB_U]; uint8_t fl[GB_U];   // en: edge id | source << 16
         AASM_UNROLL
-        for (int i = 0; i < GB_U; i++) { const int32_t p = p0 + i * nth; en[i] = p < E ? L->ks[p] : 0u; }
+        for (int i = 0; i < GB_U; i++) { const int32_t p = p0 + i * nth; en[i] = 0u; if (p < E) { const uint32_t el = L->ks[p]; en[i] = el | ((uint32_t)L->src[el] << 16); } }
         AASM_UNROLL
         for (int i = 0; i < GB_U; i++) {
             const int64_t e = eb + (en[i] & 0xffffu);
@@ -1737,10 +1757,10 @@ AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup
             const int32_t l0 = L->rp[hv[i]], l1 = L->rp[hv[i] + 1];
             int32_t rank = 0, j = l0;
             for (; j + 4 <= l1; j += 4) {
-                const uint32_t k0 = L->ks[j] & 0xffffu, k1 = L->ks[j + 1] & 0xffffu, k2 = L->ks[j + 2] & 0xffffu, k3 = L->ks[j + 3] & 0xffffu;
+                const uint32_t k0 = L->ks[j], k1 = L->ks[j + 1], k2 = L->ks[j + 2], k3 = L->ks[j + 3];
                 rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
             }
-            for (; j < l1; j++) rank += ((L->ks[j] & 0xffffu) < key) ? 1 : 0;
+            for (; j < l1; j++) rank += (L->ks[j] < key) ? 1 : 0;
             w.r_pk[eb + l0 + rank] = rec;
             if (rank < 2) w.rvh[3 * (vb + hv[i]) + 1 + rank] = rec;
         }
