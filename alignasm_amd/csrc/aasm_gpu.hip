@@ -63,6 +63,7 @@ AASM_DEF_KERNEL(aasm_k4_nsl, KN_NSL, 256)
 AASM_DEF_KERNEL(aasm_k4_row_count, KN_ROW_COUNT, 256)
 AASM_DEF_KERNEL(aasm_k4_row_fill, KN_ROW_FILL, 64)
 AASM_DEF_KERNEL_LDS(aasm_k46_graph, KN_GRAPH, GB_TPB, AASM_GB_LDS_BYTES, 5)   // rows + reversed CSR + sweep headers of one contig: 31.8 KB of LDS, 5 workgroups (20 waves) per CU
+AASM_DEF_KERNEL_LDS(aasm_k46_graph_l, KN_GRAPH_L, GB_TPB, AASM_GB_LDS_BYTES_T(GB_MAXV_L, GB_MAXE_L), 2)   // contigs of up to 3 584 vertices / 8 192 edges: 62 KB, two workgroups per CU
 AASM_DEF_KERNEL(aasm_k6_rev_fill, KN_REV_FILL, 256)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_w, KN_REV_FILL_W, 64, AASM_REVF_LDS_BYTES, 8)
 AASM_DEF_KERNEL_LDS(aasm_k6_rev_fill_ord, KN_REV_FILL_ORD, 64, AASM_REVO_LDS_BYTES, 2)   // 25 KB of LDS per block: 6 blocks per CU, i.e. at most 2 waves per SIMD
@@ -473,8 +474,8 @@ __global__ void __launch_bounds__(1024) aasm_scan_small(const int32_t *in_a, int
     if (threadIdx.x == 0) { out_a[n] = sh_carry[0]; if (in_b) out_b[n] = sh_carry[1]; }
 }
 
-// ---- scalar read-back: up to eight device words -> the host-mapped pinned words, ONE launch (it was a copyBuffer per word) ----
-struct ScalarSrc { const int64_t *p[8]; };
+// ---- scalar read-back: up to twelve device words -> the host-mapped pinned words, ONE launch (it was a copyBuffer per word) ----
+struct ScalarSrc { const int64_t *p[12]; };
 __global__ void aasm_read_scalars(ScalarSrc src, int n, int64_t *dst) {
     const int i = (int)threadIdx.x;
     if (i < n) __hip_atomic_store(dst + i, *src.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -676,7 +677,7 @@ struct GpuBackend {
             L(KN_CS_RANGES, aasm_k0_cs_ranges) L(KN_SORT, aasm_k1_sort) L(KN_SORT_RANK, aasm_k1_sort_rank) L(KN_SORT_FIX, aasm_k1_sort_fix) L(KN_GATHER_PARTS, aasm_k1_gather_parts)
             L(KN_OV_COUNT, aasm_k2_ov_count) L(KN_OV_MERGE, aasm_k2_ov_merge) L(KN_VCOUNT, aasm_k2_vcount)
             L(KN_VFILL_REC, aasm_k2_vfill_rec) L(KN_VFILL_SLOT, aasm_k2_vfill_slot) L(KN_NSL, aasm_k4_nsl)
-            L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_GRAPH, aasm_k46_graph) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord) L(KN_REV_FILL_ORD_S, aasm_k6_rev_fill_ord_s)
+            L(KN_ROW_COUNT, aasm_k4_row_count) L(KN_ROW_FILL, aasm_k4_row_fill) L(KN_GRAPH, aasm_k46_graph) L(KN_GRAPH_L, aasm_k46_graph_l) L(KN_REV_FILL, aasm_k6_rev_fill) L(KN_REV_FILL_W, aasm_k6_rev_fill_w) L(KN_REV_FILL_ORD, aasm_k6_rev_fill_ord) L(KN_REV_FILL_ORD_S, aasm_k6_rev_fill_ord_s)
             L(KN_SORT_ROWS_REV, aasm_k6_rev_place) L(KN_REV_HDR, aasm_k6_rev_hdr) L(KN_REV_SWEEP, aasm_k6_rev_sweep) L(KN_FWD_SWEEP, aasm_k5_fwd_sweep) L(KN_REV_SWEEP_G, aasm_k6_rev_sweep_g) L(KN_FWD_SWEEP_G, aasm_k5_fwd_sweep_g)
             L(KN_CHILDREN, aasm_k7_children)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
@@ -736,8 +737,8 @@ struct GpuBackend {
         if (fail) return;
         ScalarSrc src;
         int i = 0;
-        for (auto p : ps) { if (i < 8) src.p[i] = p; i++; }
-        for (int j = i; j < 8; j++) src.p[j] = nullptr;
+        for (auto p : ps) { if (i < 12) src.p[i] = p; i++; }
+        for (int j = i; j < 12; j++) src.p[j] = nullptr;
         hipLaunchKernelGGL(aasm_read_scalars, dim3(1), dim3(64), 0, stream, src, n, cx.pinned_dev);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(stream);

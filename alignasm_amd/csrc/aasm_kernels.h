@@ -101,6 +101,7 @@ struct WS {
     // ---- status / counters
     int32_t *status;
     int64_t *counters;
+    int32_t *gb_flag; int32_t gb_off;  // per contig: 1 / 2 = its rows, reversed CSR and sweep headers come from one workgroup (kb_graph_build, the small / the large form); gb_off: nobody's (tests, probes)
     int64_t *prof_heap, *prof_sel, *prof_gb;    // [C * 8] cycle sums per section (diagnostic build only)
     // ---- K7 pre-pass: compacted sidetrack keys and the packed per-vertex header
     Dist *st_cost;                       // per vertex, at the front of its CSR row: its sidetrack keys in list order, edge head in .pad
@@ -131,11 +132,12 @@ struct WS {
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
 };
 
-enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_MAXE, CNT_N };
+enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_GB_S, CNT_GB_L, CNT_GB_REST, CNT_N };
 
 AASM_DEV void set_status(const WS &w, int64_t c, int code) { if (w.status[c] == 0) w.status[c] = code; }
 // the chain class (kb_chain): contigs whose sweep, K7 pre-pass and heaps run in one workgroup; the one-stage kernels skip them
 AASM_DEV bool in_chain_class(const WS &w, int64_t c) { return w.chain_flag != nullptr && w.chain_flag[c] != 0; }
+AASM_DEV bool in_graph_class(const WS &w, int64_t c) { return w.gb_flag && w.gb_flag[c] != 0; }   // (built by kb_graph_build: the separate launches leave the contig alone)
 // Input range the narrowed fields are exact for (aasm_dev.h: Dist counters and HNode key counters are
 // int32, e_wr is int32): coordinates in [0, 2^40), so that a path sum over < 2^20 edges of
 // 2 * coordinate stays far inside int64 and every per-edge reference weight fits int32 after the
@@ -1228,7 +1230,7 @@ template <int G> AASM_DEV void fill_row_part(const WS &w, const RowPlan &r, int6
 // one tile of AASM_WAVE rows [gv0, gv0 + AASM_WAVE) below gv_end; LDSI: the in-degree counters of the tile's (one) contig are `lcnt`, in LDS (else w.indeg)
 template <bool LDSI> AASM_DEV void row_fill_tile(const WS &w, int lane, int64_t gv0, int64_t gv_end, int32_t *lcnt) {
     const int64_t gv = gv0 + lane;
-    const bool act = gv < gv_end;
+    const bool act = gv < gv_end && (LDSI || !in_graph_class(w, w.v_ctg[gv]));
     int32_t d = act ? w.deg[gv] : 0;
     RowPlan r;
     if (act && d > 0) r = plan_row(w, gv);
@@ -1405,6 +1407,7 @@ AASM_DEV void kb_rev_fill(const KCtx &k, const WS &w) {             // thread pe
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT) return;
     const int64_t c = w.v_ctg[gv], vb = w.voff[c], e_base = w.rowptr[vb];
+    if (in_graph_class(w, c)) return;
     const int32_t u = (int32_t)(gv - vb);
     const int64_t r0 = w.rowptr[gv], r1 = w.rowptr[gv + 1];
     for (int64_t e0 = r0; e0 < r1; e0 += 4) {                        // four edges per round: heads -> (list start, cursor) -> the two stores
@@ -1525,8 +1528,8 @@ AASM_DEV void kb_rev_fill_ord(const KCtx &k, const WS &w) {         // one wave 
 // so the work is balanced and every entry is one coalesced 16-byte read and one write.  Short lists: kb_rev_hdr.
 #define REV_REG_SORT 8
 #define REVP_KEYS 2048
-struct RevPlaceLds { int64_t ptr[AASM_WAVE_MAX + 1]; int32_t key[REVP_KEYS]; };
-#define AASM_REVP_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REVP_KEYS * 4)
+struct RevPlaceLds { int64_t ptr[AASM_WAVE_MAX + 1]; int32_t key[REVP_KEYS]; uint8_t skip[AASM_WAVE_MAX]; };
+#define AASM_REVP_LDS_BYTES ((AASM_WAVE_MAX + 1) * 8 + REVP_KEYS * 4 + AASM_WAVE_MAX + 8)
 static_assert(sizeof(RevPlaceLds) <= AASM_REVP_LDS_BYTES, "LDS budget");
 // #{j in [a, b) : key[j] < kx}; eight independent reads per wait (a lane's rank loop over a list of a few hundred keys
 // is otherwise one LDS round trip per key)
@@ -1547,7 +1550,9 @@ AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per 
     for (int32_t t = k.lane; t <= nrows; t += AASM_WAVE) L->ptr[t] = w.rptr[row0 + t];
     wave_lds_sync();
     bool any_long = false;
-    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) any_long |= L->ptr[t + 1] - L->ptr[t] > REV_REG_SORT;
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) L->skip[t] = in_graph_class(w, w.v_ctg[row0 + t]) ? 1 : 0;   // (kb_graph_build's lists are in order already)
+    wave_lds_sync();
+    for (int32_t t = k.lane; t < nrows; t += AASM_WAVE) any_long |= !L->skip[t] && L->ptr[t + 1] - L->ptr[t] > REV_REG_SORT;
     if (!wave_any(any_long)) return;
     const int64_t seg0 = L->ptr[0], seg1 = L->ptr[nrows];
     const bool staged = seg1 - seg0 <= REVP_KEYS;
@@ -1560,7 +1565,7 @@ AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per 
         // that the key every lane compares with is ONE address (a broadcast read)
         for (int32_t r = 0; r < nrows; r++) {
             const int64_t p0 = L->ptr[r], len = L->ptr[r + 1] - p0;
-            if (len <= REV_REG_SORT) continue;
+            if (len <= REV_REG_SORT || L->skip[r]) continue;
             for (int64_t a = k.lane; a < len; a += AASM_WAVE) {
                 const int32_t kx = w.r_e[p0 + a];
                 const int32_t rank = rank_below(w.r_e + p0, 0, (int32_t)len, kx);
@@ -1573,7 +1578,7 @@ AASM_DEV void kb_rev_place(const KCtx &k, const WS &w) {            // wave per 
         int32_t lo = 0, hi = nrows;                                  // ptr[lo] <= i < ptr[hi]
         while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L->ptr[mid] <= i) lo = mid; else hi = mid; }
         const int64_t p0 = L->ptr[lo], p1 = L->ptr[lo + 1];
-        if (p1 - p0 <= REV_REG_SORT) continue;
+        if (p1 - p0 <= REV_REG_SORT || L->skip[lo]) continue;
         const int32_t kx = L->key[i - seg0];
         const int32_t rank = rank_below(L->key, (int32_t)(p0 - seg0), (int32_t)(p1 - seg0), kx);
         w.r_pk[p0 + rank] = w.tmp_pk[i];
@@ -1633,7 +1638,7 @@ AASM_DEV void sweep_vertex_init(const WS &w, int64_t gv, int32_t ideg) {
 
 AASM_DEV void kb_rev_hdr(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
-    if (gv >= w.VT) return;
+    if (gv >= w.VT || in_graph_class(w, w.v_ctg[gv])) return;
     const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
     I4 h[3];
     for (int t = 0; t < 3; t++) { h[t].x = h[t].y = h[t].z = h[t].w = 0; }
@@ -1691,13 +1696,18 @@ AASM_UNROLL
 #define GB_U 4                           // list entries / vertices of a thread whose loads leave together (steps 4 and 5)
 #define GB_MAXV 1792
 #define GB_MAXE 4096                     // (both far below 65 536: edge ids and sources are 16-bit words in LDS)
-#define AASM_GB_LDS_BYTES (GB_MAXV * 4 + (GB_MAXV + 4) * 4 + 16 * 4 + (GB_TPB / 64) * (AASM_WAVE_MAX + 1) * 4 + GB_MAXE * 4)
-struct GbLds { int32_t cnt[GB_MAXV]; int32_t rp[GB_MAXV + 4]; int32_t aux[16]; int32_t P[GB_TPB / 64][AASM_WAVE_MAX + 1]; uint16_t ks[GB_MAXE]; uint16_t src[GB_MAXE]; };   // 31.8 KB: five workgroups per CU
-static_assert(sizeof(GbLds) <= AASM_GB_LDS_BYTES, "LDS budget");
+#define GB_MAXV_L 3584                   // ... and the form for contigs of up to ~2 500 records: 62 KB of LDS, two workgroups per CU
+#define GB_MAXE_L 8192
+#define AASM_GB_LDS_BYTES_T(V, E) ((V) * 4 + ((V) + 4) * 4 + 16 * 4 + (GB_TPB / 64) * (AASM_WAVE_MAX + 1) * 4 + (E) * 4)
+#define AASM_GB_LDS_BYTES AASM_GB_LDS_BYTES_T(GB_MAXV, GB_MAXE)
+template <int MV, int ME> struct GbLdsT { int32_t cnt[MV]; int32_t rp[MV + 4]; int32_t aux[16]; int32_t P[GB_TPB / 64][AASM_WAVE_MAX + 1]; uint16_t ks[ME]; uint16_t src[ME]; };   // 31.8 KB: five workgroups per CU
+static_assert(sizeof(GbLdsT<GB_MAXV, GB_MAXE>) <= AASM_GB_LDS_BYTES && sizeof(GbLdsT<GB_MAXV_L, GB_MAXE_L>) <= AASM_GB_LDS_BYTES_T(GB_MAXV_L, GB_MAXE_L), "LDS budget");
+template <int MV, int ME>
 AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup per contig
     const int64_t c = k.bid;
     const int64_t V = w.ctgV[c];
-    if (V == 0) return;
+    if (V == 0 || w.gb_flag[c] != (MV == GB_MAXV ? 1 : 2)) return;   // (a contig of the other form, or of the separate launches)
+    typedef GbLdsT<MV, ME> GbLds;
     GbLds *L = (GbLds *)k.lds;
     const int64_t vb = w.voff[c], eb = w.rowptr[vb];
     const int64_t cb = w.rec_off[c] - w.R0, cN = w.rec_off[c + 1] - w.rec_off[c];
@@ -1723,7 +1733,11 @@ AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup
         block_barrier();
         int32_t base = incl - sum;
         for (int i = 0; i < wv; i++) base += L->aux[i];
-        for (int32_t v = a0; v < a1; v++) { const int32_t d = L->cnt[v]; L->rp[v] = base; L->cnt[v] = 0; base += d; }   // (cnt: the cursors of step 3)
+        for (int32_t v = a0; v < a1; v++) {
+            const int32_t d = L->cnt[v];
+            L->rp[v] = base; L->cnt[v] = 0; base += d;               // (cnt: the cursors of step 3)
+            if (w.indeg) w.indeg[vb + v] = d;                        // (a batch with contigs of the separate launches: their in-list starts come from a scan over everybody's counts)
+        }
         if (tid == 0) { L->rp[V] = E; w.rptr[vb + V] = eb + E; }     // (= the next contig's first start: the same value from both)
         block_barrier();
     }
@@ -2271,10 +2285,16 @@ AASM_DEV void kb_heap_cap(const KCtx &k, const WS &w) {             // thread pe
     const int64_t V = w.ctgV[c];
     w.mw_flag[c] = 0; w.mw_cap[c] = 0; w.mw_lg[c] = 2;
     if (w.chain_flag) w.chain_flag[c] = 0;
+    w.gb_flag[c] = 0;
     if (V == 0) { w.hcap_cnt[c] = 0; return; }
     const int64_t vb = w.voff[c];
     const int64_t E = w.rowptr[vb + V] - w.rowptr[vb];
-    atomic_max_i64(&w.counters[CNT_MAXE], E);                        // most edges of a contig (kb_graph_build's lists in LDS)
+    {   // one workgroup builds the graph of a small contig of a sparse batch (kb_graph_build); everybody else: the separate launches
+        const bool sparse_batch = w.rowptr[w.VT] <= 6 * w.VT;
+        const int32_t f = (w.gb_off || !sparse_batch) ? 0 : (V <= GB_MAXV && E <= GB_MAXE) ? 1 : (V <= GB_MAXV_L && E <= GB_MAXE_L) ? 2 : 0;
+        w.gb_flag[c] = f;
+        atomic_add(&w.counters[f == 1 ? CNT_GB_S : f == 2 ? CNT_GB_L : CNT_GB_REST], (int64_t)1);
+    }
     if (E > (int64_t)INT32_MAX - 64) { w.status[c] = -5; w.hcap_cnt[c] = 0; return; }   // contig-local edge ids are int32 (AASM_E_OVERFLOW)  (not in the chain class either)
     int64_t I = E - (V - 1);
     if (I < 0) I = 0;

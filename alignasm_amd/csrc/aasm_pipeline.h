@@ -22,7 +22,7 @@ namespace aasm {
 
 enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
-    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_GRAPH, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
+    KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_GRAPH, KN_GRAPH_L, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
     KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16
 };
@@ -43,7 +43,8 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_NSL: kb_nsl(k, w); break;
         case KN_ROW_COUNT: kb_row_count(k, w); break;
         case KN_ROW_FILL: kb_row_fill(k, w); break;
-        case KN_GRAPH: kb_graph_build(k, w); break;
+        case KN_GRAPH: kb_graph_build<GB_MAXV, GB_MAXE>(k, w); break;
+        case KN_GRAPH_L: kb_graph_build<GB_MAXV_L, GB_MAXE_L>(k, w); break;
         case KN_REV_FILL: kb_rev_fill(k, w); break;
         case KN_REV_FILL_W: kb_rev_fill_w(k, w); break;
         case KN_REV_FILL_ORD: case KN_REV_FILL_ORD_S: kb_rev_fill_ord(k, w); break;
@@ -219,7 +220,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // (heap arena sizing + classes need only V and E per contig: sized here, so that their read-back shares the edges' one)
         A(hcap_cnt, int32_t, C, "hcap_cnt"); A(hoff, int64_t, C + 1, "hoff");
         A(mw_flag, int32_t, C, "mw_flag"); A(mw_lg, int32_t, C, "mw_lg"); A(mw_cap, int32_t, C, "mw_cap"); A(mw_off, int64_t, C + 1, "mw_off"); A(mw_list, int32_t, C, "mw_list"); A(mw_sorted, int32_t, C, "mw_sorted"); A(mw_key, int32_t, C, "mw_key");
-        A(chain_flag, int32_t, C, "chain_flag"); A(chain_list, int32_t, C, "chain_list");
+        A(chain_flag, int32_t, C, "chain_flag"); A(chain_list, int32_t, C, "chain_list"); A(gb_flag, int32_t, C, "gb_flag");
+        w.gb_off = (opts.reserved[0] & 0x10000) ? 1 : 0;                 // (bit 16: every contig by the separate launches, for tests and probes)
         w.mw_mode = (opts.reserved[0] & 2) ? 1 : (opts.reserved[0] & 4) ? 2 : 0;
         w.mw_compact = opts.keep_debug ? 1 : 0;   // debug runs compare arena indices with the reference's allocation order
         CHECK_ALLOC();
@@ -227,9 +229,10 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         be.scan_i32(w.deg, VT, w.rowptr);
         be.launch(KN_HEAP_CAP, cdiv(C, 256), 256, w);
         be.scan_i32_pair(w.hcap_cnt, w.hoff, w.mw_cap, w.mw_off, C);
-        int64_t et_mv[8];
-        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN, w.counters + CNT_MAXE}, et_mv);
-        const int64_t ET = et_mv[0], MAXV = et_mv[1], MAXE = et_mv[7];   // (most vertices / edges of one contig)
+        int64_t et_mv[12];
+        be.read_i64s({w.rowptr + VT, w.counters + CNT_MAXV, w.hoff + C, w.mw_off + C, w.counters + CNT_MW, w.counters + CNT_MAXN, w.counters + CNT_CHAIN, w.counters + CNT_GB_S, w.counters + CNT_GB_L, w.counters + CNT_GB_REST}, et_mv);
+        const int64_t ET = et_mv[0], MAXV = et_mv[1];                 // (MAXV: most vertices of one contig)
+        const int64_t GB_S = et_mv[7], GB_L = et_mv[8], GB_REST = et_mv[9];   // contigs whose graph one workgroup builds (kb_graph_build, two forms) / the others
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
         w.ET = ET; sz.ET = ET;
@@ -239,16 +242,19 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
         if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); }
         // sparse, every contig small: rows, reversed CSR and the sweeps' headers of a contig by ONE workgroup (kb_graph_build)
-        const bool one_wg = ET <= 6 * VT && MAXV <= GB_MAXV && MAXE <= GB_MAXE && !(opts.reserved[0] & 0x10000);   // (bit 16: the separate launches, for tests and probes)
-        if (one_wg) {
-            CHECK_ALLOC();
-            be.launch(KN_GRAPH, C, GB_TPB, w);
+        // the small contigs of a sparse batch: rows, reversed CSR and the sweeps' headers of a contig by ONE workgroup (kb_graph_build: kb_heap_cap
+        // picked them); the others - dense batches, contigs of more than GB_MAXV_L vertices or GB_MAXE_L edges - by the separate launches, which
+        // leave the contigs of the class alone
+        w.indeg = nullptr;
+        if (GB_REST > 0) { AZ(indeg, int32_t, VT, "indeg"); AZ(rcur, int32_t, VT, "rcur"); }   // (two fills in one)
+        CHECK_ALLOC();
+        if (GB_S > 0) be.launch(KN_GRAPH, C, GB_TPB, w);
+        if (GB_L > 0) be.launch(KN_GRAPH_L, C, GB_TPB, w);
+        if (GB_REST == 0) {
             be.phase_end(AASM_PH_EDGES);
             be.phase_begin(AASM_PH_REVCSR);
             be.phase_end(AASM_PH_REVCSR);
         } else {
-        AZ(indeg, int32_t, VT, "indeg"); AZ(rcur, int32_t, VT, "rcur");   // (two fills in one)
-        CHECK_ALLOC();
         be.launch(KN_ROW_FILL, cdiv(VT, AASM_WAVE), AASM_WAVE, w);
         be.phase_end(AASM_PH_EDGES);
 

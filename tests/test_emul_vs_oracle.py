@@ -86,10 +86,11 @@ def test_chain_class_forms(T, case, chain):
         assert n_class == int(((sizes >= -(-int(sizes.sum()) // len(sizes))) & (sizes > 1)).sum())
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[4], CASES[5], CASES[7], CASES[8], CASES[14]], ids=lambda c: "graph_c%dx%d_s%d%s" % (c[0], c[1], c[2], "_nsl" if c[8] else ""))
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[4], CASES[5], CASES[7], CASES[8], CASES[14], (2, 2000, 5, 4, False, 0, False, False, False), (1, 2450, 7, 1, False, 0, True, False, True), (12, 700, 3, 4, False, 0, False, True, False)], ids=lambda c: "graph_c%dx%d_s%d%s" % (c[0], c[1], c[2], "_nsl" if c[8] else ""))
 def test_graph_build_forms(T, case):
     """Rows, reversed CSR and the sweeps' vertex headers of a contig by one workgroup (kb_graph_build: the default where the batch is
-    sparse and every contig has at most 1 792 vertices and 4 096 edges) against the separate launches (row_fill, scan, rev_fill,
+    sparse and every contig has at most 1 792 vertices and 4 096 edges, or - the form with more LDS - 3 584 and 8 192; the last case: a heavy-tailed batch with
+    contigs of both forms and one beyond them, which the separate launches build beside them) against the separate launches (row_fill, scan, rev_fill,
     rev_place, rev_hdr): the outputs, and every array the later kernels read, byte for byte."""
     nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
@@ -102,7 +103,11 @@ def test_graph_build_forms(T, case):
         assert T.diff_outputs(want, out) == []
         assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
         got[form] = {n: T.emul_debug(n, dt).copy() for n, dt in names}
-        assert (T.emul().emul_debug_fetch(b"indeg", None, 0) >= 0) == form       # (the one-workgroup form has no global in-degree counters)
+        n_s, n_l, n_rest = (int(x) for x in T.emul_debug("counters", np.int64)[18:21])   # contigs by form: one workgroup (small / large), separate launches
+        assert (n_s + n_l == 0) if form else (n_s + n_l > 0)
+        assert (T.emul().emul_debug_fetch(b"indeg", None, 0) >= 0) == (n_rest > 0)   # (global in-degree counters only where the separate launches have contigs)
+        if heavy and nr >= 700 and not form:
+            assert n_s > 0 and n_l > 0 and n_rest > 0                # the mixed batch: all three at once
     for n, _ in names:
         assert np.array_equal(got[False][n], got[True][n]), n
 

@@ -54,8 +54,10 @@ def test_hip_intermediates_match_oracle(T, case):
 
 
 # ---- rows + reversed CSR + sweep headers of a contig by one workgroup (aasm_k46_graph): the default for sparse batches whose contigs all have
-# at most 1 792 vertices and 4 096 edges - most sparse cases above; here against the separate launches (row_fill, scan, rev_fill, rev_place, rev_hdr)
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9], CASES[12], (5, 1250, 3, 4, False, 0, False, False, False), (3, 1200, 8, 4, False, 7, True, False, True)], ids=_id)
+# at most 1 792 vertices and 4 096 edges (a second form: 3 584 / 8 192) - most sparse cases above; here against the separate launches (row_fill, scan, rev_fill, rev_place, rev_hdr)
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9], CASES[12], (5, 1250, 3, 4, False, 0, False, False, False), (3, 1200, 8, 4, False, 7, True, False, True),
+                                  (3, 2000, 5, 4, False, 0, False, False, False), (2, 2450, 7, 1, False, 0, True, False, True),
+                                  (12, 700, 3, 4, False, 0, False, True, False), (300, 100, 9, 4, False, 0, False, True, False)], ids=_id)   # (3 584 vertices / 8 192 edges: the form with more LDS; heavy-tailed: contigs of both forms and of the separate launches in one batch)
 def test_graph_build_forms(T, case):
     """Outputs and intermediates against the oracle in both forms, and every array the later kernels read byte for byte between them
     (in-lists in list order, the two header records, in-list starts, the forward headers, the pending counts)."""
@@ -74,6 +76,10 @@ def test_graph_build_forms(T, case):
         kept[form] = {n: res.debug(n, dt).copy() for n, dt in names}
         st = res.stats()
         kept[form]["sizes"] = (st["n_edges"], st["n_vertices"])
+        n_s, n_l, n_rest = (int(x) for x in res.debug("counters", np.int64)[18:21])   # contigs by form: one workgroup (small / large), separate launches
+        assert (n_s + n_l == 0) if form else (dense or n_s + n_l > 0)
+        if (nc, nr) == (12, 700) and not form:
+            assert n_s > 0 and n_l > 0 and n_rest > 0
         res.close()
     db.close()
     ET, VT = kept[True]["sizes"]

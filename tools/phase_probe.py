@@ -11,6 +11,7 @@ ap.add_argument("--heavy", type=int, default=0); ap.add_argument("--dup", type=i
 ap.add_argument("--input-order", type=int, default=0, help="1: K7's several-waves class in input order instead of largest node bound first")
 ap.add_argument("--grid-order", type=int, default=0, help="1: blocks take their work items in grid order (default: XCD by XCD)")
 ap.add_argument("--chain", default="auto", help="the chain class (aasm_k67_chain): auto / all / none")
+ap.add_argument("--graph-launches", type=int, default=0, help="1: rows, reversed CSR and sweep headers by the separate launches (default: one workgroup per contig where the contigs are small)")
 ap.add_argument("--cs", type=int, default=0, help="1: the batch carries cs tags and the device derives the match ranges (K0)")
 a = ap.parse_args()
 t = time.time()
@@ -24,7 +25,7 @@ else:
     print("gen %.2fs records=%d ranges=%d" % (time.time() - t, hb.view.n_records, hb.view.n_ranges), flush=True)
 t = time.time(); db = A.DeviceBatch(hb); print("upload %.2fs" % (time.time() - t), flush=True)
 for r in range(a.reps):
-    t = time.time(); res = db.solve(max_paths=a.k, timing=True, heap_input_order=bool(a.input_order), grid_order=bool(a.grid_order), chain=a.chain); wall = time.time() - t
+    t = time.time(); res = db.solve(max_paths=a.k, timing=True, heap_input_order=bool(a.input_order), grid_order=bool(a.grid_order), chain=a.chain, graph_launches=bool(a.graph_launches)); wall = time.time() - t
     st = res.stats(); res.close()
     ph = {k: round(v, 3) for k, v in st["phase_ms"].items() if v > 0}
     print(json.dumps({"rep": r, "wall_ms": round(wall * 1e3, 2), "total_ms": round(st["total_ms"], 3), "phases": ph,
