@@ -24,6 +24,8 @@ cp $O/${TAG}_c5_pmc_fetch_write.json $R/profiles/          # (bench.py reads roo
 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --cpu-sample 200 > $O/${TAG}_c5_bench_file_1gpu.json 2> $O/c5.err || exit 1
 for n in 1 250 625 1000 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
 for n in 1 250 625 1000; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 --chain none 2>&1 | tail -n 1 > $O/${TAG}_probe_n${n}_three_launches.json; done   # the chain class off: K6, pre-pass, K7 one after the other
+python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --graph-launches 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_graph_by_separate_launches.json   # aasm_k46_graph off: row_fill, scan, rev_fill, rev_place, rev_hdr
+python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n5000.json
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --dup 3 --shuffle 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_dup3_shuffled.json
 python3 $R/tools/phase_probe.py --contigs 1000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_1000contigs.json
 python3 $R/tools/phase_probe.py --contigs 5000 --k 10000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_k10000_5000contigs.json
@@ -42,6 +44,7 @@ python3 $R/tools/giant_probe.py > $O/${TAG}_giant_contigs.jsonl 2>&1
 python3 $R/tools/e2e_cli.py --contigs 5000 --k 4 > $O/${TAG}_e2e_cli.log 2>&1
 AASM_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $O/${TAG}_c4_selflaunch_2ranks_1gpu_gloo.json 2> $O/c4.err
 python3 $R/tools/kprof.py 5000 1000 4 0 21 > $O/${TAG}_k7_k9_sections_c3.txt 2>&1
+python3 $R/tools/kprof_gb.py 5000 1000 21 > $O/${TAG}_k46_graph_sections_c3.txt 2>&1
 python3 $R/tools/kprof.py 5000 1000 4 0 21 3 > $O/${TAG}_k7_k9_sections_c3_dup3.txt 2>&1
 python3 $R/tools/kprof_enum.py 5000 1000 10000 0 21 > $O/${TAG}_k8_sections.txt 2>&1
 rm -rf $O/kt $O/kt5 $O/ktk $O/ktd $O/kth $O/kts $O/pmc5_fetch $O/pmc5_write $O/pmc_fetch $O/pmc_write $O/pmc_sq
