@@ -2064,11 +2064,13 @@ AASM_DEV void kb_topo_fill(const KCtx &k, const WS &w) {            // wave per 
 // v -> u, so it is a source in u's in-list - which is in ascending (source, position) order already; parallel edges of
 // one source are neighbours there.  The list is written over the front of u's OWN in-list slots (cval is indexed
 // like r_pk): no counting pass, no scan, no atomics, nothing to sort.
-AASM_DEV void children_vertex(const WS &w, int64_t gv) {
+// (ch4: the first four children, for a caller that goes on with them - kb_k7_prep: no trip through memory for what this thread just wrote)
+AASM_DEV int32_t children_vertex(const WS &w, int64_t gv, int32_t *ch4 = nullptr) {
     const int64_t vb = w.voff[w.v_ctg[gv]];
     const int32_t u = (int32_t)(gv - vb);
     const int64_t r0 = w.rptr[gv], r1 = w.rptr[gv + 1];
     int32_t n = 0, prev = -1;
+    int32_t c0 = -1, c1 = -1, c2 = -1, c3 = -1;
     // (a thread has two or three in-edges and every one is two dependent loads: four edges per round, their loads issued
     // together - the kernel waits on memory 93 % of its time, not on bandwidth)
     for (int64_t t = r0; t < r1; t += 4) {
@@ -2079,11 +2081,17 @@ AASM_DEV void children_vertex(const WS &w, int64_t gv) {
         for (int i = 0; i < 4; i++) bst[i] = src[i] >= 0 ? w.sp_best[vb + src[i]] : -1;
         AASM_UNROLL
         for (int i = 0; i < 4; i++) {
-            if (src[i] >= 0 && src[i] != prev && bst[i] == u) w.cval[r0 + n++] = src[i];
+            if (src[i] >= 0 && src[i] != prev && bst[i] == u) {
+                w.cval[r0 + n] = src[i];
+                c0 = n == 0 ? src[i] : c0; c1 = n == 1 ? src[i] : c1; c2 = n == 2 ? src[i] : c2; c3 = n == 3 ? src[i] : c3;
+                n++;
+            }
             if (src[i] >= 0) prev = src[i];
         }
     }
     w.ccnt[gv] = n;
+    if (ch4) { ch4[0] = c0; ch4[1] = c1; ch4[2] = c2; ch4[3] = c3; }
+    return n;
 }
 AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
@@ -2097,7 +2105,7 @@ AASM_DEV void kb_children(const KCtx &k, const WS &w) {              // thread p
 // one coalesced load (lane t = key t) instead of flag, cost and head through three dependent loads.
 // A sidetrack cost has score sum >= 0 (d[u] is minimal in the CALC_SUM order, whose first key is the sum), so
 // no heap key is ever max() (sum -2): K7's key test needs no sentinel handling.  Checked here.
-AASM_DEV void sidetrack_vertex(const WS &w, int64_t gv) {
+AASM_DEV int32_t sidetrack_vertex(const WS &w, int64_t gv) {       // (returns the key count it stores in st_n)
     const int64_t c = w.v_ctg[gv], vb = w.voff[c];
     const Dist *d = w.sp_d + vb;
     const Dist du = w.sp_d[gv];
@@ -2125,6 +2133,7 @@ AASM_DEV void sidetrack_vertex(const WS &w, int64_t gv) {
     }
     w.st_n[gv] = n_ins;
     if (bad) w.status[c] = -6;                                       // must not happen (see above)
+    return n_ins;
 }
 // the next four vertices along best[] (final once K6 is done): the 4-hop jump record of a vertex
 AASM_DEV void tnx_vertex(const WS &w, int64_t gv) {
@@ -2220,11 +2229,12 @@ AASM_DEV void kb_sidetrack_w(const KCtx &k, const WS &w) {          // wave per 
 // list, the keys and the header of a vertex are one thread's work in one launch (kb_k7_prep; round 5 - the counts used to
 // come from st_n[child], a second launch).
 // (returns the two header quads: kb_chain's prep wave publishes them only after everything else the vertex's step reads is in memory)
-AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b) {
+// (nch / ch4 / nkeys: what the caller's children_vertex / sidetrack_vertex just returned; nch < 0 / nkeys < 0: read from memory)
+AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b, int32_t nch = -1, const int32_t *ch4 = nullptr, int32_t nkeys = 0) {
     const int64_t vb = w.voff[w.v_ctg[gv]], e_base = w.rowptr[vb];
-    const int64_t c0 = w.rptr[gv], c1 = c0 + w.ccnt[gv];          // (kb_children: the list sits at the front of the in-list slots)
-    const int32_t fc = (c1 > c0) ? w.cval[c0] : -1;
-    a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;
+    const int64_t c0 = w.rptr[gv], c1 = c0 + (nch >= 0 ? nch : w.ccnt[gv]);   // (kb_children: the list sits at the front of the in-list slots)
+    const int32_t fc = (c1 > c0) ? (nch >= 0 ? ch4[0] : w.cval[c0]) : -1;
+    a.x = (int32_t)(w.rowptr[gv] - e_base); a.y = (nch >= 0 && nkeys >= 0) ? nkeys : w.st_n[gv]; a.z = (int32_t)(c1 - c0); a.w = fc;
     b.x = (int32_t)(uint32_t)(uint64_t)c0; b.y = (int32_t)((uint64_t)c0 >> 32);
     b.z = 0; b.w = 0;
     if (fc >= 0) { const int64_t rp0 = w.rowptr[vb + fc]; b.z = (int32_t)(rp0 - e_base); b.w = (int32_t)(w.rowptr[vb + fc + 1] - rp0); }
@@ -2232,7 +2242,7 @@ AASM_DEV void heap_hdr_vertex(const WS &w, int64_t gv, I4 &a, I4 &b) {
         int32_t ch[4];
         int64_t rp[4], rq[4];
         AASM_UNROLL
-        for (int i = 0; i < 4; i++) ch[i] = (t0 + i < c1) ? w.cval[t0 + i] : -1;
+        for (int i = 0; i < 4; i++) ch[i] = (t0 + i < c1) ? ((nch >= 0 && t0 == c0) ? ch4[i] : w.cval[t0 + i]) : -1;
         AASM_UNROLL
         for (int i = 0; i < 4; i++) { rp[i] = 0; rq[i] = 0; if (ch[i] >= 0) { rp[i] = w.rowptr[vb + ch[i]]; rq[i] = w.rowptr[vb + ch[i] + 1]; } }
         AASM_UNROLL
@@ -2263,10 +2273,11 @@ AASM_DEV void kb_tnx16(const KCtx &k, const WS &w) {                // thread pe
 AASM_DEV void kb_k7_prep(const KCtx &k, const WS &w) {              // thread per vertex
     const int64_t gv = k.bid * k.nthreads + k.tid;
     if (gv >= w.VT || in_chain_class(w, w.v_ctg[gv])) return;
-    children_vertex(w, gv);
-    sidetrack_vertex(w, gv);
+    int32_t ch4[4];
+    const int32_t nch = children_vertex(w, gv, ch4);
+    const int32_t nkeys = sidetrack_vertex(w, gv);
     I4 a, b;
-    heap_hdr_vertex(w, gv, a, b);                                    // (reads back this thread's own child list and key count)
+    heap_hdr_vertex(w, gv, a, b, nch, ch4, nkeys);                   // (the count and the first four children in registers: a fifth child and on come back from cval)
     w.vhdr[gv] = a; w.vhdr2[gv] = b;
 }
 AASM_DEV void kb_heap_hdr(const KCtx &k, const WS &w) {
@@ -2843,12 +2854,12 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
         if (r2_head < r2_tail) {
             // ---- child lists + headers of up to 64 vertices whose in-neighbours all have their keys
             const int32_t n2 = (r2_tail - r2_head < AASM_WAVE) ? (r2_tail - r2_head) : AASM_WAVE;
-            int32_t u = -1;
-            if (k.lane < n2) { u = cq[r2_head + k.lane]; children_vertex(w, vb + u); }
-            wave_fence();                                            // (the header pass reads the child list back)
+            int32_t u = -1, nch = 0, ch4[4] = {-1, -1, -1, -1};
+            if (k.lane < n2) { u = cq[r2_head + k.lane]; nch = children_vertex(w, vb + u, ch4); }
+            wave_fence();                                            // (the header pass reads a child list of more than four back)
             I4 a, b;
             a.x = a.y = a.z = a.w = 0; b = a;
-            if (k.lane < n2) { heap_hdr_vertex(w, vb + u, a, b); tnx16_vertex(w, vb + u); }
+            if (k.lane < n2) { heap_hdr_vertex(w, vb + u, a, b, nch, ch4, -1); tnx16_vertex(w, vb + u); }
             wave_fence();                                            // child slots, jump records: in memory before the marker words
             if (k.lane < n2 && !(w.chain_test && c == 0 && u == (int32_t)w.ctgV[c] - 1)) { w.vhdr2[vb + u] = b; w.vhdr[vb + u] = a; }   // (test hook: contig 0's root never gets its header)
             r2_head += n2;
