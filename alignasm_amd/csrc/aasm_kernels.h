@@ -1816,7 +1816,9 @@ AASM_DEV void kb_graph_build(const KCtx &k, const WS &w) {          // workgroup
 // the chain per contig: aasm_pipeline.h picks): what used to be wave-uniform (queue head
 // and tail, the popped vertex) is uniform per lane group and lives in vector registers; ballots are cut to the
 // group's bits.
+#ifndef AASM_SWEEP_G
 #define AASM_SWEEP_G (AASM_WAVE >= 32 ? 32 : 1)
+#endif
 template <int G> struct SweepGrp {
     static constexpr int N = AASM_WAVE / G;                          // contigs per wave
     int g, gl;

@@ -90,6 +90,9 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 #define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups at 4 waves / SIMD)
 
+#ifndef AASM_GROUPED_MIN
+#define AASM_GROUPED_MIN 2560
+#endif
 struct PipelineSizes { int64_t C = 0, R = 0, S = 0, VT = 0, ET = 0, HT = 0, bad_record = -1; };
 
 // Runs the pipeline for contigs [0, C) described by `in` (device pointers; ctg_rec_off
@@ -283,7 +286,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         CHECK_ALLOC();
         // big sparse batches (mean degree <= 6, thousands of contigs: bound by instruction issue): two contigs per wave,
         // AASM_SWEEP_G lanes each; dense ones and small batches (bound by the chain per contig): a wave per contig
-        const bool grouped = ET <= 6 * VT && C >= 2560;            // (few contigs: a wave each - the scalar-uniform variant has the shorter chain per pop)
+        const bool grouped = ET <= 6 * VT && C >= AASM_GROUPED_MIN;            // (few contigs: a wave each - the scalar-uniform variant has the shorter chain per pop)
         const int64_t sweep_n = AASM_WAVE / AASM_SWEEP_G;
         auto side_work = [&]() {
             be.fork();                                               // side stream waits for everything enqueued so far
