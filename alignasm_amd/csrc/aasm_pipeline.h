@@ -24,7 +24,7 @@ enum Kern {
     KN_CS_RANGES, KN_SORT, KN_SORT_RANK, KN_SORT_FIX, KN_GATHER_PARTS, KN_OV_COUNT, KN_OV_MERGE, KN_VCOUNT, KN_VFILL_REC, KN_VFILL_SLOT,
     KN_NSL, KN_ROW_COUNT, KN_ROW_FILL, KN_GRAPH, KN_GRAPH_L, KN_REV_FILL, KN_REV_FILL_W, KN_REV_FILL_ORD, KN_REV_FILL_ORD_S, KN_SORT_ROWS_REV, KN_REV_HDR, KN_REV_SWEEP, KN_FWD_SWEEP, KN_REV_SWEEP_G, KN_FWD_SWEEP_G,
     KN_CHILDREN, KN_HEAP_CAP, KN_SIDETRACK, KN_SIDETRACK_W, KN_HEAP_HDR, KN_HEAP, KN_HEAP_MW, KN_HEAP_MW8, KN_HEAP_MW16, KN_MW_RANK, KN_ENUM, KN_ENUM_S, KN_ENUM_HEAP, KN_SELECT, KN_GATHER_OUT, KN_TOPO_COUNT, KN_TOPO_FILL,
-    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16
+    KN_SEL_PLAN, KN_SEL_PLANFILL, KN_SEL_RECOVER, KN_SEL_CLASSIFY, KN_SEL_CONVERT, KN_SEL_FINAL, KN_CHAIN, KN_K7_PREP, KN_TNX, KN_TNX16, KN_TNX16_WG
 };
 
 // dispatch a kernel body (used verbatim by both backends)
@@ -83,6 +83,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
         case KN_K7_PREP: kb_k7_prep(k, w); break;
         case KN_TNX: kb_tnx(k, w); break;
         case KN_TNX16: kb_tnx16(k, w); break;
+        case KN_TNX16_WG: kb_tnx16_wg(k, w); break;
         default: break;
     }
 }
@@ -282,7 +283,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // K9, so they run on a second stream beside rev_sweep -> heaps -> enumeration.
         A(rev_order, int32_t, VT, "rev_order"); A(fwd_order, int32_t, VT, "fwd_order"); A(fwd_pos, int32_t, VT, "fwd_pos");
         A(tp_deg, int32_t, VT, "tp_deg"); A(tp_vj, int32_t, VT, "tp_vj"); A(tp_ptr, int64_t, VT + 1, "tp_ptr");
-        A(te_tgt, int32_t, ET, "te_tgt"); A(te_wq, int64_t, ET, "te_wq"); A(te_wr, int32_t, ET, "te_wr"); A(te_fl, uint8_t, ET, "te_fl");
+        A(te_pk, I4, ET, "te_pk");
         CHECK_ALLOC();
         // big sparse batches (mean degree <= 6, thousands of contigs: bound by instruction issue): two contigs per wave,
         // AASM_SWEEP_G lanes each; dense ones and small batches (bound by the chain per contig): a wave per contig
@@ -340,8 +341,11 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         // side stream, which finishes its topological copy about when the reverse sweep ends, and run beside the heap pre-pass
         be.fork_again();
         be.use_side(true);
-        be.launch(KN_TNX, cdiv(VT, 256), 256, w);
-        be.launch(KN_TNX16, cdiv(VT, 256), 256, w);
+        if (GB_S + GB_L > 0) be.launch(KN_TNX16_WG, C, TNX_TPB, w);  // (the small contigs of a sparse batch - kb_graph_build's class: sixteen hops through the tree in LDS)
+        if (GB_REST > 0) {
+            be.launch(KN_TNX, cdiv(VT, 256), 256, w);
+            be.launch(KN_TNX16, cdiv(VT, 256), 256, w);
+        }
         be.use_side(false);
         be.phase_begin(AASM_PH_HEAP_PREP);
         if (ET > 6 * VT) {

@@ -110,6 +110,14 @@ def test_graph_build_forms(T, case):
             assert n_s > 0 and n_l > 0 and n_rest > 0                # the mixed batch: all three at once
     for n, _ in names:
         assert np.array_equal(got[False][n], got[True][n]), n
+    # ... and the 16-hop jump records of K9's recovery, which the small contigs get from a workgroup with the contig's tree in LDS
+    # (kb_tnx16_wg) - with the chain class off, or batches this small never reach it
+    got7 = {}
+    for form in (False, True):
+        out = T.emul_solve(hb, K, nsl, graph_launches=form, chain="none")
+        assert T.diff_outputs(want, out) == []
+        got7[form] = T.emul_debug("tnx16", np.int32).copy()
+    assert np.array_equal(got7[False], got7[True])
 
 
 def test_all_pool_overflow_reruns_the_pick(T):

@@ -87,6 +87,17 @@ def test_graph_build_forms(T, case):
         a, b = kept[False][n], kept[True][n]
         m = {"rptr": VT + 1, "r_pk": 4 * ET, "rvh": 12 * VT, "fvh": 8 * VT, "cnt_tmp2": VT}.get(n, ET)   # (allocations are padded: the cells the kernels own)
         assert np.array_equal(a[:m], b[:m]), n
+    # ... and the 16-hop jump records of K9's recovery, which the small contigs get from a workgroup with the contig's tree in LDS
+    # (aasm_k9_tnx16_wg) - with the chain class off, or batches this small never reach it
+    db = api.DeviceBatch(hb)
+    kept7 = {}
+    for form in (False, True):
+        res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, graph_launches=form, chain="none")
+        assert T.diff_outputs(want, res.fetch()) == []
+        kept7[form] = res.debug("tnx16", np.int32).copy()
+        res.close()
+    db.close()
+    assert np.array_equal(kept7[False][:16 * VT], kept7[True][:16 * VT])
 
 
 # ---- the chain class (aasm_k67_chain: sweep, pre-pass and heaps of a contig beside each other).  By default it takes every sparse
