@@ -130,6 +130,8 @@ struct WS {
     int32_t *chain_flag, *chain_list;    // per contig: in the class; the contigs of the class, in any order
     int32_t *pend;                       // per vertex: in-neighbours whose keys are not written yet (the prep wave counts them down)
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
+    I4 *bfsq;                            // per contig slice: the SP tree in BFS order, a record {vertex, position of its parent, start of its keys, #keys} per position (kb_chain's order wave -> heap wave)
+    int32_t chain_ord;                   // kb_chain: 1 = the BFS order comes from a wave of its own (default), 0 = the heap wave keeps its own queue (probes, tests)
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_GB_S, CNT_GB_L, CNT_GB_REST, CNT_N };
@@ -1837,7 +1839,7 @@ template <int G> struct SweepGrp {
 // Progress words of one chain-class workgroup (kb_chain), in LDS.  sweep wave -> prep wave: `tail_pub` vertices of rev_order are
 // final (d, best and the order entry are in memory); prep wave -> heap wave: a vertex's header words in global memory turn from
 // -1 to their values; `sweep_done` / `prep_done` end the waits (1: finished, 2: gave up).
-struct ChainSync { int32_t tail_pub, sweep_done, prep_done, pad; };
+struct ChainSync { int32_t tail_pub, sweep_done, prep_done, ord_pub, ord_done, pad[3]; };   // (ord_pub: positions of the BFS order that are complete; ord_done: 1 = all of them, 2 = a header never came)
 #if defined(AASM_HOST_EMUL)
 AASM_DEV void st_shared_i32(int32_t *p, int32_t v) { *p = v; }
 #else
@@ -2814,8 +2816,8 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
 // it: the heap wave - the slowest of the three - finds what it needs and the contig costs max(K6, K7) instead of the sum.
 // Every wait ends: the sweep waits for nobody; the pre-pass only for the sweep (`sweep_done`); the heap wave only for the
 // pre-pass (`prep_done`), and gives up with AASM_E_INTERNAL after 30 s rather than sit.
-#define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH) + 16)
-#define CHAIN_WAVES 3
+#define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH) + 32)
+#define CHAIN_WAVES 4
 #define CHAIN_LONG_ROW 8
 struct ChainLds { RevQ rq; HeapLdsT<HEAP_RING_CH, HEAP_QN_CH> hl; ChainSync s; };
 static_assert(sizeof(ChainLds) <= AASM_CHAIN_LDS_BYTES, "LDS budget");
@@ -2906,6 +2908,188 @@ AASM_DEV void chain_prep(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
     if (!(w.chain_test == 2 && c == 0)) st_shared_i32(&S->prep_done, result);   // (test hook 2: the heap wave of contig 0 is left to its own patience)
 }
 
+// The BFS order of a contig's SP tree by a wave of its own (kb_chain, wave 2).  A quarter of the heap wave's time per vertex was not
+// inserts: waiting for the vertex's header, decoding it, fetching the child slots, pushing the children into its queue window, popping,
+// the spill path of wide frontiers.  None of that needs the heaps - the order the reference allocates in is the FIFO order of the tree
+// (k_shortest_walks.hpp:196-215: pop u, insert its keys, push its children in list order), and the tree is known as soon as the headers
+// are.  So this wave walks the tree, up to 64 queue entries a step (their headers ready as a prefix, their children appended by a prefix
+// sum of the child counts - the same order as one by one), and leaves ONE record per position: {vertex, position of its parent, start of
+// its keys, #keys}.  The array is its own queue (head = next to expand, tail = next to write); `ord_pub` tells the heap wave how many
+// positions are complete.  The heap wave (kb_heap_ord) reads records, keys and its parent's root - nothing else.
+AASM_DEV void chain_order(const KCtx &k, const WS &w, int64_t c, ChainSync *S) {
+    const int64_t V = w.ctgV[c], vb = w.voff[c];
+    int32_t result = 1;
+    if (V > 0 && w.status[c] == 0 && !w.mw_flag[c]) {
+        I4 *q = w.bfsq + vb;
+        const I4 *vh = w.vhdr + vb, *vh2 = w.vhdr2 + vb;
+        const int64_t patience = (w.chain_test == 2) ? (int64_t)100000000 : (int64_t)30 * 100000000;   // as the heap wave's
+        int32_t head = 0, tail = 1;
+        if (k.lane == 0) { I4 r; r.x = (int32_t)(V - 1); r.y = -1; r.z = 0; r.w = 0; q[0] = r; }       // the root: dest
+        wave_fence();
+        while (head < tail) {
+            const int32_t nb = (tail - head < AASM_WAVE) ? (tail - head) : AASM_WAVE;
+            I4 rec; rec.x = -1; rec.y = -1; rec.z = 0; rec.w = 0;
+            bool rdy = false;
+            wave_fence();                                            // (entries other lanes wrote in the step before)
+            if (k.lane < nb) {
+                rec = q[head + k.lane];
+                rdy = ld_shared_i32(&vh[rec.x].x) != -1 && ld_shared_i32(&vh2[rec.x].y) != -1;
+            }
+            const uint64_t rm = wave_ballot(rdy);
+            int32_t r = (~rm == 0ull) ? AASM_WAVE : ffs64(~rm) - 1;  // the entries whose headers are there, as a prefix
+            if (r == 0) {                                            // not even the first: wait for it (or learn that it will never come)
+                if (!chain_wait_hdr(S, vh, vh2, uni(rec.x), patience)) { result = 2; break; }
+                r = 1;
+            }
+            wave_fence();
+            int32_t nch = 0;
+            int64_t c0 = 0;
+            if (k.lane < r) {
+                const I4 ha = vh[rec.x], hb = vh2[rec.x];
+                rec.z = ha.x; rec.w = ha.y; nch = ha.z;              // where its keys start, how many there are
+                c0 = (int64_t)(((uint64_t)(uint32_t)hb.y << 32) | (uint32_t)hb.x);
+            }
+            const int32_t incl = wave_incl_add(nch);
+            const int32_t tot = wave_bcast(incl, AASM_WAVE - 1);
+            if (k.lane < r) {
+                q[head + k.lane] = rec;
+                int32_t at = tail + incl - nch;
+                for (int32_t t = 0; t < nch; t++) {                  // (one or two children as a rule)
+                    const I4 ci = w.cinfo[c0 + t];
+                    I4 ch; ch.x = ci.x; ch.y = head + k.lane; ch.z = ci.y; ch.w = 0;
+                    q[at + t] = ch;
+                }
+            }
+            head += r; tail += tot;
+            store_drain();                                           // the records are in memory before the count that announces them
+            st_shared_i32(&S->ord_pub, head);
+        }
+    }
+    store_drain();
+    st_shared_i32(&S->ord_done, result);
+}
+
+// kb_chain's heap wave when the order comes from chain_order: for position i of the BFS order - the inherited heap is its parent's
+// finished root (a ring of the newest roots in LDS, else h_root), its keys are a contiguous run - the inserts of kb_heap, same arena,
+// same indices.  Record i + 2 and the keys of position i + 1 are fetched while position i's inserts run (parked at the step's end, as
+// kb_heap does with its prefetch).
+template <int RING, int QN>
+AASM_DEV void kb_heap_ord(const KCtx &k, const WS &w, ChainSync *S) {
+    const int64_t c = k.bid;
+    const int64_t V = w.ctgV[c];
+    if (V == 0) return;
+    HeapLdsT<RING, QN> *L = (HeapLdsT<RING, QN> *)k.lds;
+    const int64_t vb = w.voff[c];
+    int32_t *h = w.h_root + vb;
+    const Dist *sk = w.st_cost + w.rowptr[vb];
+    const I4 *q = w.bfsq + vb;
+    int32_t *rroot = (int32_t *)L->bq;                               // roots of the newest RN positions
+    constexpr int32_t RN = QN * 4;
+    HeapState hs;
+    hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.rn = RING; hs.bounce = &L->bounce; hs.oldn = L->oldn; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
+    hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);
+    const int32_t src = (int32_t)(V - 2);
+    if (w.mw_flag[c]) return;
+    if (k.lane == 0) w.h_cnt[c] = 0;
+    if (w.status[c] != 0) return;
+    bool lost = false;
+    const int64_t patience = (w.chain_test == 2) ? (int64_t)100000000 : (int64_t)30 * 100000000;
+    Spine sp; sp.root = -2; sp.len = 0; sp.tail = -1;
+    KProfNone kp;
+    HeapStage *St = &L->stage;
+    int32_t i = 0;
+    int32_t u = -1, p = -1, so = 0, n = 0;                           // position i: vertex, parent's position, key offset, #keys (keys in St)
+    bool have = false;
+    int32_t a_u = -1, a_p = -1, a_so = 0, a_n = 0;                   // position i + 1
+    bool a_have = false;
+    int32_t pend_u = -1, pend_root = -1;
+    int32_t pub = 0;
+    while (!hs.ovf) {
+        if (!have) {                                                 // nothing staged (the start; the order wave was not ahead): wait for position i, fetch it now
+            const int64_t t0 = wave_realtime();
+            int64_t guard = 0;
+            bool end = false;
+            for (;;) {
+                const int32_t od = uni(ld_shared_i32(&S->ord_done));    // (before the count: once it is set the count is the last one)
+                pub = uni(ld_shared_i32(&S->ord_pub));
+                if (i < pub) break;
+                if (od) { end = true; lost = od == 2; break; }
+                if ((++guard & 1023) == 0 && wave_realtime() - t0 > patience) { end = true; lost = true; break; }
+                wave_sleep();
+            }
+            if (end) break;
+            wave_fence();
+            const I4 r0 = q[i];
+            u = uni(r0.x); p = uni(r0.y); so = uni(r0.z); n = uni(r0.w);
+            wave_lds_sync();
+            FOR_LANE(t, (n < HEAP_KMAX ? n : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t]; St->key[t] = kk; }
+            wave_lds_sync();
+            have = true; a_have = false;
+        }
+        // ---- the inherited heap: the parent's finished root
+        int32_t hu = -1;
+        if (p >= 0) {
+            if (i - p <= RN) hu = uni(rroot[p & (RN - 1)]);
+            else { wave_fence(); hu = uni(h[uni(q[p].x)]); }         // (a frontier wider than the ring: the root is in memory - stored two steps after it was made at the latest)
+        }
+        // ---- every global store of this step ahead of its loads (kb_heap)
+        if (pend_u >= 0) h[pend_u] = pend_root;
+        if (hs.alloc - hs.flushed >= HEAP_RING / 2) heap_flush(hs, k.lane);
+        // ---- position i + 1 (if the order wave is not ahead this is a wait of its own), then its keys and record i + 2 behind the inserts
+        pub = uni(ld_shared_i32(&S->ord_pub));
+        if (!a_have && i + 1 < pub) {
+            wave_fence();
+            const I4 r1 = q[i + 1];
+            a_u = uni(r1.x); a_p = uni(r1.y); a_so = uni(r1.z); a_n = uni(r1.w);
+            a_have = true;
+        }
+        LaneArr<Dist> pk;
+        I4 rb;
+        rb.x = rb.y = rb.z = rb.w = 0;
+#if !defined(AASM_HOST_EMUL)
+        pk.r = dist_zero();
+#endif
+        const bool b_have = a_have && i + 2 < pub;
+        if (a_have) { FOR_LANE(t, (a_n < HEAP_KMAX ? a_n : HEAP_KMAX), k.lane) pk.at(t) = sk[(int64_t)a_so + t]; }
+        if (b_have) rb = q[i + 2];
+        // ---- inserts in list order (:202-211)
+        for (int32_t t = 0; t < n && !hs.ovf; t++) {
+            if (t >= HEAP_KMAX && (t & (HEAP_KMAX - 1)) == 0) {
+                wave_lds_sync();
+                FOR_LANE(j, (n - t < HEAP_KMAX ? n - t : HEAP_KMAX), k.lane) { const Dist kk = sk[(int64_t)so + t + j]; St->key[j] = kk; }
+                wave_lds_sync();
+            }
+            const Dist cc = St->key[t & (HEAP_KMAX - 1)];
+            hu = heap_insert<true>(hs, sp, hu, cc, u, cc.pad, k.lane, kp);
+        }
+        pend_u = (k.lane == 0) ? u : -1; pend_root = hu;
+        wave_lds_sync();
+        if (k.lane == 0) rroot[i & (RN - 1)] = hu;
+        // ---- park what was fetched: position i + 1 becomes the one at hand
+        if (a_have) { FOR_LANE(t, (a_n < HEAP_KMAX ? a_n : HEAP_KMAX), k.lane) St->key[t] = pk.at(t); }
+        wave_lds_sync();
+        have = a_have; u = a_u; p = a_p; so = a_so; n = a_n;
+        a_have = b_have;
+        if (b_have) { a_u = uni(rb.x); a_p = uni(rb.y); a_so = uni(rb.z); a_n = uni(rb.w); }
+        i++;
+    }
+    if (pend_u >= 0) h[pend_u] = pend_root;
+    heap_flush(hs, k.lane);
+    {
+        // :188-189 (no src -> dest path: must not happen) can only be asked once the sweep has finished
+        const int64_t t0 = wave_realtime();
+        int64_t guard = 0;
+        while (!lost && !uni(ld_shared_i32(&S->sweep_done))) {
+            if ((++guard & 1023) == 0 && wave_realtime() - t0 > patience) lost = true;
+            wave_sleep();
+        }
+        wave_fence();
+        if (lost || uni(ld_shared_i32(&w.sp_d[vb + src].anom)) < 0) { if (k.lane == 0) { set_status(w, c, -6); w.h_cnt[c] = 0; } return; }
+    }
+    if (hs.ovf) { if (k.lane == 0) set_status(w, c, -5); return; }
+    if (k.lane == 0) { w.h_cnt[c] = hs.alloc; atomic_add(&w.counters[CNT_HEAPNODES], (int64_t)hs.alloc); }
+}
+
 // The three roles share one kernel, hence one register allocation: with every role reading its pointers from the kernel's
 // argument block the compiler loads them all into scalar registers up front, and the heap role - the critical path, 89 SGPRs on
 // its own - ran with 36 of its scalars spilled to vector lanes (2.36 ms for a 1 000-record contig against 2.16 in the kernel of
@@ -2926,7 +3110,7 @@ AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAV
     ChainLds *L = (ChainLds *)k.lds;
     const int64_t c = w.chain_list[k.bid];
     const int wv = k.tid / AASM_WAVE;
-    if (k.tid == 0) { L->s.tail_pub = 0; L->s.sweep_done = 0; L->s.prep_done = 0; L->s.pad = 0; }
+    if (k.tid == 0) { L->s.tail_pub = 0; L->s.sweep_done = 0; L->s.prep_done = 0; L->s.ord_pub = 0; L->s.ord_done = 0; }
     block_barrier();
     KCtx k2 = k;
     k2.bid = c; k2.tid = k.lane; k2.nthreads = AASM_WAVE;
@@ -2935,12 +3119,21 @@ AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAV
         kb_rev_sweep<AASM_WAVE, true>(k2, chain_role_ws(w), &L->s);
     } else if (wv == 1) {
         chain_prep(k2, chain_role_ws(w), c, &L->s);
-    } else {
+    } else if (wv == 2) {
+        if (w.chain_ord) chain_order(k2, chain_role_ws(w), c, &L->s);
+        else {                                                       // (probes, tests: the heap wave with its own queue, no order wave)
+#if !defined(AASM_HOST_EMUL)
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            k2.lds = (char *)&L->hl;
+            kb_heap<true, HEAP_RING_CH, HEAP_QN_CH>(k2, w, &L->s);
+        }
+    } else if (w.chain_ord) {
 #if !defined(AASM_HOST_EMUL)
         __builtin_amdgcn_s_setprio(1);                               // the heap wave is the contig's critical path
 #endif
         k2.lds = (char *)&L->hl;
-        kb_heap<true, HEAP_RING_CH, HEAP_QN_CH>(k2, w, &L->s);
+        kb_heap_ord<HEAP_RING_CH, HEAP_QN_CH>(k2, w, &L->s);
     }
 }
 

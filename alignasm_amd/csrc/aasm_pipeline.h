@@ -89,6 +89,7 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
 }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+#define AASM_CHAIN_ORD_MAX 896          // contigs of the chain class up to which its workgroups run the order wave (3.5 four-wave workgroups per CU)
 #define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups at 4 waves / SIMD)
 
 #ifndef AASM_GROUPED_MIN
@@ -119,6 +120,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     // the class's workgroups and the three launches of the others run beside each other)
     w.chain_mode = (opts.reserved[0] & 192) == 192 ? 0 : (opts.reserved[0] & 64) ? 1 : (opts.reserved[0] & 128) ? 2 : 0;
     w.chain_test = (opts.reserved[2] & 16) ? 2 : (opts.reserved[2] & 8) ? 1 : 0;
+    w.chain_ord = (opts.reserved[2] & 32) ? 0 : 1;                    // (bit 5: the heap wave of the chain class keeps its own BFS queue - probes, tests; decided below by the size of the class)
     w.chain_all = ((opts.reserved[0] & 192) != 192 && C <= AASM_CHAIN_SMALL_BATCH) ? 1 : 0;
     w.chain_minN = (int32_t)std::min<int64_t>(std::max<int64_t>(2048, 4 * (R / std::max<int64_t>(C, 1))), INT32_MAX);
     if ((opts.reserved[0] & 192) == 192) w.chain_minN = (int32_t)std::min<int64_t>(std::max<int64_t>(1, cdiv(R, std::max<int64_t>(C, 1))), INT32_MAX);
@@ -239,12 +241,15 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         const int64_t GB_S = et_mv[7], GB_L = et_mv[8], GB_REST = et_mv[9];   // contigs whose graph one workgroup builds (kb_graph_build, two forms) / the others
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
+        // the class's BFS order from a wave of its own while four waves a contig leave the SIMDs room (measured: 900 contigs 4.05 against 4.38 ms,
+        // 1 000 contigs - four workgroups on every CU, a second residency round for some - 5.32 against 4.55): beyond that the heap wave keeps its own queue
+        if (NCHAIN > AASM_CHAIN_ORD_MAX) w.chain_ord = 0;
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
         A(rptr, int64_t, VT + 1, "rptr"); A(r_pk, I4, ET, "r_pk");
         A(rvh, I4, 3 * VT, "rvh"); A(fvh, I4, 2 * VT, "fvh");
         A(sp_d, Dist, VT, "sp_d"); A(sp_best, int32_t, VT, "sp_best"); A(cnt_tmp, int32_t, VT, "cnt_tmp"); A(cnt_tmp2, int32_t, VT, "cnt_tmp2"); A(an, int32_t, VT, "an");
-        if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); }
+        if (NCHAIN > 0) { A(pend, int32_t, VT, "pend"); A(cq, int32_t, VT, "cq"); A(bfsq, I4, VT, "bfsq"); }
         // sparse, every contig small: rows, reversed CSR and the sweeps' headers of a contig by ONE workgroup (kb_graph_build)
         // the small contigs of a sparse batch: rows, reversed CSR and the sweeps' headers of a contig by ONE workgroup (kb_graph_build: kb_heap_cap
         // picked them); the others - dense batches, contigs of more than GB_MAXV_L vertices or GB_MAXE_L edges - by the separate launches, which

@@ -73,7 +73,10 @@ def test_chain_class_forms(T, case, chain):
     nc, nr, seed, K, dense, dup, shuf, heavy, nsl = case
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
     want = T.oracle_solve(hb, K, nsl)
-    got = T.emul_solve(hb, K, nsl, chain=chain)
+    got = T.emul_solve(hb, K, nsl, chain=chain, chain_own_queue=True)   # the heap wave with its own BFS queue (the form for classes of more than 896 contigs)
+    assert T.diff_outputs(want, got) == []
+    assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+    got = T.emul_solve(hb, K, nsl, chain=chain)                          # the order from a wave of its own (default)
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
     n_class = int(T.emul_debug("counters", np.int64)[17])

@@ -124,9 +124,11 @@ def test_chain_class_forms_leave_the_same_intermediates(T, case, chain):
     api = T.api()
     hb = T.synth(nc, nr, seed, dense=dense, dup_every=dup, shuffle=shuf, heavy_tail=heavy)
     db = api.DeviceBatch(hb)
-    res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, chain=chain)
-    assert T.diff_intermediates(hb, res.debug, K, nsl) == []
-    res.close(); db.close()
+    for own_queue in (True, False):                                 # the heap wave with its own BFS queue / the order from a wave of its own (default up to 896 contigs)
+        res = db.solve(max_paths=K, non_skip_linkable=nsl, keep_debug=True, chain=chain, chain_own_queue=own_queue)
+        assert T.diff_intermediates(hb, res.debug, K, nsl) == []
+        res.close()
+    db.close()
 
 
 def test_chain_class_beyond_one_residency_round_and_as_the_long_tail(T):
@@ -149,8 +151,9 @@ def test_chain_class_beyond_one_residency_round_and_as_the_long_tail(T):
     assert T.diff_outputs(want, got) == []
 
 
+@pytest.mark.parametrize("own_queue", [False, True], ids=["order_wave", "own_queue"])
 @pytest.mark.parametrize("how", [1, 2], ids=["header_never_comes", "prep_wave_never_reports"])
-def test_chain_class_waits_end_in_an_error_not_a_hang(T, how):
+def test_chain_class_waits_end_in_an_error_not_a_hang(T, how, own_queue):
     """Every wait of aasm_k67_chain has an exit every wave reaches.  Test hooks (opts.reserved[2] bits 3 / 4): the pre-pass wave of
     contig 0 never publishes the root's header - the heap wave learns from `prep_done` that it will not come; or it does not even
     report that it is done - the heap wave's own patience (1 s under the hook, 30 s otherwise) ends the wait.  Either way contig 0
@@ -160,7 +163,7 @@ def test_chain_class_waits_end_in_an_error_not_a_hang(T, how):
     hb = T.synth(12, 90, 7, dup_every=5)
     want = T.oracle_solve(hb, 16)
     t0 = time.time()
-    got = api.solve_batch(hb, max_paths=16, chain="all", test_chain_lost=how)
+    got = api.solve_batch(hb, max_paths=16, chain="all", test_chain_lost=how, chain_own_queue=own_queue)   # (the order wave waits for the header and gives up the same way; the heap wave learns it from `ord_done`)
     assert time.time() - t0 < 20
     assert got["status"][0] == -6 and (got["status"][1:] == 0).all()
     mo, ao = want["main_off"], want["alt_off"]

@@ -12,6 +12,7 @@ ap.add_argument("--input-order", type=int, default=0, help="1: K7's several-wave
 ap.add_argument("--grid-order", type=int, default=0, help="1: blocks take their work items in grid order (default: XCD by XCD)")
 ap.add_argument("--chain", default="auto", help="the chain class (aasm_k67_chain): auto / all / none")
 ap.add_argument("--graph-launches", type=int, default=0, help="1: rows, reversed CSR and sweep headers by the separate launches (default: one workgroup per contig where the contigs are small)")
+ap.add_argument("--chain-own-queue", type=int, default=0, help="1: the chain class's heap wave keeps its own BFS queue (default: the order comes from a wave of its own)")
 ap.add_argument("--cs", type=int, default=0, help="1: the batch carries cs tags and the device derives the match ranges (K0)")
 a = ap.parse_args()
 t = time.time()
@@ -25,7 +26,7 @@ else:
     print("gen %.2fs records=%d ranges=%d" % (time.time() - t, hb.view.n_records, hb.view.n_ranges), flush=True)
 t = time.time(); db = A.DeviceBatch(hb); print("upload %.2fs" % (time.time() - t), flush=True)
 for r in range(a.reps):
-    t = time.time(); res = db.solve(max_paths=a.k, timing=True, heap_input_order=bool(a.input_order), grid_order=bool(a.grid_order), chain=a.chain, graph_launches=bool(a.graph_launches)); wall = time.time() - t
+    t = time.time(); res = db.solve(max_paths=a.k, timing=True, heap_input_order=bool(a.input_order), grid_order=bool(a.grid_order), chain=a.chain, graph_launches=bool(a.graph_launches), chain_own_queue=bool(a.chain_own_queue)); wall = time.time() - t
     st = res.stats(); res.close()
     ph = {k: round(v, 3) for k, v in st["phase_ms"].items() if v > 0}
     print(json.dumps({"rep": r, "wall_ms": round(wall * 1e3, 2), "total_ms": round(st["total_ms"], 3), "phases": ph,
