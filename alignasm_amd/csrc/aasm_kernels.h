@@ -2804,18 +2804,22 @@ AASM_DEV void kb_heap(const KCtx &k, const WS &w, ChainSync *S = nullptr) {   //
 // while the rest of the chip idles).  Nothing in the data says they have to: a vertex's distance and tree edge are final the
 // moment the sweep APPENDS it to its queue (every out-edge relaxed: k_shortest_walks.hpp:160-175), its sidetrack keys need only
 // that and the distances of its heads (final earlier), and the heap of a vertex needs its parent's heap and its own keys
-// (:196-215).  So a workgroup of three waves takes a contig:
+// (:196-215).  So a workgroup takes a contig, a wave per role (four since the BFS order has a wave of its own: chain_order, below;
+// classes of more than AASM_CHAIN_ORD_MAX contigs keep the three-role form, where wave 2 is the heap wave with its own queue):
 //   wave 0  the reverse sweep as before (kb_rev_sweep), which now also publishes how many vertices of rev_order are final;
 //   wave 1  the pre-pass, lanes over vertices, behind it: for the vertices that became final - their sidetrack keys (what
 //           kb_sidetrack does), then one count-down per out-edge on the head's `pend`; a vertex whose in-neighbours ALL have their
 //           keys gets its child list and header (kb_children + kb_heap_hdr: the children of u are in-neighbours of u) - these
 //           go through a work list (cq) and are published by the header's two marker words turning from -1;
-//   wave 2  the heaps in the reference's BFS order, exactly kb_heap (same arena, same indices), which waits for a header only
-//           where the one-launch form could assume it.
+//   wave 2  the BFS order of the tree: one record {vertex, parent's position, keys} per position (chain_order); it is the one that
+//           waits for headers;
+//   wave 3  the heaps in that order (kb_heap_ord: kb_heap's inserts, same arena, same indices) - or, three-role form, wave 2 =
+//           kb_heap itself, which waits for a header only where the one-launch form could assume it.
 // The graphs are local (edges join neighbouring parts, paf_data.cpp:599-694), so a vertex's in-neighbours are final soon after
 // it: the heap wave - the slowest of the three - finds what it needs and the contig costs max(K6, K7) instead of the sum.
-// Every wait ends: the sweep waits for nobody; the pre-pass only for the sweep (`sweep_done`); the heap wave only for the
-// pre-pass (`prep_done`), and gives up with AASM_E_INTERNAL after 30 s rather than sit.
+// Every wait ends: the sweep waits for nobody; the pre-pass only for the sweep (`sweep_done`); the order wave only for the
+// pre-pass (`prep_done`) and the heap wave only for the order wave (`ord_done`) - each gives up with AASM_E_INTERNAL after 30 s
+// rather than sit.
 #define AASM_CHAIN_LDS_BYTES (AASM_REV_LDS_BYTES + AASM_HEAP_LDS_BYTES_T(HEAP_RING_CH, HEAP_QN_CH) + 32)
 #define CHAIN_WAVES 4
 #define CHAIN_LONG_ROW 8
