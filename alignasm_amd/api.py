@@ -105,14 +105,14 @@ def reserve_workspace(device=0, nbytes=0):
 
 
 def make_opts(max_paths=10000, non_skip_linkable=False, device=0, timing=False, keep_debug=False, sequential_select=False,
-              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False, test_dirty_scan=False, chain="auto", test_chain_lost=0, graph_launches=False, chain_own_queue=False):
+              test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, enum_small=False, sort_depth_test=0, heap_input_order=False, heap_block_waves=0, grid_order=False, test_dirty_scan=False, chain="auto", test_chain_lost=0, graph_launches=False, chain_own_queue=False, test_small_root_ring=False):
     o = Opts(int(max_paths), 1 if non_skip_linkable else 0, int(device), 1 if timing else 0, 1 if keep_debug else 0)
     # bit 0: force the one-wave-per-contig selection kernel; bits 1 / 2: K7 with several waves per contig for every contig / for none
     # bit 3: K8 with the d-ary heap queue instead of the sorted-front / sorted-runs queue (cross-check of the two)
     # bits 6 / 7: the chain class (aasm_k67_chain: a contig's sweep, pre-pass and heaps beside each other) for every sparse contig / for none
     o.reserved[0] = (1 if sequential_select else 0) | {"auto": 0, "all": 2, "none": 4}[heap_waves] | (8 if enum_heap else 0) | (16 if enum_small else 0) | (32 if grid_order else 0) | {"auto": 0, "all": 64, "none": 128, "half": 192}[chain] | ((1 << 8) if heap_input_order else (int(heap_block_waves) << 8)) | ((1 << 16) if graph_launches else 0)   # bit 16: rows, reversed CSR and sweep headers by the separate launches even where one workgroup per contig would do (aasm_k46_graph); bits 8-15: 1 = K7's several-waves class in input order instead of largest first; 4 / 8 / 16 = that many waves per contig of it
     o.reserved[1] = int(test_max_contigs)              # test hook: longer contig ranges "do not fit" (range split)
-    o.reserved[2] = (1 if test_inject_launch_failure else 0) | (2 if wrap_devices else 0) | (4 if test_dirty_scan else 0) | (8 if test_chain_lost == 1 else 16 if test_chain_lost == 2 else 0) | (32 if chain_own_queue else 0) | ((int(sort_depth_test) & 0xff) << 8)   # bit 1: shards wrap around the devices that exist
+    o.reserved[2] = (1 if test_inject_launch_failure else 0) | (2 if wrap_devices else 0) | (4 if test_dirty_scan else 0) | (8 if test_chain_lost == 1 else 16 if test_chain_lost == 2 else 0) | (32 if chain_own_queue else 0) | (64 if test_small_root_ring else 0) | ((int(sort_depth_test) & 0xff) << 8)   # bit 1: shards wrap around the devices that exist
     return o
 
 
@@ -204,10 +204,10 @@ def free_out(out: BatchOut):
 
 
 def solve_batch(batch, max_paths=10000, non_skip_linkable=False, device=0, timing=False, n_devices=1, sequential_select=False,
-                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, heap_input_order=False, test_dirty_scan=False, chain="auto", test_chain_lost=0, graph_launches=False, chain_own_queue=False):
+                test_max_contigs=0, test_inject_launch_failure=False, heap_waves="auto", enum_heap=False, wrap_devices=False, heap_input_order=False, test_dirty_scan=False, chain="auto", test_chain_lost=0, graph_launches=False, chain_own_queue=False, test_small_root_ring=False):
     """solve_ctg_read over a batch (HostBatch or Paf).  Returns a dict of numpy arrays."""
     view = batch.view if isinstance(batch, HostBatch) else batch.view()
-    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap, wrap_devices, heap_input_order=heap_input_order, test_dirty_scan=test_dirty_scan, chain=chain, test_chain_lost=test_chain_lost, graph_launches=graph_launches, chain_own_queue=chain_own_queue)
+    opts = make_opts(max_paths, non_skip_linkable, device, timing, False, sequential_select, test_max_contigs, test_inject_launch_failure, heap_waves, enum_heap, wrap_devices, heap_input_order=heap_input_order, test_dirty_scan=test_dirty_scan, chain=chain, test_chain_lost=test_chain_lost, graph_launches=graph_launches, chain_own_queue=chain_own_queue, test_small_root_ring=test_small_root_ring)
     if n_devices > 1:
         out = BatchOut()
         _check(LIB.aasm_solve_batch_multi(C.byref(view), C.byref(opts), int(n_devices), C.byref(out)))

@@ -132,6 +132,7 @@ struct WS {
     int32_t *cq;                         // per contig slice: vertices whose header can be built, in the order they became ready
     I4 *bfsq;                            // per contig slice: the SP tree in BFS order, a record {vertex, position of its parent, start of its keys, #keys} per position (kb_chain's order wave -> heap wave)
     int32_t chain_ord;                   // kb_chain: 1 = the BFS order comes from a wave of its own (default), 0 = the heap wave keeps its own queue (probes, tests)
+    int32_t chain_rn;                    // test hook (opts.reserved[2] bit 6): kb_heap_ord's ring of roots has this many entries (default 0: all 512), so that parents beyond it - frontiers wider than the ring - come up on small inputs
 };
 
 enum { CNT_RANGE_STEPS = 0, CNT_UNCONN, CNT_POOL, CNT_AR, CNT_CONVERTED, CNT_HEAPNODES, CNT_PATHS, CNT_OVF, CNT_ISPR_E, CNT_ISPR_V, CNT_PATH_E, CNT_OUT_E, CNT_PQ_PUSH, CNT_MW, CNT_MAXN, CNT_LONGSORT, CNT_MAXV, CNT_CHAIN, CNT_GB_S, CNT_GB_L, CNT_GB_REST, CNT_N };
@@ -2988,7 +2989,7 @@ AASM_DEV void kb_heap_ord(const KCtx &k, const WS &w, ChainSync *S) {
     const Dist *sk = w.st_cost + w.rowptr[vb];
     const I4 *q = w.bfsq + vb;
     int32_t *rroot = (int32_t *)L->bq;                               // roots of the newest RN positions
-    constexpr int32_t RN = QN * 4;
+    const int32_t RN = w.chain_rn > 0 ? w.chain_rn : QN * 4;         // (a power of two)
     HeapState hs;
     hs.nodes = w.hnodes + w.hoff[c]; hs.ring = L->ring; hs.rn = RING; hs.bounce = &L->bounce; hs.oldn = L->oldn; hs.alloc = 0; hs.flushed = 0; hs.ring_lo = 0; hs.ovf = false;
     hs.cap = (int32_t)(w.hoff[c + 1] - w.hoff[c]);

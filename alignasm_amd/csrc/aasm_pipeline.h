@@ -120,6 +120,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
     // the class's workgroups and the three launches of the others run beside each other)
     w.chain_mode = (opts.reserved[0] & 192) == 192 ? 0 : (opts.reserved[0] & 64) ? 1 : (opts.reserved[0] & 128) ? 2 : 0;
     w.chain_test = (opts.reserved[2] & 16) ? 2 : (opts.reserved[2] & 8) ? 1 : 0;
+    w.chain_rn = (opts.reserved[2] & 64) ? 4 : 0;                     // (bit 6, tests: a 4-entry ring of roots in the chain class's heap wave)
     w.chain_ord = (opts.reserved[2] & 32) ? 0 : 1;                    // (bit 5: the heap wave of the chain class keeps its own BFS queue - probes, tests; decided below by the size of the class)
     w.chain_all = ((opts.reserved[0] & 192) != 192 && C <= AASM_CHAIN_SMALL_BATCH) ? 1 : 0;
     w.chain_minN = (int32_t)std::min<int64_t>(std::max<int64_t>(2048, 4 * (R / std::max<int64_t>(C, 1))), INT32_MAX);

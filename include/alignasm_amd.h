@@ -109,6 +109,8 @@ typedef struct aasm_opts {
                                 *     bit 3: the chain class's pre-pass wave of contig 0 never publishes the root's header (the contig must end with
                                 *            AASM_E_INTERNAL, nothing may hang); bit 4: ... and never reports that it is done (the heap wave gives up
                                 *            after 1 s instead of its 30 s);
+                                *     bit 5: the chain class's heap wave keeps its own BFS queue (default: the order comes from a wave of its
+                                *            own while the class has at most 896 contigs); bit 6: its ring of parents' roots has 4 entries, not 512;
                                 *     bits 8-15: d + 1 = the sort replay of duplicate-key contigs takes its heap sort
                                 *            fallback after d partition levels instead of 2 lg N                          */
 } aasm_opts;

@@ -300,10 +300,10 @@ def oracle_solve(hb: HostBatch, K=10000, nsl=False, threads=4):
         oracle().oracle_free_out(C.byref(out))
 
 
-def emul_solve(hb: HostBatch, K=10000, nsl=False, sequential_select=False, heap_waves="auto", heap_input_order=False, chain="auto", graph_launches=False, chain_own_queue=False):
+def emul_solve(hb: HostBatch, K=10000, nsl=False, sequential_select=False, heap_waves="auto", heap_input_order=False, chain="auto", graph_launches=False, chain_own_queue=False, test_small_root_ring=False):
     o = Opts(int(K), 1 if nsl else 0, 0, 0, 1)
     o.reserved[0] = (1 if sequential_select else 0) | {"auto": 0, "all": 2, "none": 4}[heap_waves] | ((1 << 8) if heap_input_order else 0) | {"auto": 0, "all": 64, "none": 128, "half": 192}[chain] | ((1 << 16) if graph_launches else 0)
-    o.reserved[2] = 32 if chain_own_queue else 0
+    o.reserved[2] = (32 if chain_own_queue else 0) | (64 if test_small_root_ring else 0)
     out = BatchOut()
     rc = emul().emul_solve_batch(C.byref(hb.view), C.byref(o), C.byref(out))
     assert rc == 0, rc

@@ -79,6 +79,9 @@ def test_chain_class_forms(T, case, chain):
     got = T.emul_solve(hb, K, nsl, chain=chain)                          # the order from a wave of its own (default)
     assert T.diff_outputs(want, got) == []
     assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
+    got = T.emul_solve(hb, K, nsl, chain=chain, test_small_root_ring=True)   # ... with a 4-entry ring of roots: parents beyond it (h_root), as on frontiers wider than 512
+    assert T.diff_outputs(want, got) == []
+    assert T.diff_intermediates(hb, T.emul_debug, K, nsl) == []
     n_class = int(T.emul_debug("counters", np.int64)[17])
     sizes = np.diff(hb.arrays["ctg_rec_off"])
     if chain == "none" or dense:

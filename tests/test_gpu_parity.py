@@ -113,6 +113,8 @@ def test_chain_class_forms_match_oracle(T, case, chain):
     want = T.oracle_solve(hb, K, nsl)
     got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, chain=chain)
     assert T.diff_outputs(want, got) == []
+    got = api.solve_batch(hb, max_paths=K, non_skip_linkable=nsl, chain=chain, test_small_root_ring=True)   # (a 4-entry ring of roots in the class's heap wave: parents beyond it come from h_root, as on frontiers wider than 512)
+    assert T.diff_outputs(want, got) == []
 
 
 @pytest.mark.parametrize("chain", ["none", "half", "all"])
