@@ -84,7 +84,8 @@ AASM_DEF_KERNEL(aasm_k9_tnx, KN_TNX, 256)
 AASM_DEF_KERNEL(aasm_k9_tnx16, KN_TNX16, 256)
 AASM_DEF_KERNEL_LDS(aasm_k9_tnx16_wg, KN_TNX16_WG, TNX_TPB, AASM_TNXWG_LDS_BYTES, 4)   // the 16-hop jump records of a small contig from its tree in LDS
 AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
-AASM_DEF_KERNEL_LDS(aasm_k67_chain, KN_CHAIN, 64 * CHAIN_WAVES, AASM_CHAIN_LDS_BYTES, 4)   // sweep + pre-pass + heaps of one contig, a wave each
+AASM_DEF_KERNEL_LDS(aasm_k67_chain, KN_CHAIN, 64 * CHAIN_WAVES, AASM_CHAIN_LDS_BYTES, 4)   // sweep + pre-pass + BFS order + heaps of one contig, a wave each
+AASM_DEF_KERNEL_LDS(aasm_k67_chain3, KN_CHAIN3, 64 * (CHAIN_WAVES - 1), AASM_CHAIN_LDS_BYTES, 4)   // ... without the order wave (the heap wave keeps its own queue): classes of more than 896 contigs
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw, KN_HEAP_MW, 256, AASM_MW_LDS_BYTES(4), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw8, KN_HEAP_MW8, 512, AASM_MW_LDS_BYTES(8), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw16, KN_HEAP_MW16, 1024, AASM_MW_LDS_BYTES(16), 4)
@@ -683,7 +684,7 @@ struct GpuBackend {
             L(KN_CHILDREN, aasm_k7_children)
             L(KN_HEAP_CAP, aasm_k7_heap_cap) L(KN_SIDETRACK, aasm_k7_sidetrack) L(KN_SIDETRACK_W, aasm_k7_sidetrack_w) L(KN_HEAP_HDR, aasm_k7_heap_hdr) L(KN_HEAP, aasm_k7_heap) L(KN_HEAP_MW, aasm_k7_heap_mw) L(KN_HEAP_MW8, aasm_k7_heap_mw8) L(KN_HEAP_MW16, aasm_k7_heap_mw16) L(KN_MW_RANK, aasm_k7_mw_rank) L(KN_ENUM, aasm_k8_enum) L(KN_ENUM_S, aasm_k8_enum_s) L(KN_ENUM_HEAP, aasm_k8_enum_heap) L(KN_SELECT, aasm_k9_select)
             L(KN_GATHER_OUT, aasm_k9_gather_out) L(KN_TOPO_COUNT, aasm_k9_topo_count) L(KN_TOPO_FILL, aasm_k9_topo_fill)
-            L(KN_CHAIN, aasm_k67_chain) L(KN_K7_PREP, aasm_k7_prep) L(KN_TNX, aasm_k9_tnx) L(KN_TNX16, aasm_k9_tnx16) L(KN_TNX16_WG, aasm_k9_tnx16_wg)
+            L(KN_CHAIN, aasm_k67_chain) L(KN_CHAIN3, aasm_k67_chain3) L(KN_K7_PREP, aasm_k7_prep) L(KN_TNX, aasm_k9_tnx) L(KN_TNX16, aasm_k9_tnx16) L(KN_TNX16_WG, aasm_k9_tnx16_wg)
             L(KN_SEL_PLAN, aasm_k9_sel_plan) L(KN_SEL_PLANFILL, aasm_k9_sel_planfill) L(KN_SEL_RECOVER, aasm_k9_sel_recover) L(KN_SEL_CLASSIFY, aasm_k9_sel_classify) L(KN_SEL_CONVERT, aasm_k9_sel_convert) L(KN_SEL_FINAL, aasm_k9_sel_final)
 #undef L
             default: break;

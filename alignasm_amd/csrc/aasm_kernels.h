@@ -3111,7 +3111,10 @@ AASM_DEV const WS &chain_role_ws(const WS &) {
     return *p;
 }
 #endif
-AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAVES waves per contig of the class
+// (two kernels, so that each form's heap wave gets the register allocation of ITS roles: with both forms in one kernel the heap role ran
+// with 15 scalars spilled and classes of 1 000-1 280 contigs lost 3-4 %)
+template <bool ORD>
+AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // ORD: four waves per contig of the class (sweep, pre-pass, order, heaps); else three (the heap wave keeps its own queue)
     ChainLds *L = (ChainLds *)k.lds;
     const int64_t c = w.chain_list[k.bid];
     const int wv = k.tid / AASM_WAVE;
@@ -3125,15 +3128,15 @@ AASM_DEV void kb_chain(const KCtx &k, const WS &w) {                // CHAIN_WAV
     } else if (wv == 1) {
         chain_prep(k2, chain_role_ws(w), c, &L->s);
     } else if (wv == 2) {
-        if (w.chain_ord) chain_order(k2, chain_role_ws(w), c, &L->s);
-        else {                                                       // (probes, tests: the heap wave with its own queue, no order wave)
+        if (ORD) chain_order(k2, chain_role_ws(w), c, &L->s);
+        else {                                                       // (classes of more than AASM_CHAIN_ORD_MAX contigs, probes, tests: the heap wave with its own queue, no order wave)
 #if !defined(AASM_HOST_EMUL)
             __builtin_amdgcn_s_setprio(1);
 #endif
             k2.lds = (char *)&L->hl;
             kb_heap<true, HEAP_RING_CH, HEAP_QN_CH>(k2, w, &L->s);
         }
-    } else if (w.chain_ord) {
+    } else if (ORD) {
 #if !defined(AASM_HOST_EMUL)
         __builtin_amdgcn_s_setprio(1);                               // the heap wave is the contig's critical path
 #endif

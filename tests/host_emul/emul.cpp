@@ -56,6 +56,7 @@ struct EmuBackend {
             case KN_SORT_FIX: case KN_GATHER_PARTS: case KN_ROW_FILL: case KN_GRAPH: case KN_GRAPH_L: case KN_TNX16_WG: case KN_SORT_ROWS_REV: case KN_REV_FILL_W: case KN_REV_FILL_ORD: case KN_REV_FILL_ORD_S: case KN_SIDETRACK_W:
             case KN_REV_SWEEP: case KN_FWD_SWEEP: case KN_REV_SWEEP_G: case KN_FWD_SWEEP_G: case KN_HEAP: case KN_HEAP_MW: case KN_HEAP_MW8: case KN_HEAP_MW16: case KN_ENUM: case KN_SELECT: case KN_GATHER_OUT: case KN_TOPO_FILL: case KN_SEL_RECOVER: case KN_SEL_CONVERT: case KN_SEL_FINAL: case KN_SEL_PLAN: case KN_SEL_PLANFILL:
                 return 1;
+            case KN_CHAIN3: return CHAIN_WAVES - 1;
             case KN_CHAIN: return CHAIN_WAVES;          // one "thread" per wave, in wave order: the sweep runs to its end, then the pre-pass, then the heaps
             default: return nthreads;
         }
