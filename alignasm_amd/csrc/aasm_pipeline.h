@@ -243,8 +243,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         const int64_t GB_S = et_mv[7], GB_L = et_mv[8], GB_REST = et_mv[9];   // contigs whose graph one workgroup builds (kb_graph_build, two forms) / the others
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
-        // the class's BFS order from a wave of its own while four waves a contig leave the SIMDs room (measured: 900 contigs 4.05 against 4.38 ms,
-        // 1 000 contigs - four workgroups on every CU, a second residency round for some - 5.32 against 4.55): beyond that the heap wave keeps its own queue
+        // the class's BFS order from a wave of its own while four waves a contig fit the chip at once (four workgroups per CU: 896 contigs 4.08
+        // against 4.27 ms; 1 000-1 280 contigs need five per CU): beyond that the three-role kernel, where the heap wave keeps its own queue
         if (NCHAIN > AASM_CHAIN_ORD_MAX) w.chain_ord = 0;
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");
@@ -334,7 +334,7 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
             be.use_side2(true);
             be.phase_begin(AASM_PH_CHAIN);
             if (w.chain_ord) be.launch(KN_CHAIN, NCHAIN, AASM_WAVE * CHAIN_WAVES, w);
-            else be.launch(KN_CHAIN3, NCHAIN, AASM_WAVE * (CHAIN_WAVES - 1), w);   // (no order wave: three waves a contig, five workgroups a CU - four with it; 1 250 contigs 4.6 against 6.0 ms)
+            else be.launch(KN_CHAIN3, NCHAIN, AASM_WAVE * (CHAIN_WAVES - 1), w);   // (no order wave: three waves a contig, five workgroups a CU; 1 250 contigs 4.6 ms where four-wave workgroups took 6.0)
             be.phase_end(AASM_PH_CHAIN);
             be.use_side2(false);
         }
