@@ -84,8 +84,8 @@ AASM_DEF_KERNEL(aasm_k9_tnx, KN_TNX, 256)
 AASM_DEF_KERNEL(aasm_k9_tnx16, KN_TNX16, 256)
 AASM_DEF_KERNEL_LDS(aasm_k9_tnx16_wg, KN_TNX16_WG, TNX_TPB, AASM_TNXWG_LDS_BYTES, 4)   // the 16-hop jump records of a small contig from its tree in LDS
 AASM_DEF_KERNEL_LDS(aasm_k7_heap, KN_HEAP, 64, AASM_HEAP_LDS_BYTES, 5)
-AASM_DEF_KERNEL_LDS(aasm_k67_chain, KN_CHAIN, 64 * CHAIN_WAVES, AASM_CHAIN_LDS_BYTES, 4)   // sweep + pre-pass + BFS order + heaps of one contig, a wave each
-AASM_DEF_KERNEL_LDS(aasm_k67_chain3, KN_CHAIN3, 64 * (CHAIN_WAVES - 1), AASM_CHAIN_LDS_BYTES, 4)   // ... without the order wave (the heap wave keeps its own queue): classes of more than 896 contigs
+AASM_DEF_KERNEL_LDS(aasm_k67_chain, KN_CHAIN, 64 * CHAIN_WAVES, AASM_CHAIN_LDS_BYTES, 5)   // sweep + pre-pass + BFS order + heaps of one contig, a wave each (96 VGPRs, 19 spilled: worth it for the fifth wave slot per SIMD)
+AASM_DEF_KERNEL_LDS(aasm_k67_chain3, KN_CHAIN3, 64 * (CHAIN_WAVES - 1), AASM_CHAIN_LDS_BYTES, 5)   // ... without the order wave (the heap wave keeps its own queue): classes of more than 896 contigs
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw, KN_HEAP_MW, 256, AASM_MW_LDS_BYTES(4), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw8, KN_HEAP_MW8, 512, AASM_MW_LDS_BYTES(8), 4)
 AASM_DEF_KERNEL_LDS(aasm_k7_heap_mw16, KN_HEAP_MW16, 1024, AASM_MW_LDS_BYTES(16), 4)

@@ -90,8 +90,10 @@ AASM_DEV void run_kernel_body(int kn, const KCtx &k, const WS &w) {
 }
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-#define AASM_CHAIN_ORD_MAX 896          // contigs of the chain class up to which its workgroups run the order wave (3.5 four-wave workgroups per CU)
-#define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups at 4 waves / SIMD)
+#ifndef AASM_CHAIN_ORD_MAX
+#define AASM_CHAIN_ORD_MAX 1024         // contigs of the chain class up to which its workgroups run the order wave (four four-wave workgroups per CU; measured: 1 000 contigs 4.28 against 4.40 ms, 1 150 contigs 5.3 against 4.58)
+#endif
+#define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups; the kernels are held to 96 VGPRs - 5 waves / SIMD - so that the forward sweep beside them finds slots: at 4 waves / SIMD a 1 250-contig class took a second round, 5.55 against 4.64 ms)
 
 #ifndef AASM_GROUPED_MIN
 #define AASM_GROUPED_MIN 2560
@@ -243,8 +245,8 @@ int run_pipeline(B &be, const aasm_batch_in &in, const aasm_opts &opts, WS &w, P
         const int64_t GB_S = et_mv[7], GB_L = et_mv[8], GB_REST = et_mv[9];   // contigs whose graph one workgroup builds (kb_graph_build, two forms) / the others
         const int64_t hh[4] = {et_mv[2], et_mv[3], et_mv[4], et_mv[5]};
         const int64_t NCHAIN = et_mv[6];
-        // the class's BFS order from a wave of its own while four waves a contig fit the chip at once (four workgroups per CU: 896 contigs 4.08
-        // against 4.27 ms; 1 000-1 280 contigs need five per CU): beyond that the three-role kernel, where the heap wave keeps its own queue
+        // the class's BFS order from a wave of its own while four waves a contig fit the chip beside the forward sweep (four workgroups per CU);
+        // beyond that the three-role kernel, where the heap wave keeps its own queue
         if (NCHAIN > AASM_CHAIN_ORD_MAX) w.chain_ord = 0;
         w.ET = ET; sz.ET = ET;
         A(e_col, int32_t, ET, "csr_col"); A(e_wq, int64_t, ET, "csr_w_qry"); A(e_wr, int32_t, ET, "csr_w_ref"); A(e_fl, uint8_t, ET, "csr_w_flags");

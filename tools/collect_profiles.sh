@@ -22,7 +22,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc5_write -
 python3 $R/tools/pmc_summary.py $O/${TAG}_c5_pmc_fetch_write.json $O/pmc5_fetch $O/pmc5_write
 cp $O/${TAG}_c5_pmc_fetch_write.json $R/profiles/          # (bench.py reads roofline.traffic from profiles/)
 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --cpu-sample 200 > $O/${TAG}_c5_bench_file_1gpu.json 2> $O/c5.err || exit 1
-for n in 1 250 625 1000 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
+for n in 1 250 625 1000 1250 2500; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n$n.json; done
+for n in 1 625; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 --chain-own-queue 1 2>&1 | tail -n 1 > $O/${TAG}_probe_n${n}_own_queue.json; done   # the chain class without the order wave (aasm_k67_chain3)
 for n in 1 250 625 1000; do python3 $R/tools/phase_probe.py --contigs $n --reps 3 --chain none 2>&1 | tail -n 1 > $O/${TAG}_probe_n${n}_three_launches.json; done   # the chain class off: K6, pre-pass, K7 one after the other
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 --graph-launches 1 2>&1 | tail -n 1 > $O/${TAG}_probe_c3_graph_by_separate_launches.json   # aasm_k46_graph off: row_fill, scan, rev_fill, rev_place, rev_hdr
 python3 $R/tools/phase_probe.py --contigs 5000 --reps 3 2>&1 | tail -n 1 > $O/${TAG}_probe_n5000.json
