@@ -93,7 +93,7 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 #ifndef AASM_CHAIN_ORD_MAX
 #define AASM_CHAIN_ORD_MAX 1024         // contigs of the chain class up to which its workgroups run the order wave (four four-wave workgroups per CU; measured: 1 000 contigs 4.28 against 4.40 ms, 1 150 contigs 5.3 against 4.58)
 #endif
-#define AASM_CHAIN_SMALL_BATCH 1280      // contigs: up to here every workgroup of the class is resident at once (256 CUs x 5 three-wave workgroups; the kernels are held to 96 VGPRs - 5 waves / SIMD - so that the forward sweep beside them finds slots: at 4 waves / SIMD a 1 250-contig class took a second round, 5.55 against 4.64 ms)
+#define AASM_CHAIN_SMALL_BATCH 1536      // contigs: up to here every contig of a sparse batch is in the class.  1 280 workgroups are resident at once (256 CUs x 5 three-wave workgroups; the kernels are held to 96 VGPRs - 5 waves / SIMD - so that the forward sweep beside them finds slots: at 4 waves / SIMD a 1 250-contig class took a second round, 5.55 against 4.64 ms); a partial second round still beats the three launches up to ~1 600 contigs (measured: 1 400 contigs 4.85 against 6.3 ms, 1 500: 5.9 / 6.5, 1 600: 6.55 / 6.64, 1 800: 6.7 / 6.8, 2 200: 7.4 / 7.2)
 
 #ifndef AASM_GROUPED_MIN
 #define AASM_GROUPED_MIN 2560

@@ -101,7 +101,7 @@ def test_graph_build_forms(T, case):
 
 
 # ---- the chain class (aasm_k67_chain: sweep, pre-pass and heaps of a contig beside each other).  By default it takes every sparse
-# contig of a batch of <= 1 280 contigs - i.e. every sparse case above - and the long tail of bigger ones; here the other forms
+# contig of a batch of <= 1 536 contigs - i.e. every sparse case above - and the long tail of bigger ones; here the other forms
 @pytest.mark.parametrize("chain", ["none", "half", "all"])
 @pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9], CASES[11], CASES[14], CASES[16]], ids=_id)
 def test_chain_class_forms_match_oracle(T, case, chain):
@@ -140,7 +140,7 @@ def test_chain_class_beyond_one_residency_round_and_as_the_long_tail(T):
     hb = T.synth(3000, 30, 5, dup_every=6)
     want = T.oracle_solve(hb, 4)
     assert T.diff_outputs(want, api.solve_batch(hb, max_paths=4, chain="all")) == []
-    hb = T.synth(1400, 300, 9, heavy_tail=True)                      # 420 k records, the longest contigs ~2 400: the default rule picks a handful
+    hb = T.synth(1700, 300, 9, heavy_tail=True)                      # 510 k records in more contigs than the every-contig rule takes (1 536), the longest ~2 400: the default rule picks a handful
     sizes = np.diff(hb.arrays["ctg_rec_off"])
     assert 0 < (sizes >= max(2048, 4 * 300)).sum() < 40
     want = T.oracle_solve(hb, 4)
